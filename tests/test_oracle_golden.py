@@ -1,0 +1,108 @@
+"""CPU (`-m "not gpu"`): the oracle against the fixtures generated from the imported reference.
+
+What this pins: the oracle's restatement of LearnedIndex.search (routing, per-rank scan, id
+mapping, <k padding, stable merge) == the reference's own Python, on G1/G3/G4/G5/G6.  The fp32
+summation order inside torch / faiss (BLAS) differs from the oracle's canonical fmaf chain, so
+ids are compared modulo reference near-ties (< 2e-6) and distances to 1e-4 relative.
+"""
+import numpy as np
+import pytest
+
+from helpers import compare_modulo_near_ties, inputs_for, layers_from, load_golden
+
+ONE_LEVEL = ["G1", "G3", "G4", "G5", "G6"]
+
+
+@pytest.mark.parametrize("name", ONE_LEVEL)
+def test_bucket_order_matches_reference(oracle, name):
+    g = load_golden(name)
+    Xn, Qn, Xs, Qs = inputs_for(name, g)
+    nb = int(g["n_buckets"])
+    assert g["min_logit_gap"] > 1e-4  # torch-vs-chain noise is ~1e-6: exact equality expected
+    bo = oracle.precompute_bucket_order(layers_from(g), Qn, nb)
+    np.testing.assert_array_equal(bo, g["ref_bucket_order"])
+    np.testing.assert_array_equal(bo[:, :, 0], g["ref_classes_top"])
+    probs, classes = oracle.predict_proba(layers_from(g), Qn)
+    np.testing.assert_array_equal(classes[:, :nb], g["ref_classes_top"])
+    np.testing.assert_allclose(probs[:, :nb], g["ref_probs_top"], rtol=2e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ONE_LEVEL)
+def test_search_matches_reference(oracle, name):
+    g = load_golden(name)
+    Xn, Qn, Xs, Qs = inputs_for(name, g)
+    nb, k = int(g["n_buckets"]), int(g["k"])
+    d, n, bo = oracle.search(layers_from(g), Qn, Xs, Qs, g["data_prediction"], nb, k, nthreads=4)
+    assert d.dtype == np.float64 and n.dtype == np.uint32 and d.shape == n.shape == (Qs.shape[0], k)
+    ndiff = compare_modulo_near_ties(g["ref_dists"], g["ref_nns"], d, n)
+    assert ndiff <= 0.002 * n.size
+    # per-rank outputs of _search_single_bucket
+    groups = oracle.group_buckets(g["data_prediction"])
+    ids = np.arange(1, Xs.shape[0] + 1)
+    for r in range(nb):
+        dr, nr = oracle.search_single_bucket(Xs, ids, groups, Qs, bo[:, r, :], nthreads=4)
+        compare_modulo_near_ties(g["ref_rank_dists"][r], g["ref_rank_nns"][r], dr, nr)
+
+
+def test_edge_cases_G4(oracle):
+    g = load_golden("G4")
+    Xn, Qn, Xs, Qs = inputs_for("G4", g)
+    layers = layers_from(g)
+    dp = g["data_prediction"]
+    short_b, empty_b = int(g["short_bucket"]), int(g["empty_bucket"])
+    assert (dp[:, 0] == short_b).sum() == 3 and (dp[:, 0] == empty_b).sum() == 0
+    d, n, bo = oracle.search(layers, Qn, Xs, Qs, dp, 4, 10)
+    # the fixture really exercises the edge cases
+    assert (bo[:, :, 0] == short_b).any() and (bo[:, :, 0] == empty_b).any()
+    groups = oracle.group_buckets(dp)
+    ids = np.arange(1, Xs.shape[0] + 1)
+    r_s, q_s = [(r, q) for r in range(4) for q in np.where(bo[:, r, 0] == short_b)[0]][0]
+    dr, nr = oracle.search_single_bucket(Xs, ids, groups, Qs, bo[:, r_s, :])
+    last_label = np.where(dp[:, 0] == short_b)[0][-1] + 1
+    assert np.all(dr[q_s, 3:] == np.float64(np.float32(1) + np.finfo(np.float32).max))  # Q4 padding
+    assert np.all(nr[q_s, 3:] == last_label)
+    r_e, q_e = [(r, q) for r in range(4) for q in np.where(bo[:, r, 0] == empty_b)[0]][0]
+    dr, nr = oracle.search_single_bucket(Xs, ids, groups, Qs, bo[:, r_e, :])
+    assert np.all(np.isinf(dr[q_e])) and np.all(nr[q_e] == 0)                        # Q2 unvisited
+    # k != 10 variants (Q3)
+    for tag, nb, k in (("nb1_k5", 1, 5), ("nb3_k5", 3, 5), ("nb3_k15", 3, 15), ("nb12_k10", 12, 10)):
+        d, n, _ = oracle.search(layers, Qn, Xs, Qs, dp, nb, k)
+        assert d.shape == g[f"{tag}_dists"].shape
+        compare_modulo_near_ties(g[f"{tag}_dists"], g[f"{tag}_nns"], d, n)
+    assert bool(g["k25_raises"])
+    with pytest.raises(AssertionError):
+        oracle.search(layers, Qn, Xs, Qs, dp, 2, 25)
+    assert bool(g["alias_raises"])  # the reference cannot run with aliased frames
+
+
+def test_duplicate_vectors_tie_order(oracle):
+    """Exact ties: the lower in-bucket row wins (and the reference fixture agrees)."""
+    g = load_golden("G4")
+    _, _, Xs, Qs = inputs_for("G4", g)
+    rows = np.concatenate([[int(g["dup_src"])], g["dup_rows"]])
+    D, I = oracle.knn_ip(Qs[:8], Xs[rows], 10)
+    assert np.all(I == np.arange(10)[None, :])
+    assert np.all(D == D[:, :1])
+
+
+def test_knn_matches_float64_bruteforce(oracle):
+    rs = np.random.RandomState(5)
+    xb = rs.randn(777, 45).astype(np.float32)
+    xq = rs.randn(33, 45).astype(np.float32)
+    D, I = oracle.knn_ip(xq, xb, 10, nthreads=3)
+    ref = xq.astype(np.float64) @ xb.astype(np.float64).T
+    order = np.argsort(-ref, axis=1, kind="stable")[:, :10]
+    assert (I == order).mean() > 0.99
+    np.testing.assert_allclose(D, np.take_along_axis(ref, order, 1), rtol=1e-5, atol=1e-5)
+    # chain definition, element by element
+    for q, j in ((0, 0), (5, 3), (32, 9)):
+        assert D[q, j] == oracle.dot(xq[q], xb[I[q, j]])
+    # threads do not change results
+    D1, I1 = oracle.knn_ip(xq, xb, 10, nthreads=1)
+    assert np.array_equal(D, D1) and np.array_equal(I, I1)
+
+
+def test_expf_close_to_libm(oracle):
+    xs = np.linspace(-86.9, 0, 4001).astype(np.float32)
+    got = np.array([oracle.lib().lmi_oracle_expf(float(x)) for x in xs], dtype=np.float32)
+    np.testing.assert_allclose(got, np.exp(xs.astype(np.float64)), rtol=3e-7)
