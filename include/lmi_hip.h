@@ -1,0 +1,129 @@
+/*
+ * lmi_hip.h -- C ABI of liblmi_hip.so: the MI355X (gfx950) implementation of the
+ * LearnedMetricIndex query hot path.
+ *
+ * The reference (Coda-Research-Group/LearnedMetricIndex, pure Python) has no FFI of its own; its
+ * native arithmetic is reached through two third-party Python calls.  Each entry point below
+ * names the reference interface it replaces (paths relative to /root/reference/search/li/):
+ *
+ *   lmi_set_mlp / lmi_mlp_topk     NeuralNetwork.predict_proba            model.py:226-241
+ *                                  (Sequential(Linear,ReLU,..)(x), softmax, topk)  model.py:45-49,97-99
+ *                                  + _precompute_bucket_order 1-level     LearnedIndex.py:197-214
+ *   lmi_buckets_*                  data_navigation.groupby(category_L*) + data_search.loc[...]
+ *                                                                         LearnedIndex.py:101-104,350,357
+ *   lmi_scan_topk                  the `for rank` x `for bucket` loop: filter_path_idxs, faiss.knn,
+ *                                  1 - sim, local->global ids, stable merge
+ *                                                                         LearnedIndex.py:107-146,328-373, utils.py:61-65
+ *   lmi_search                     LearnedIndex.search (1-level index)    LearnedIndex.py:41-161
+ *   lmi_knn_ip                     faiss.knn(xq, xb, k, METRIC_INNER_PRODUCT)   call site LearnedIndex.py:360-365
+ *   lmi_merge_gathered             (no reference counterpart) merge of per-GPU top-k after the one
+ *                                  RCCL all-gather of the bucket-sharded multi-GPU mode
+ *
+ * Conventions
+ *   - Every function returns 0 on success and a negative code on failure; lmi_last_error()
+ *     returns a thread-local, NUL-terminated description of the last failure.  Nothing throws.
+ *   - A handle is bound to one device and one HIP stream (lmi_set_stream; default: the NULL
+ *     stream).  All device work is enqueued on that stream.  A handle is not thread-safe.
+ *   - `on_device` != 0: the float/int buffers of that call are device pointers valid on the
+ *     handle's device and the call is asynchronous on the handle's stream.  `on_device` == 0: they
+ *     are host pointers; the call copies in/out and returns after the results have landed.
+ *   - All matrices are dense row-major.  Weights use torch.nn.Linear layout W[out][in].
+ *   - Arithmetic contract (identical to oracle/lmi_oracle.c): every inner product is the k-ordered
+ *     binary32 chain acc = fmaf(a[k], b[k], acc); Linear layers start the chain at the bias, the
+ *     scan at 0.  Ties: lower class index / lower in-bucket row first; ranks merge by
+ *     (distance, bucket rank, position) exactly like the reference's stable argsort.
+ */
+#ifndef LMI_HIP_H
+#define LMI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LMI_ABI_VERSION 1
+#define LMI_K_PER_BUCKET 10 /* LearnedIndex.py:334: k is never forwarded to the bucket scan */
+#define LMI_MAX_K 64
+#define LMI_MAX_LAYERS 8
+
+typedef struct lmi_index lmi_index;
+
+/* Timing slots filled by lmi_timings (milliseconds, hipEvent-measured on the handle's stream). */
+enum {
+    LMI_T_INFERENCE = 0, /* MLP forward + class ranking   -> measured_time["inference"]            */
+    LMI_T_ROUTE = 1,     /* routing (CSR of queries per bucket) + query packing                     */
+    LMI_T_SCAN = 2,      /* the bucket-scan kernel alone  -> measured_time["seq_search"]            */
+    LMI_T_MERGE = 3,     /* chunk/rank merge kernel       -> measured_time["sort"]                  */
+    LMI_T_TOTAL = 4,     /* first to last event           -> measured_time["search"]                */
+    LMI_T_COUNT = 8
+};
+
+int lmi_abi_version(void);
+const char *lmi_last_error(void);
+
+/* Lifetime. */
+int lmi_create(int device, lmi_index **out);
+int lmi_destroy(lmi_index *h);
+int lmi_set_stream(lmi_index *h, void *hip_stream);
+
+/* MLP weights (host pointers).  dims[0] = input dim, dims[n_layers] = number of classes L;
+ * W[i] is [dims[i+1]][dims[i]], b[i] is [dims[i+1]].  ReLU between layers, none after the last. */
+int lmi_set_mlp(lmi_index *h, int n_layers, const int *dims, const float *const *W,
+                const float *const *b);
+
+/* Bucket-contiguous index in HBM.
+ * begin: labels[N] = data_prediction[:,0] (bucket of every object, 0 <= label < L), ids[N] = the
+ *        DataFrame index labels (NULL -> 1..N, search.py:190-191), owned[L] = which buckets this
+ *        handle keeps (NULL -> all; used by the bucket-sharded multi-GPU mode).  Host pointers.
+ * add_rows: rows [nrows][d] are the original objects row0 .. row0+nrows-1 (any order of calls, each
+ *        object exactly once); they are scattered to their bucket-contiguous position on device.
+ * end:   finishes the build; the index is immutable afterwards. */
+int lmi_buckets_begin(lmi_index *h, int64_t N, int d, int L, const int64_t *labels,
+                      const uint32_t *ids, const uint8_t *owned);
+int lmi_buckets_add_rows(lmi_index *h, const float *rows, int64_t row0, int64_t nrows, int on_device);
+int lmi_buckets_end(lmi_index *h);
+/* sizes[L] <- number of objects per bucket (0 for buckets not owned). */
+int lmi_bucket_sizes(lmi_index *h, int64_t *sizes);
+
+/* Navigation: bucket_order[nq][nb] <- the nb most probable classes per query, most probable first.
+ * logits (nullable) [nq][L] <- raw outputs of the last Linear layer. */
+int lmi_mlp_topk(lmi_index *h, const float *queries_nav, int nq, int nb, int32_t *bucket_order,
+                 float *logits, int on_device);
+
+/* Scan: for every query, top-LMI_K_PER_BUCKET by inner product inside each of its nb buckets,
+ * dist = 1 - ip (binary32), merged over the ranks to k results (k <= LMI_MAX_K).
+ * dists[nq][kout], ids[nq][kout] with kout = (nb == 1 ? LMI_K_PER_BUCKET : k).
+ * Unvisited slots: dist = +inf, id = 0.  keys (nullable) [nq][kout] <- rank*16 + position, the
+ * tie-break key needed by lmi_merge_gathered. */
+int lmi_scan_topk(lmi_index *h, const float *queries_search, int nq, const int32_t *bucket_order,
+                  int nb, int k, float *dists, uint32_t *ids, uint32_t *keys, int on_device);
+
+/* lmi_mlp_topk followed by lmi_scan_topk, nothing leaves the device in between. */
+int lmi_search(lmi_index *h, const float *queries_nav, const float *queries_search, int nq, int nb,
+               int k, float *dists, uint32_t *ids, uint32_t *keys, int32_t *bucket_order,
+               int on_device);
+
+/* Multi-GPU: gathered_{dists,ids,keys} are [world][nq][kout] (the all-gather of every rank's
+ * lmi_scan_topk outputs); writes the merged dists/ids [nq][kout]. */
+int lmi_merge_gathered(lmi_index *h, const float *gathered_dists, const uint32_t *gathered_ids,
+                       const uint32_t *gathered_keys, int world, int nq, int kout, float *dists,
+                       uint32_t *ids, int on_device);
+
+/* faiss.knn(xq, xb, k, metric=METRIC_INNER_PRODUCT) on host pointers: D[nq][k] similarities in
+ * descending order, I[nq][k] row numbers; nb < k pads with D = -FLT_MAX, I = -1.  k <= 10. */
+int lmi_knn_ip(int device, const float *xq, int64_t nq, const float *xb, int64_t nb, int d, int k,
+               float *D, int64_t *I);
+
+/* Timings of the last lmi_mlp_topk / lmi_scan_topk / lmi_search call (synchronises the stream). */
+int lmi_timings(lmi_index *h, float *ms /* [LMI_T_COUNT] */);
+/* Work done by the last scan: flops = 2 * d * sum over (query, rank) of the bucket size;
+ * items = work items executed by the persistent scan kernel. */
+int lmi_scan_stats(lmi_index *h, double *flops, int64_t *pairs, int64_t *items);
+/* Tuning: rows per scan chunk (multiple of 128; default 4096). */
+int lmi_set_chunk_rows(lmi_index *h, int rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LMI_HIP_H */

@@ -1,0 +1,254 @@
+"""ctypes binding of liblmi_hip.so (the C ABI in include/lmi_hip.h).
+
+There is no CPU fallback: if the HIP library is missing or fails, this module raises.
+torch is imported first so that the HIP runtime (libamdhip64.so.7) already loaded by PyTorch-ROCm
+is the one the library binds to; torch device pointers and streams are then valid inside it.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblmi_hip.so")
+K_PER_BUCKET = 10
+T_INFERENCE, T_ROUTE, T_SCAN, T_MERGE, T_TOTAL, T_COUNT = 0, 1, 2, 3, 4, 8
+
+_lib = None
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_vp = ctypes.c_void_p
+
+#: every symbol include/lmi_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "lmi_abi_version": (ctypes.c_int, []),
+    "lmi_last_error": (ctypes.c_char_p, []),
+    "lmi_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
+    "lmi_destroy": (ctypes.c_int, [_vp]),
+    "lmi_set_stream": (ctypes.c_int, [_vp, _vp]),
+    "lmi_set_mlp": (ctypes.c_int, [_vp, ctypes.c_int, _i32p, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
+    "lmi_buckets_begin": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
+    "lmi_buckets_add_rows": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int]),
+    "lmi_buckets_end": (ctypes.c_int, [_vp]),
+    "lmi_bucket_sizes": (ctypes.c_int, [_vp, _vp]),
+    "lmi_mlp_topk": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int]),
+    "lmi_scan_topk": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp,
+                                     ctypes.c_int]),
+    "lmi_search": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp,
+                                  ctypes.c_int]),
+    "lmi_merge_gathered": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp,
+                                          ctypes.c_int]),
+    "lmi_knn_ip": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int64, _vp, ctypes.c_int64, ctypes.c_int,
+                                  ctypes.c_int, _vp, _vp]),
+    "lmi_timings": (ctypes.c_int, [_vp, _vp]),
+    "lmi_scan_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double), _i64p, _i64p]),
+    "lmi_set_chunk_rows": (ctypes.c_int, [_vp, ctypes.c_int]),
+}
+
+
+class LmiError(RuntimeError):
+    """Raised when a C-ABI call returns non-zero (message from lmi_last_error)."""
+
+
+def lib() -> ctypes.CDLL:
+    """Loads liblmi_hip.so (after torch, so one HIP runtime serves both) and declares prototypes."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LmiError(
+                f"{LIB_PATH} is missing: build it with learnedmetricindex_amd/csrc/build.sh "
+                "(or __graft_entry__.build()); there is no CPU fallback")
+        import torch  # noqa: F401  (loads PyTorch-ROCm's libamdhip64 first)
+
+        L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.lmi_abi_version() != 1:
+            raise LmiError("liblmi_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise LmiError(lib().lmi_last_error().decode("utf-8", "replace"))
+
+
+def _ptr(a) -> int:
+    """Raw address of a numpy array or torch tensor (None -> NULL)."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    return a.data_ptr()  # torch.Tensor
+
+
+def _np(a, dtype) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+class Index:
+    """One device-resident index: thin, typed wrapper over an `lmi_index*`."""
+
+    def __init__(self, device: int = 0, chunk_rows: Optional[int] = None):
+        self._h = _vp()
+        _check(lib().lmi_create(int(device), ctypes.byref(self._h)))
+        self.device = int(device)
+        self.n_classes = None
+        self.d_nav = None
+        self.d = None
+        self.L = None
+        if chunk_rows is not None:
+            _check(lib().lmi_set_chunk_rows(self._h, int(chunk_rows)))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().lmi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def set_stream(self, stream_ptr: int) -> None:
+        _check(lib().lmi_set_stream(self._h, _vp(stream_ptr)))
+
+    # ---- MLP -------------------------------------------------------------------------------
+    def set_mlp(self, layers: Sequence) -> None:
+        """layers = [(W [out,in], b [out]), ...] in torch.nn.Linear layout."""
+        Ws = [_np(W, np.float32) for W, _ in layers]
+        bs = [_np(b, np.float32) for _, b in layers]
+        dims = [Ws[0].shape[1]] + [W.shape[0] for W in Ws]
+        for i, (W, b) in enumerate(zip(Ws, bs)):
+            assert W.shape == (dims[i + 1], dims[i]) and b.shape == (dims[i + 1],)
+        n = len(Ws)
+        dims_c = (ctypes.c_int32 * (n + 1))(*dims)
+        Wp = (_vp * n)(*[W.ctypes.data for W in Ws])
+        bp = (_vp * n)(*[b.ctypes.data for b in bs])
+        _check(lib().lmi_set_mlp(self._h, n, dims_c, Wp, bp))
+        self.d_nav, self.n_classes = dims[0], dims[-1]
+
+    # ---- buckets ---------------------------------------------------------------------------
+    def buckets_begin(self, labels, d: int, L: int, ids=None, owned=None) -> None:
+        labels = _np(labels, np.int64).reshape(-1)
+        ids_a = None if ids is None else _np(ids, np.uint32).reshape(-1)
+        owned_a = None if owned is None else _np(owned, np.uint8).reshape(-1)
+        assert ids_a is None or ids_a.shape == labels.shape
+        assert owned_a is None or owned_a.shape == (L,)
+        _check(lib().lmi_buckets_begin(self._h, labels.shape[0], int(d), int(L), _ptr(labels), _ptr(ids_a),
+                                       _ptr(owned_a)))
+        self.N, self.d, self.L = labels.shape[0], int(d), int(L)
+
+    def add_rows(self, rows, row0: int) -> None:
+        """rows: numpy [n,d] float32 (host) or a CUDA torch tensor (device)."""
+        if isinstance(rows, np.ndarray):
+            rows = _np(rows, np.float32)
+            on_device = 0
+        else:
+            assert rows.is_cuda and rows.is_contiguous() and rows.dtype.is_floating_point and rows.element_size() == 4
+            on_device = 1
+        assert rows.shape[1] == self.d
+        _check(lib().lmi_buckets_add_rows(self._h, _ptr(rows), int(row0), int(rows.shape[0]), on_device))
+
+    def buckets_end(self) -> None:
+        _check(lib().lmi_buckets_end(self._h))
+
+    def set_buckets(self, data, labels, L: int, ids=None, owned=None, piece: int = 1 << 18) -> None:
+        data = data if not isinstance(data, np.ndarray) else _np(data, np.float32)
+        self.buckets_begin(labels, data.shape[1], L, ids, owned)
+        for r0 in range(0, data.shape[0], piece):
+            self.add_rows(data[r0: r0 + piece], r0)
+        self.buckets_end()
+
+    def bucket_sizes(self) -> np.ndarray:
+        out = np.zeros(self.L, dtype=np.int64)
+        _check(lib().lmi_bucket_sizes(self._h, _ptr(out)))
+        return out
+
+    # ---- query path, host arrays ------------------------------------------------------------
+    def mlp_topk(self, queries_nav, nb: int, want_logits: bool = False):
+        q = _np(queries_nav, np.float32)
+        order = np.empty((q.shape[0], nb), dtype=np.int32)
+        logits = np.empty((q.shape[0], self.n_classes), dtype=np.float32) if want_logits else None
+        _check(lib().lmi_mlp_topk(self._h, _ptr(q), q.shape[0], int(nb), _ptr(order), _ptr(logits), 0))
+        return (order, logits) if want_logits else order
+
+    @staticmethod
+    def kout(nb: int, k: int) -> int:
+        return K_PER_BUCKET if nb == 1 else k
+
+    def scan_topk(self, queries_search, bucket_order, k: int = 10, want_keys: bool = False):
+        q = _np(queries_search, np.float32)
+        bo = _np(bucket_order, np.int32).reshape(q.shape[0], -1)
+        nb = bo.shape[1]
+        ko = self.kout(nb, k)
+        d = np.empty((q.shape[0], ko), dtype=np.float32)
+        i = np.empty((q.shape[0], ko), dtype=np.uint32)
+        keys = np.empty((q.shape[0], ko), dtype=np.uint32) if want_keys else None
+        _check(lib().lmi_scan_topk(self._h, _ptr(q), q.shape[0], _ptr(bo), nb, int(k), _ptr(d), _ptr(i), _ptr(keys), 0))
+        return (d, i, keys) if want_keys else (d, i)
+
+    def search(self, queries_nav, queries_search, nb: int, k: int = 10, want_keys: bool = False):
+        qn = _np(queries_nav, np.float32)
+        qs = qn if queries_search is queries_nav else _np(queries_search, np.float32)
+        nq = qn.shape[0]
+        ko = self.kout(nb, k)
+        d = np.empty((nq, ko), dtype=np.float32)
+        i = np.empty((nq, ko), dtype=np.uint32)
+        bo = np.empty((nq, nb), dtype=np.int32)
+        keys = np.empty((nq, ko), dtype=np.uint32) if want_keys else None
+        _check(lib().lmi_search(self._h, _ptr(qn), _ptr(qs), nq, int(nb), int(k), _ptr(d), _ptr(i), _ptr(keys),
+                                _ptr(bo), 0))
+        return (d, i, bo, keys) if want_keys else (d, i, bo)
+
+    # ---- query path, device tensors (torch), asynchronous on the handle's stream --------------
+    def search_device(self, qn_t, qs_t, nb: int, k: int, d_t, i_t, keys_t=None, bo_t=None) -> None:
+        _check(lib().lmi_search(self._h, _ptr(qn_t), _ptr(qs_t), int(qn_t.shape[0]), int(nb), int(k), _ptr(d_t),
+                                _ptr(i_t), _ptr(keys_t), _ptr(bo_t), 1))
+
+    def mlp_topk_device(self, qn_t, nb: int, bo_t, logits_t=None) -> None:
+        _check(lib().lmi_mlp_topk(self._h, _ptr(qn_t), int(qn_t.shape[0]), int(nb), _ptr(bo_t), _ptr(logits_t), 1))
+
+    def scan_topk_device(self, qs_t, bo_t, nb: int, k: int, d_t, i_t, keys_t=None) -> None:
+        _check(lib().lmi_scan_topk(self._h, _ptr(qs_t), int(qs_t.shape[0]), _ptr(bo_t), int(nb), int(k), _ptr(d_t),
+                                   _ptr(i_t), _ptr(keys_t), 1))
+
+    def merge_gathered(self, gd, gi, gk, world: int, nq: int, kout: int, out_d, out_i) -> None:
+        on_device = 0 if isinstance(gd, np.ndarray) else 1
+        _check(lib().lmi_merge_gathered(self._h, _ptr(gd), _ptr(gi), _ptr(gk), int(world), int(nq), int(kout),
+                                        _ptr(out_d), _ptr(out_i), on_device))
+
+    def timings(self) -> np.ndarray:
+        ms = np.zeros(T_COUNT, dtype=np.float32)
+        _check(lib().lmi_timings(self._h, _ptr(ms)))
+        return ms
+
+    def scan_stats(self):
+        fl = ctypes.c_double(0)
+        pairs = ctypes.c_int64(0)
+        items = ctypes.c_int64(0)
+        _check(lib().lmi_scan_stats(self._h, ctypes.byref(fl), ctypes.byref(pairs), ctypes.byref(items)))
+        return fl.value, pairs.value, items.value
+
+
+def knn_ip(xq, xb, k: int = 10, device: int = 0):
+    """faiss.knn(xq, xb, k, metric=faiss.METRIC_INNER_PRODUCT) on the GPU (LearnedIndex.py:360-365)."""
+    xq = _np(xq, np.float32)
+    xb = _np(xb, np.float32)
+    assert xq.ndim == 2 and xb.ndim == 2 and xq.shape[1] == xb.shape[1]
+    D = np.empty((xq.shape[0], k), dtype=np.float32)
+    I = np.empty((xq.shape[0], k), dtype=np.int64)
+    _check(lib().lmi_knn_ip(int(device), _ptr(xq), xq.shape[0], _ptr(xb), xb.shape[0], xq.shape[1], int(k),
+                            _ptr(D), _ptr(I)))
+    return D, I

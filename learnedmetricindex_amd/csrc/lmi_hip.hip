@@ -1,0 +1,686 @@
+// lmi_hip.hip -- host side of liblmi_hip.so: the C ABI declared in include/lmi_hip.h.
+// Owns the device-resident index (fragment-major slab, ids, CSR of buckets), the packed MLP
+// weights and the per-call workspaces; enqueues the kernels of lmi_kernels.h on one HIP stream.
+#include "lmi_kernels.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "lmi_hip.h"
+
+using namespace lmi;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return -1;
+}
+
+#define HIPCHK(expr)                                                                                \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define CHK(expr)              \
+    do {                       \
+        int r_ = (expr);       \
+        if (r_ != 0) return r_; \
+    } while (0)
+
+inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+inline long long rup(long long a, long long b) { return (a + b - 1) / b * b; }
+
+// device buffer that only grows
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) HIPCHK(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        HIPCHK(hipMalloc(&p, want));
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+}  // namespace
+
+struct lmi_index {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cus = 256;
+    int scan_blocks_per_cu = 2;
+
+    // ---- MLP ----
+    int n_layers = 0;
+    std::vector<int> dims;    // dims[0..n_layers]
+    std::vector<int> n_rb;    // per layer: output row-blocks
+    std::vector<int> KG;      // per layer: k-groups of the layer's input
+    std::vector<DevBuf> Wf;   // packed weights
+    std::vector<DevBuf> bias; // padded bias
+
+    // ---- buckets ----
+    bool building = false, built = false;
+    int64_t N = 0;
+    int d = 0, L = 0, KGs = 0;
+    int chunk_rows = 4096;
+    int64_t n_rb_total = 0;
+    std::vector<int> h_nb_rows, h_rb_start, h_nch;
+    DevBuf slab, ids_slab, pos, d_nb_rows, d_rb_start, d_nch;
+    int64_t rows_added = 0;
+    DevBuf stage;  // H2D staging for add_rows / host query uploads
+
+    // ---- per-call workspaces ----
+    DevBuf act[2], xfrag, logits, order, q_nav, q_srch;
+    DevBuf m, cb_start, item_base, part_base, stats, head, slot_local, slot_col, colmap, qfrag;
+    DevBuf part_score, part_row, rank_d, rank_id, out_d, out_id, out_key;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid[6] = {false, false, false, false, false, false};
+    long long h_stats[2] = {0, 0};
+    bool stats_pending = false;
+};
+
+static int set_dev(lmi_index* h) {
+    HIPCHK(hipSetDevice(h->device));
+    return 0;
+}
+
+extern "C" int lmi_abi_version(void) { return LMI_ABI_VERSION; }
+extern "C" const char* lmi_last_error(void) { return g_err.c_str(); }
+
+extern "C" int lmi_create(int device, lmi_index** out) {
+    if (!out) return fail("lmi_create: out is NULL");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail("lmi_create: device %d out of range (%d devices)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail("lmi_create: device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    lmi_index* h = new lmi_index();
+    h->device = device;
+    h->num_cus = prop.multiProcessorCount;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS));
+    int occ = 0;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_kernel, 256, SCAN_LDS));
+    h->scan_blocks_per_cu = std::max(1, std::min(occ, 2));
+    for (int i = 0; i < 6; ++i) HIPCHK(hipEventCreate(&h->ev[i]));
+    *out = h;
+    return 0;
+}
+
+extern "C" int lmi_destroy(lmi_index* h) {
+    if (!h) return 0;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    for (auto& b : h->Wf) b.release();
+    for (auto& b : h->bias) b.release();
+    DevBuf* bufs[] = {&h->slab, &h->ids_slab, &h->pos, &h->d_nb_rows, &h->d_rb_start, &h->d_nch, &h->stage,
+                      &h->act[0], &h->act[1], &h->xfrag, &h->logits, &h->order, &h->q_nav, &h->q_srch, &h->m,
+                      &h->cb_start, &h->item_base, &h->part_base, &h->stats, &h->head, &h->slot_local,
+                      &h->slot_col, &h->colmap, &h->qfrag, &h->part_score, &h->part_row, &h->rank_d,
+                      &h->rank_id, &h->out_d, &h->out_id, &h->out_key};
+    for (DevBuf* b : bufs) b->release();
+    for (int i = 0; i < 6; ++i)
+        if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    delete h;
+    return 0;
+}
+
+extern "C" int lmi_set_stream(lmi_index* h, void* s) {
+    if (!h) return fail("lmi_set_stream: NULL handle");
+    h->stream = reinterpret_cast<hipStream_t>(s);
+    return 0;
+}
+
+extern "C" int lmi_set_chunk_rows(lmi_index* h, int rows) {
+    if (!h) return fail("lmi_set_chunk_rows: NULL handle");
+    if (rows < 128 || rows % 128) return fail("lmi_set_chunk_rows: rows must be a positive multiple of 128");
+    if (h->building || h->built) return fail("lmi_set_chunk_rows: must be called before lmi_buckets_begin");
+    h->chunk_rows = rows;
+    return 0;
+}
+
+// upload a row-major host matrix and pack it fragment-major (rows padded to 32, K to 8*KG)
+static int pack_from_host(lmi_index* h, const float* src, int rows, int cols, int n_rb, int KG, DevBuf& dst) {
+    CHK(h->stage.reserve((size_t)rows * cols * sizeof(float)));
+    HIPCHK(hipMemcpyAsync(h->stage.p, src, (size_t)rows * cols * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    CHK(dst.reserve((size_t)n_rb * KG * 1024));
+    long long total = (long long)n_rb * 32 * KG;
+    pack_gather_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(h->stage.as<float>(), cols, nullptr, rows,
+                                                               (long long)n_rb * 32, KG, dst.as<float4>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));  // staging buffer is reused by the next call
+    return 0;
+}
+
+extern "C" int lmi_set_mlp(lmi_index* h, int n_layers, const int* dims, const float* const* W,
+                           const float* const* b) {
+    if (!h) return fail("lmi_set_mlp: NULL handle");
+    if (n_layers < 1 || n_layers > LMI_MAX_LAYERS) return fail("lmi_set_mlp: n_layers %d out of range", n_layers);
+    CHK(set_dev(h));
+    for (int i = 0; i <= n_layers; ++i)
+        if (dims[i] < 1) return fail("lmi_set_mlp: dims[%d] = %d", i, dims[i]);
+    for (auto& x : h->Wf) x.release();
+    for (auto& x : h->bias) x.release();
+    h->n_layers = n_layers;
+    h->dims.assign(dims, dims + n_layers + 1);
+    h->n_rb.assign(n_layers, 0);
+    h->KG.assign(n_layers, 0);
+    h->Wf.assign(n_layers, DevBuf());
+    h->bias.assign(n_layers, DevBuf());
+    for (int i = 0; i < n_layers; ++i) {
+        h->n_rb[i] = cdiv(dims[i + 1], 32);
+        h->KG[i] = (i == 0) ? cdiv(dims[0], 8) : h->n_rb[i - 1] * 4;  // hidden K = padded features
+        if (!W[i] || !b[i]) return fail("lmi_set_mlp: NULL weight/bias for layer %d", i);
+        CHK(pack_from_host(h, W[i], dims[i + 1], dims[i], h->n_rb[i], h->KG[i], h->Wf[i]));
+        std::vector<float> bp((size_t)h->n_rb[i] * 32, 0.0f);
+        std::copy(b[i], b[i] + dims[i + 1], bp.begin());
+        CHK(h->bias[i].reserve(bp.size() * sizeof(float)));
+        HIPCHK(hipMemcpy(h->bias[i].p, bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+extern "C" int lmi_buckets_begin(lmi_index* h, int64_t N, int d, int L, const int64_t* labels,
+                                 const uint32_t* ids, const uint8_t* owned) {
+    if (!h) return fail("lmi_buckets_begin: NULL handle");
+    if (N < 0 || d < 1 || L < 1 || (N > 0 && !labels)) return fail("lmi_buckets_begin: bad arguments");
+    if (N >= (1ll << 31) - 64ll * L) return fail("lmi_buckets_begin: N too large for 32-bit positions");
+    CHK(set_dev(h));
+    h->N = N;
+    h->d = d;
+    h->L = L;
+    h->KGs = (int)rup(cdiv(d, 8), STAGE_G);
+    h->built = false;
+    h->h_nb_rows.assign(L, 0);
+    for (int64_t i = 0; i < N; ++i) {
+        int64_t b = labels[i];
+        if (b < 0 || b >= L) return fail("lmi_buckets_begin: labels[%lld] = %lld outside [0,%d)", (long long)i, (long long)b, L);
+        if (!owned || owned[b]) h->h_nb_rows[b]++;
+    }
+    h->h_rb_start.assign(L + 1, 0);
+    h->h_nch.assign(L, 0);
+    const int chunk_rb = h->chunk_rows / 32;
+    for (int b = 0; b < L; ++b) {
+        int nrb = cdiv(h->h_nb_rows[b], 32);
+        h->h_rb_start[b + 1] = h->h_rb_start[b] + nrb;
+        h->h_nch[b] = cdiv(nrb, chunk_rb);
+        if (h->h_nch[b] > 1024) return fail("lmi_buckets_begin: bucket %d needs %d chunks (> 1024); raise chunk rows", b, h->h_nch[b]);
+    }
+    h->n_rb_total = h->h_rb_start[L];
+    // bucket-contiguous position of every object (stable: ascending original row inside a bucket,
+    // the order pandas groupby yields) and the id of every slab row
+    std::vector<int> pos((size_t)N);
+    std::vector<uint32_t> ids_slab((size_t)std::max<int64_t>(h->n_rb_total, 1) * 32, 0u);
+    std::vector<int> fill(L, 0);
+    for (int64_t i = 0; i < N; ++i) {
+        int b = (int)labels[i];
+        if (owned && !owned[b]) { pos[i] = -1; continue; }
+        int p = h->h_rb_start[b] * 32 + fill[b]++;
+        pos[i] = p;
+        ids_slab[p] = ids ? ids[i] : (uint32_t)(i + 1);  // search.py:190-191: 1-based labels
+    }
+    const size_t slab_bytes = (size_t)std::max<int64_t>(h->n_rb_total, 1) * h->KGs * 1024;
+    CHK(h->slab.reserve(slab_bytes));
+    HIPCHK(hipMemsetAsync(h->slab.p, 0, slab_bytes, h->stream));
+    CHK(h->ids_slab.reserve(ids_slab.size() * 4));
+    HIPCHK(hipMemcpy(h->ids_slab.p, ids_slab.data(), ids_slab.size() * 4, hipMemcpyHostToDevice));
+    CHK(h->pos.reserve(std::max<size_t>(pos.size(), 1) * 4));
+    if (N) HIPCHK(hipMemcpy(h->pos.p, pos.data(), pos.size() * 4, hipMemcpyHostToDevice));
+    CHK(h->d_nb_rows.reserve(L * 4));
+    CHK(h->d_rb_start.reserve((L + 1) * 4));
+    CHK(h->d_nch.reserve(L * 4));
+    HIPCHK(hipMemcpy(h->d_nb_rows.p, h->h_nb_rows.data(), L * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_rb_start.p, h->h_rb_start.data(), (L + 1) * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_nch.p, h->h_nch.data(), L * 4, hipMemcpyHostToDevice));
+    h->rows_added = 0;
+    h->building = true;
+    return 0;
+}
+
+extern "C" int lmi_buckets_add_rows(lmi_index* h, const float* rows, int64_t row0, int64_t nrows, int on_device) {
+    if (!h || !h->building) return fail("lmi_buckets_add_rows: call lmi_buckets_begin first");
+    if (row0 < 0 || nrows < 0 || row0 + nrows > h->N) return fail("lmi_buckets_add_rows: rows [%lld,%lld) outside [0,%lld)", (long long)row0, (long long)(row0 + nrows), (long long)h->N);
+    if (nrows == 0) return 0;
+    CHK(set_dev(h));
+    const int64_t piece = std::max<int64_t>(1, (256ll << 20) / ((int64_t)h->d * 4));
+    for (int64_t off = 0; off < nrows; off += piece) {
+        const int64_t n = std::min(piece, nrows - off);
+        const float* src = rows + off * h->d;
+        if (!on_device) {
+            CHK(h->stage.reserve((size_t)n * h->d * 4));
+            HIPCHK(hipMemcpyAsync(h->stage.p, src, (size_t)n * h->d * 4, hipMemcpyHostToDevice, h->stream));
+            src = h->stage.as<float>();
+        }
+        long long total = (long long)n * h->KGs;
+        pack_scatter_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(src, h->d, h->pos.as<int>(), row0 + off, n,
+                                                                    h->KGs, h->slab.as<float4>());
+        HIPCHK(hipGetLastError());
+        if (!on_device) HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    h->rows_added += nrows;
+    return 0;
+}
+
+extern "C" int lmi_buckets_end(lmi_index* h) {
+    if (!h || !h->building) return fail("lmi_buckets_end: call lmi_buckets_begin first");
+    if (h->rows_added != h->N) return fail("lmi_buckets_end: %lld of %lld rows were added", (long long)h->rows_added, (long long)h->N);
+    CHK(set_dev(h));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->pos.release();
+    h->building = false;
+    h->built = true;
+    return 0;
+}
+
+extern "C" int lmi_bucket_sizes(lmi_index* h, int64_t* sizes) {
+    if (!h || !(h->built || h->building)) return fail("lmi_bucket_sizes: no buckets");
+    for (int b = 0; b < h->L; ++b) sizes[b] = h->h_nb_rows[b];
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+static int record(lmi_index* h, int i) {
+    HIPCHK(hipEventRecord(h->ev[i], h->stream));
+    h->ev_valid[i] = true;
+    return 0;
+}
+
+// device pointer to the caller's input (uploads host data into `buf`)
+static int input_ptr(lmi_index* h, const void* src, size_t bytes, int on_device, DevBuf& buf, const void** out) {
+    if (on_device) { *out = src; return 0; }
+    CHK(buf.reserve(bytes));
+    HIPCHK(hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, h->stream));
+    *out = buf.p;
+    return 0;
+}
+
+static int mlp_enqueue(lmi_index* h, const float* d_q, int nq, int nb, int* d_order, float* d_logits_out) {
+    if (h->n_layers == 0) return fail("lmi_mlp_topk: no MLP set (lmi_set_mlp)");
+    const int L = h->dims[h->n_layers];
+    if (nb < 1 || nb > L) return fail("lmi_mlp_topk: n_buckets %d outside [1,%d]", nb, L);
+    const int ncb = cdiv(nq, 32);
+    // pack the queries as the B operand of layer 0
+    CHK(h->xfrag.reserve((size_t)ncb * h->KG[0] * 1024));
+    {
+        long long total = (long long)ncb * 32 * h->KG[0];
+        pack_gather_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(d_q, h->dims[0], nullptr, nq, (long long)ncb * 32,
+                                                                   h->KG[0], h->xfrag.as<float4>());
+        HIPCHK(hipGetLastError());
+    }
+    int maxrb = 0;
+    for (int i = 0; i + 1 < h->n_layers; ++i) maxrb = std::max(maxrb, h->n_rb[i]);
+    for (int i = 0; i < 2; ++i) CHK(h->act[i].reserve((size_t)std::max(1, ncb) * std::max(1, maxrb) * 4 * 1024));
+    float* d_logits = d_logits_out;
+    if (!d_logits) {
+        CHK(h->logits.reserve((size_t)nq * L * 4));
+        d_logits = h->logits.as<float>();
+    }
+    const float4* in = h->xfrag.as<float4>();
+    for (int i = 0; i < h->n_layers; ++i) {
+        const bool last = i + 1 == h->n_layers;
+        dim3 grid(cdiv(ncb, 4), cdiv(h->n_rb[i], 4));
+        if (last) {
+            mlp_layer_kernel<true><<<grid, 256, 0, h->stream>>>(h->Wf[i].as<float4>(), h->bias[i].as<float>(), in,
+                                                               h->KG[i], h->n_rb[i], ncb, d_logits, 0, nq, L);
+        } else {
+            float* o = h->act[i & 1].as<float>();
+            mlp_layer_kernel<false><<<grid, 256, 0, h->stream>>>(h->Wf[i].as<float4>(), h->bias[i].as<float>(), in,
+                                                                h->KG[i], h->n_rb[i], ncb, o, h->n_rb[i] * 4, nq, L);
+            in = reinterpret_cast<const float4*>(o);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    rank_classes_kernel<<<nq, 64, 0, h->stream>>>(d_logits, nq, L, nb, d_order);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int lmi_mlp_topk(lmi_index* h, const float* queries_nav, int nq, int nb, int32_t* bucket_order,
+                            float* logits, int on_device) {
+    if (!h) return fail("lmi_mlp_topk: NULL handle");
+    if (nq < 0) return fail("lmi_mlp_topk: nq < 0");
+    if (nq == 0) return 0;
+    CHK(set_dev(h));
+    if (h->n_layers == 0) return fail("lmi_mlp_topk: no MLP set (lmi_set_mlp)");
+    const int L = h->dims[h->n_layers];
+    const void* d_q = nullptr;
+    CHK(input_ptr(h, queries_nav, (size_t)nq * h->dims[0] * 4, on_device, h->q_nav, &d_q));
+    int* d_order = bucket_order;
+    float* d_logits = logits;
+    if (!on_device) {
+        CHK(h->order.reserve((size_t)nq * nb * 4));
+        d_order = h->order.as<int>();
+        if (logits) { CHK(h->logits.reserve((size_t)nq * L * 4)); d_logits = h->logits.as<float>(); }
+    }
+    for (int i = 0; i < 6; ++i) h->ev_valid[i] = false;
+    CHK(record(h, 0));
+    CHK(mlp_enqueue(h, static_cast<const float*>(d_q), nq, nb, d_order, d_logits));
+    CHK(record(h, 1));
+    if (!on_device) {
+        HIPCHK(hipMemcpyAsync(bucket_order, d_order, (size_t)nq * nb * 4, hipMemcpyDeviceToHost, h->stream));
+        if (logits) HIPCHK(hipMemcpyAsync(logits, d_logits, (size_t)nq * L * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return 0;
+}
+
+static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_order, int nb, int kout, int raw,
+                        float* d_dists, uint32_t* d_ids, uint32_t* d_keys) {
+    const int L = h->L;
+    const int nslots = nq * nb;
+    const long long ncb_bound = (long long)nslots / 32 + L + 4;
+    // partial-list bound: every query visits nb distinct buckets -> at most the nb largest chunk counts
+    std::vector<int> nch_sorted(h->h_nch);
+    std::sort(nch_sorted.begin(), nch_sorted.end(), std::greater<int>());
+    long long per_query = 0;
+    for (int i = 0; i < std::min(nb, L); ++i) per_query += nch_sorted[i];
+    if (nb > L) per_query += (long long)(nb - L) * (nch_sorted.empty() ? 0 : nch_sorted[0]);
+    const long long part_lists = std::max<long long>(1, per_query * nq);
+
+    CHK(h->m.reserve(L * 4));
+    CHK(h->cb_start.reserve((L + 1) * 4));
+    CHK(h->item_base.reserve((L + 1) * 4));
+    CHK(h->part_base.reserve((L + 1) * 8));
+    CHK(h->stats.reserve(16));
+    CHK(h->head.reserve(16));
+    CHK(h->slot_local.reserve((size_t)nslots * 4));
+    CHK(h->slot_col.reserve((size_t)nslots * 4));
+    CHK(h->colmap.reserve((size_t)ncb_bound * 32 * 4));
+    CHK(h->qfrag.reserve((size_t)ncb_bound * h->KGs * 1024));
+    CHK(h->part_score.reserve((size_t)part_lists * KPB * 4));
+    CHK(h->part_row.reserve((size_t)part_lists * KPB * 4));
+    CHK(h->rank_d.reserve((size_t)nslots * KPB * 4));
+    CHK(h->rank_id.reserve((size_t)nslots * KPB * 4));
+
+    RouteArrays R;
+    R.nb_rows = h->d_nb_rows.as<int>();
+    R.nch = h->d_nch.as<int>();
+    R.m = h->m.as<int>();
+    R.cb_start = h->cb_start.as<int>();
+    R.item_base = h->item_base.as<int>();
+    R.part_base = h->part_base.as<long long>();
+    R.stats = h->stats.as<long long>();
+
+    HIPCHK(hipMemsetAsync(h->m.p, 0, L * 4, h->stream));
+    HIPCHK(hipMemsetAsync(h->head.p, 0, 16, h->stream));
+    HIPCHK(hipMemsetAsync(h->colmap.p, 0xFF, (size_t)ncb_bound * 32 * 4, h->stream));
+    route_count_kernel<<<cdiv(nslots, 256), 256, 0, h->stream>>>(d_order, nslots, L, R, h->slot_local.as<int>());
+    HIPCHK(hipGetLastError());
+    route_scan_kernel<<<1, 256, 0, h->stream>>>(L, R);
+    HIPCHK(hipGetLastError());
+    route_fill_kernel<<<cdiv(nslots, 256), 256, 0, h->stream>>>(d_order, h->slot_local.as<int>(), nslots, nb,
+                                                               R.cb_start, h->colmap.as<int>(), h->slot_col.as<int>());
+    HIPCHK(hipGetLastError());
+    {
+        long long total = ncb_bound * 32 * h->KGs;
+        pack_gather_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(d_qs, h->d, h->colmap.as<int>(), nq, ncb_bound * 32,
+                                                                   h->KGs, h->qfrag.as<float4>());
+        HIPCHK(hipGetLastError());
+    }
+    CHK(record(h, 2));
+    ScanParams S;
+    S.slab = h->slab.as<float4>();
+    S.qfrag = h->qfrag.as<float4>();
+    S.KG = h->KGs;
+    S.L = L;
+    S.chunk_rb = h->chunk_rows / 32;
+    S.rb_start = h->d_rb_start.as<int>();
+    S.nb_rows = R.nb_rows;
+    S.nch = R.nch;
+    S.m = R.m;
+    S.cb_start = R.cb_start;
+    S.item_base = R.item_base;
+    S.part_base = R.part_base;
+    S.head = h->head.as<unsigned>();
+    S.part_score = h->part_score.as<float>();
+    S.part_row = h->part_row.as<unsigned>();
+    scan_kernel<<<h->num_cus * h->scan_blocks_per_cu, 256, SCAN_LDS, h->stream>>>(S);
+    HIPCHK(hipGetLastError());
+    CHK(record(h, 3));
+    MergeParams M;
+    M.bucket_order = d_order;
+    M.slot_col = h->slot_col.as<int>();
+    M.nq = nq;
+    M.nb = nb;
+    M.L = L;
+    M.kout = kout;
+    M.raw = raw;
+    M.rb_start = S.rb_start;
+    M.nb_rows = R.nb_rows;
+    M.nch = R.nch;
+    M.cb_start = R.cb_start;
+    M.part_base = R.part_base;
+    M.part_score = S.part_score;
+    M.part_row = S.part_row;
+    M.ids_slab = h->ids_slab.as<unsigned>();
+    M.rank_d = h->rank_d.as<float>();
+    M.rank_id = h->rank_id.as<unsigned>();
+    M.out_d = d_dists;
+    M.out_id = d_ids;
+    M.out_key = d_keys;
+    merge_kernel<<<nq, 64, 0, h->stream>>>(M);
+    HIPCHK(hipGetLastError());
+    CHK(record(h, 4));
+    h->stats_pending = true;
+    return 0;
+}
+
+static int check_scan_args(lmi_index* h, int nq, int nb, int k, int* kout) {
+    if (!h->built) return fail("lmi_scan_topk: the bucket index is not built (lmi_buckets_begin/add_rows/end)");
+    if (nq < 0 || nb < 1) return fail("lmi_scan_topk: bad nq/n_buckets");
+    if (k < 1 || k > LMI_MAX_K) return fail("lmi_scan_topk: k %d outside [1,%d]", k, LMI_MAX_K);
+    *kout = nb == 1 ? KPB : k;  // LearnedIndex.py:122-124: a single rank is returned unmerged
+    if ((long long)nb * KPB < *kout) return fail("lmi_scan_topk: k %d exceeds n_buckets*10 candidates", k);
+    if ((long long)nq * nb >= (1ll << 31)) return fail("lmi_scan_topk: nq*n_buckets too large");
+    return 0;
+}
+
+extern "C" int lmi_scan_topk(lmi_index* h, const float* queries_search, int nq, const int32_t* bucket_order,
+                             int nb, int k, float* dists, uint32_t* ids, uint32_t* keys, int on_device) {
+    if (!h) return fail("lmi_scan_topk: NULL handle");
+    int kout = 0;
+    CHK(check_scan_args(h, nq, nb, k, &kout));
+    if (nq == 0) return 0;
+    CHK(set_dev(h));
+    const void* d_qs = nullptr;
+    const void* d_order = nullptr;
+    CHK(input_ptr(h, queries_search, (size_t)nq * h->d * 4, on_device, h->q_srch, &d_qs));
+    CHK(input_ptr(h, bucket_order, (size_t)nq * nb * 4, on_device, h->order, &d_order));
+    float* d_d = dists;
+    uint32_t* d_i = ids;
+    uint32_t* d_k = keys;
+    if (!on_device) {
+        CHK(h->out_d.reserve((size_t)nq * kout * 4));
+        CHK(h->out_id.reserve((size_t)nq * kout * 4));
+        d_d = h->out_d.as<float>();
+        d_i = h->out_id.as<uint32_t>();
+        if (keys) { CHK(h->out_key.reserve((size_t)nq * kout * 4)); d_k = h->out_key.as<uint32_t>(); }
+    }
+    for (int i = 0; i < 6; ++i) h->ev_valid[i] = false;
+    CHK(record(h, 1));
+    CHK(scan_enqueue(h, static_cast<const float*>(d_qs), nq, static_cast<const int*>(d_order), nb, kout, 0, d_d, d_i, d_k));
+    if (!on_device) {
+        HIPCHK(hipMemcpyAsync(dists, d_d, (size_t)nq * kout * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(ids, d_i, (size_t)nq * kout * 4, hipMemcpyDeviceToHost, h->stream));
+        if (keys) HIPCHK(hipMemcpyAsync(keys, d_k, (size_t)nq * kout * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return 0;
+}
+
+extern "C" int lmi_search(lmi_index* h, const float* queries_nav, const float* queries_search, int nq, int nb,
+                          int k, float* dists, uint32_t* ids, uint32_t* keys, int32_t* bucket_order, int on_device) {
+    if (!h) return fail("lmi_search: NULL handle");
+    int kout = 0;
+    CHK(check_scan_args(h, nq, nb, k, &kout));
+    if (h->n_layers == 0) return fail("lmi_search: no MLP set (lmi_set_mlp)");
+    if (h->dims[h->n_layers] != h->L) return fail("lmi_search: MLP has %d classes, index has %d buckets", h->dims[h->n_layers], h->L);
+    if (nq == 0) return 0;
+    CHK(set_dev(h));
+    const void* d_qn = nullptr;
+    const void* d_qs = nullptr;
+    CHK(input_ptr(h, queries_nav, (size_t)nq * h->dims[0] * 4, on_device, h->q_nav, &d_qn));
+    if (queries_search == queries_nav && h->dims[0] == h->d) d_qs = d_qn;
+    else CHK(input_ptr(h, queries_search, (size_t)nq * h->d * 4, on_device, h->q_srch, &d_qs));
+    int* d_order = bucket_order;
+    float* d_d = dists;
+    uint32_t* d_i = ids;
+    uint32_t* d_k = keys;
+    if (!on_device || !bucket_order) { CHK(h->order.reserve((size_t)nq * nb * 4)); d_order = h->order.as<int>(); }
+    if (!on_device) {
+        CHK(h->out_d.reserve((size_t)nq * kout * 4));
+        CHK(h->out_id.reserve((size_t)nq * kout * 4));
+        d_d = h->out_d.as<float>();
+        d_i = h->out_id.as<uint32_t>();
+        if (keys) { CHK(h->out_key.reserve((size_t)nq * kout * 4)); d_k = h->out_key.as<uint32_t>(); }
+    }
+    for (int i = 0; i < 6; ++i) h->ev_valid[i] = false;
+    CHK(record(h, 0));
+    CHK(mlp_enqueue(h, static_cast<const float*>(d_qn), nq, nb, d_order, nullptr));
+    CHK(record(h, 1));
+    CHK(scan_enqueue(h, static_cast<const float*>(d_qs), nq, d_order, nb, kout, 0, d_d, d_i, d_k));
+    if (!on_device) {
+        HIPCHK(hipMemcpyAsync(dists, d_d, (size_t)nq * kout * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(ids, d_i, (size_t)nq * kout * 4, hipMemcpyDeviceToHost, h->stream));
+        if (keys) HIPCHK(hipMemcpyAsync(keys, d_k, (size_t)nq * kout * 4, hipMemcpyDeviceToHost, h->stream));
+        if (bucket_order) HIPCHK(hipMemcpyAsync(bucket_order, d_order, (size_t)nq * nb * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return 0;
+}
+
+extern "C" int lmi_merge_gathered(lmi_index* h, const float* gd, const uint32_t* gi, const uint32_t* gk, int world,
+                                  int nq, int kout, float* dists, uint32_t* ids, int on_device) {
+    if (!h) return fail("lmi_merge_gathered: NULL handle");
+    if (world < 1 || world > 64) return fail("lmi_merge_gathered: world %d outside [1,64]", world);
+    if (nq <= 0 || kout < 1) return nq == 0 ? 0 : fail("lmi_merge_gathered: bad nq/kout");
+    CHK(set_dev(h));
+    const size_t nin = (size_t)world * nq * kout * 4, nout = (size_t)nq * kout * 4;
+    if (on_device) {
+        merge_gathered_kernel<<<nq, 64, 0, h->stream>>>(gd, gi, gk, world, nq, kout, dists, ids);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    DevBuf in, out;
+    CHK(in.reserve(3 * nin));
+    CHK(out.reserve(2 * nout));
+    char* ip = in.as<char>();
+    HIPCHK(hipMemcpyAsync(ip, gd, nin, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(ip + nin, gi, nin, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(ip + 2 * nin, gk, nin, hipMemcpyHostToDevice, h->stream));
+    merge_gathered_kernel<<<nq, 64, 0, h->stream>>>(reinterpret_cast<float*>(ip), reinterpret_cast<unsigned*>(ip + nin),
+                                                   reinterpret_cast<unsigned*>(ip + 2 * nin), world, nq, kout,
+                                                   out.as<float>(), reinterpret_cast<unsigned*>(out.as<char>() + nout));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(dists, out.p, nout, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(ids, out.as<char>() + nout, nout, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    in.release();
+    out.release();
+    return 0;
+}
+
+extern "C" int lmi_knn_ip(int device, const float* xq, int64_t nq, const float* xb, int64_t nb, int d, int k,
+                          float* D, int64_t* I) {
+    if (k < 1 || k > KPB) return fail("lmi_knn_ip: k %d outside [1,%d]", k, KPB);
+    if (nq < 0 || nb < 0 || d < 1) return fail("lmi_knn_ip: bad sizes");
+    if (nq >= (1ll << 31)) return fail("lmi_knn_ip: nq too large");
+    for (int64_t i = 0; i < nq * k; ++i) { D[i] = -FLT_MAX; I[i] = -1; }
+    if (nq == 0 || nb == 0) return 0;
+    lmi_index* h = nullptr;
+    CHK(lmi_create(device, &h));
+    int rc = 0;
+    std::vector<int64_t> labels((size_t)nb, 0);
+    std::vector<int32_t> order((size_t)nq, 0);
+    std::vector<float> dd((size_t)nq * KPB);
+    std::vector<uint32_t> ii((size_t)nq * KPB);
+    do {
+        if ((rc = lmi_buckets_begin(h, nb, d, 1, labels.data(), nullptr, nullptr))) break;
+        if ((rc = lmi_buckets_add_rows(h, xb, 0, nb, 0))) break;
+        if ((rc = lmi_buckets_end(h))) break;
+        if ((rc = hipSetDevice(device) == hipSuccess ? 0 : fail("hipSetDevice"))) break;
+        const void *d_qs, *d_order;
+        if ((rc = input_ptr(h, xq, (size_t)nq * d * 4, 0, h->q_srch, &d_qs))) break;
+        if ((rc = input_ptr(h, order.data(), (size_t)nq * 4, 0, h->order, &d_order))) break;
+        if ((rc = h->out_d.reserve((size_t)nq * KPB * 4))) break;
+        if ((rc = h->out_id.reserve((size_t)nq * KPB * 4))) break;
+        if ((rc = scan_enqueue(h, static_cast<const float*>(d_qs), (int)nq, static_cast<const int*>(d_order), 1, KPB, 1,
+                               h->out_d.as<float>(), h->out_id.as<uint32_t>(), nullptr))) break;
+        if (hipMemcpy(dd.data(), h->out_d.p, dd.size() * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(ii.data(), h->out_id.p, ii.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+            rc = fail("lmi_knn_ip: result copy failed");
+            break;
+        }
+        for (int64_t q = 0; q < nq; ++q)
+            for (int j = 0; j < k; ++j) {
+                D[q * k + j] = dd[q * KPB + j];
+                I[q * k + j] = ii[q * KPB + j] == NOROW ? -1 : (int64_t)ii[q * KPB + j];
+            }
+    } while (0);
+    std::string keep = g_err;
+    lmi_destroy(h);
+    if (rc) g_err = keep;
+    return rc;
+}
+
+extern "C" int lmi_timings(lmi_index* h, float* ms) {
+    if (!h || !ms) return fail("lmi_timings: NULL argument");
+    CHK(set_dev(h));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < LMI_T_COUNT; ++i) ms[i] = 0.0f;
+    auto span = [&](int a, int b, float* out) -> int {
+        if (h->ev_valid[a] && h->ev_valid[b]) HIPCHK(hipEventElapsedTime(out, h->ev[a], h->ev[b]));
+        return 0;
+    };
+    CHK(span(0, 1, &ms[LMI_T_INFERENCE]));
+    CHK(span(1, 2, &ms[LMI_T_ROUTE]));
+    CHK(span(2, 3, &ms[LMI_T_SCAN]));
+    CHK(span(3, 4, &ms[LMI_T_MERGE]));
+    int first = h->ev_valid[0] ? 0 : 1;
+    int last = h->ev_valid[4] ? 4 : 1;
+    CHK(span(first, last, &ms[LMI_T_TOTAL]));
+    return 0;
+}
+
+extern "C" int lmi_scan_stats(lmi_index* h, double* flops, int64_t* pairs, int64_t* items) {
+    if (!h) return fail("lmi_scan_stats: NULL handle");
+    CHK(set_dev(h));
+    if (h->stats_pending) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(h->h_stats, h->stats.p, 16, hipMemcpyDeviceToHost));
+        h->stats_pending = false;
+    }
+    if (pairs) *pairs = h->h_stats[0];
+    if (items) *items = h->h_stats[1];
+    if (flops) *flops = 2.0 * h->d * (double)h->h_stats[0];
+    return 0;
+}

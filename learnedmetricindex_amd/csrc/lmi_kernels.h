@@ -1,0 +1,676 @@
+// lmi_kernels.h -- gfx950 (MI355X / CDNA4) device code for the LearnedMetricIndex query hot path.
+//
+// Data layout ("fragment-major", the one layout every GEMM-shaped kernel here consumes):
+//   a matrix M[R][K] (R rows, K-contiguous) is stored as float4 F[R/32][K/8][64] with
+//       F[rb][g][lane].s = M[rb*32 + (lane & 31)][8*g + 2*s + (lane >> 5)],   s = 0..3
+//   i.e. one 1-KiB fragment (rb, g) is exactly the A (or B) operand registers of four consecutive
+//   v_mfma_f32_32x32x2_f32 steps: lane l feeds row/col (l & 31) and k = k0 + (l >> 5).
+//   - a wave reads a fragment with ONE 16-byte load per lane, 1 KiB fully coalesced;
+//   - `global_load_lds_dwordx4` (LDS-DMA) can stage it: its LDS image is lane-linear, which is this
+//     layout, and the later ds_read_b128 at lane*16 is conflict-free;
+//   - the k order inside every accumulator stays 0,1,2,...: the result is the canonical k-ordered
+//     fmaf chain (bit-identical to oracle/lmi_oracle.c).
+//   R is padded to a multiple of 32 and K to a multiple of 32 with zeros (fmaf(0,0,acc) == acc).
+//
+// MFMA orientation: S^T = X . Q^T  (A = index vectors / weight rows, B = queries).  In the 32x32
+// accumulator a lane then owns ONE query column (lane & 31) and 16 rows, so per-query top-k is a
+// per-lane register list with no cross-lane traffic in the hot loop.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lmi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int KPB = 10;         // results per (query, bucket): LearnedIndex.py:334
+constexpr int TILE_ROWS = 128;  // vectors per block tile (4 waves x 32)
+constexpr int TILE_COLS = 128;  // queries per block tile (4 col-blocks x 32)
+constexpr int STAGE_G = 4;      // k-groups (of 8) per LDS stage -> BK = 32
+constexpr int STAGE_BYTES = 32768;  // A: 4 waves x 4 g x 1 KiB, B: 4 col-blocks x 4 g x 1 KiB
+constexpr int SCAN_LDS = 2 * STAGE_BYTES + 64;
+constexpr unsigned NOROW = 0xFFFFFFFFu;
+
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ------------------------------------------------------------------------------------------------
+// pack: row-major -> fragment-major.  One thread per (destination row, k-group).
+//   gather form  (rowmap != nullptr or identity): dst row p <- src row rowmap[p] (-1 -> zeros)
+//   scatter form (pos != nullptr): src row i of this chunk -> dst row pos[row0 + i] (-1 -> dropped)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load8(const float* __restrict__ src, int d, int k0, float (&v)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (k0 + j < d) ? src[k0 + j] : 0.0f;
+}
+
+__global__ void pack_gather_kernel(const float* __restrict__ src, int d, const int* __restrict__ rowmap,
+                                   int n_src_rows, long long n_dst_rows, int KG, float4* __restrict__ dst) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_dst_rows * KG) return;
+    int g = (int)(idx % KG);
+    long long p = idx / KG;
+    long long srow = rowmap ? (long long)rowmap[p] : (p < n_src_rows ? p : -1);
+    float v[8];
+    if (srow >= 0) load8(src + srow * d, d, g * 8, v);
+    else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.0f;
+    }
+    float4* f = dst + ((size_t)(p >> 5) * KG + g) * 64 + (p & 31);
+    f[0] = make_float4(v[0], v[2], v[4], v[6]);
+    f[32] = make_float4(v[1], v[3], v[5], v[7]);
+}
+
+__global__ void pack_scatter_kernel(const float* __restrict__ src, int d, const int* __restrict__ pos,
+                                    long long row0, long long nrows, int KG, float4* __restrict__ dst) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nrows * KG) return;
+    int g = (int)(idx % KG);
+    long long i = idx / KG;
+    long long p = pos[row0 + i];
+    if (p < 0) return;
+    float v[8];
+    load8(src + i * d, d, g * 8, v);
+    float4* f = dst + ((size_t)(p >> 5) * KG + g) * 64 + (p & 31);
+    f[0] = make_float4(v[0], v[2], v[4], v[6]);
+    f[32] = make_float4(v[1], v[3], v[5], v[7]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// MLP layer:  Y^T = W . X^T + b  (ReLU unless last).   model.py:45-49, 97-99, 232
+//   Wf   [n_rb][KG][64]  weights, rows = output features (padded with zero rows)
+//   Xf   [ncb][KG][64]   activations, "rows" = queries
+//   grid (ceil(ncb/4), ceil(n_rb/4)), block 256: wave w -> feature block blockIdx.y*4+w, 4 col-blocks.
+//   Accumulators start at the bias (torch addmm starts from the bias): chain = b + sum_k.
+//   !LAST: output written as the next layer's fragment-major activations (KGn = n_rb_pad*4 groups).
+//    LAST: logits row-major [nq][L].
+// ------------------------------------------------------------------------------------------------
+template <bool LAST>
+__global__ __launch_bounds__(256) void mlp_layer_kernel(const float4* __restrict__ Wf,
+                                                        const float* __restrict__ bias,
+                                                        const float4* __restrict__ Xf, int KG, int n_rb,
+                                                        int ncb, float* __restrict__ out, int KGn,
+                                                        int nq, int L) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = lane >> 5, c = lane & 31;
+    const int rb = blockIdx.y * 4 + w;
+    const int cb0 = blockIdx.x * 4;
+    if (rb >= n_rb) return;
+    f32x16 acc[4];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float bv = bias[rb * 32 + acc_row(r, h)];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[n][r] = bv;
+    }
+    const float4* ap = Wf + (size_t)rb * KG * 64 + lane;
+    const float4* bp[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        int cb = cb0 + n < ncb ? cb0 + n : ncb - 1;  // clamp: duplicates are computed and discarded
+        bp[n] = Xf + (size_t)cb * KG * 64 + lane;
+    }
+    for (int g = 0; g < KG; ++g) {
+        float4 a = ap[(size_t)g * 64];
+        float4 b[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) b[n] = bp[n][(size_t)g * 64];
+        const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const float bv = s == 0 ? b[n].x : s == 1 ? b[n].y : s == 2 ? b[n].z : b[n].w;
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv, acc[n], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int cb = cb0 + n;
+        if (cb >= ncb) continue;
+        const int q = cb * 32 + c;
+        if (LAST) {
+            if (q < nq) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int j = rb * 32 + acc_row(r, h);
+                    if (j < L) out[(size_t)q * L + j] = acc[n][r];
+                }
+            }
+        } else {
+            // feature j = rb*32 + 8*qd + 4*h + i  ->  group rb*4+qd, step s = 2h + (i>>1), half i&1
+            float* o = out + ((size_t)cb * KGn) * 256;
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                float v0 = fmaxf(acc[n][4 * qd + 0], 0.0f), v1 = fmaxf(acc[n][4 * qd + 1], 0.0f);
+                float v2 = fmaxf(acc[n][4 * qd + 2], 0.0f), v3 = fmaxf(acc[n][4 * qd + 3], 0.0f);
+                float* og = o + (size_t)(rb * 4 + qd) * 256;
+                *reinterpret_cast<float2*>(og + (0 * 32 + c) * 4 + 2 * h) = make_float2(v0, v2);
+                *reinterpret_cast<float2*>(og + (1 * 32 + c) * 4 + 2 * h) = make_float2(v1, v3);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Class ranking: first nb entries of `prob.topk(L)` (model.py:239), on the logits,
+// ties -> lower class index.  One wave per query, nb selection passes.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void rank_classes_kernel(const float* __restrict__ logits, int nq, int L,
+                                                         int nb, int* __restrict__ order) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    if (q >= nq) return;
+    const float* l = logits + (size_t)q * L;
+    float pv = INFINITY;
+    int pi = -1;
+    for (int t = 0; t < nb; ++t) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int j = lane; j < L; j += 64) {
+            float v = l[j];
+            bool after = (v < pv) || (v == pv && j > pi);
+            if (after && (v > bv || (v == bv && j < bi))) { bv = v; bi = j; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            float ov = __shfl_xor(bv, o);
+            int oi = __shfl_xor(bi, o);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) order[(size_t)q * nb + t] = (bi == 0x7fffffff) ? -1 : bi;
+        pv = bv;
+        pi = bi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Routing: the GPU twin of the `for bucket: filter_path_idxs(bucket_path, path)` loop
+// (LearnedIndex.py:350-353, utils.py:61-65): queries grouped bucket-major (CSR).
+// ------------------------------------------------------------------------------------------------
+struct RouteArrays {
+    const int* nb_rows;   // [L] objects per bucket (0: empty / not owned)
+    const int* nch;       // [L] scan chunks per bucket
+    int* m;               // [L] queries routed to the bucket (zeroed before route_count)
+    int* cb_start;        // [L+1] col-block prefix
+    int* item_base;       // [L+1] work-item prefix
+    long long* part_base; // [L+1] partial-list prefix
+    long long* stats;     // [0] = sum m_b * n_b (pairs), [1] = items
+};
+
+__global__ void route_count_kernel(const int* __restrict__ bucket_order, int nslots, int L, RouteArrays R,
+                                   int* __restrict__ slot_local) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nslots) return;
+    int b = bucket_order[p];
+    int loc = -1;
+    if (b >= 0 && b < L && R.nb_rows[b] > 0) loc = atomicAdd(&R.m[b], 1);
+    slot_local[p] = loc;
+}
+
+__global__ __launch_bounds__(256) void route_scan_kernel(int L, RouteArrays R) {
+    // one block: thread t owns buckets [t*per, (t+1)*per); exclusive scan of 4 running sums
+    __shared__ long long sh[4][256];
+    const int t = threadIdx.x;
+    const int per = (L + 255) / 256;
+    const int b0 = min(t * per, L), b1 = min(b0 + per, L);
+    long long cb = 0, items = 0, part = 0, pairs = 0;
+    for (int b = b0; b < b1; ++b) {
+        const int m = R.m[b];
+        cb += (m + 31) >> 5;
+        items += (long long)((m + TILE_COLS - 1) / TILE_COLS) * R.nch[b];
+        part += (long long)m * R.nch[b];
+        pairs += (long long)m * R.nb_rows[b];
+    }
+    sh[0][t] = cb; sh[1][t] = items; sh[2][t] = part; sh[3][t] = pairs;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        long long v[4] = {0, 0, 0, 0};
+        if (t >= o)
+            for (int i = 0; i < 4; ++i) v[i] = sh[i][t - o];
+        __syncthreads();
+        for (int i = 0; i < 4; ++i) sh[i][t] += v[i];
+        __syncthreads();
+    }
+    long long ecb = sh[0][t] - cb, eit = sh[1][t] - items, epart = sh[2][t] - part;
+    for (int b = b0; b < b1; ++b) {
+        const int m = R.m[b];
+        R.cb_start[b] = (int)ecb;
+        R.item_base[b] = (int)eit;
+        R.part_base[b] = epart;
+        ecb += (m + 31) >> 5;
+        eit += (long long)((m + TILE_COLS - 1) / TILE_COLS) * R.nch[b];
+        epart += (long long)m * R.nch[b];
+    }
+    if (t == 255) {
+        R.cb_start[L] = (int)sh[0][255];
+        R.item_base[L] = (int)sh[1][255];
+        R.part_base[L] = sh[2][255];
+        R.stats[0] = sh[3][255];
+        R.stats[1] = sh[1][255];
+    }
+}
+
+__global__ void route_fill_kernel(const int* __restrict__ bucket_order, const int* __restrict__ slot_local,
+                                  int nslots, int nb, const int* __restrict__ cb_start,
+                                  int* __restrict__ colmap, int* __restrict__ slot_col) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nslots) return;
+    int loc = slot_local[p];
+    int col = -1;
+    if (loc >= 0) {
+        col = cb_start[bucket_order[p]] * 32 + loc;
+        colmap[col] = p / nb;
+    }
+    slot_col[p] = col;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bucket scan (the hot kernel): replaces `faiss.knn(queries_for_this_bucket, data_in_this_bucket)`
+// for every (rank, bucket) at once (LearnedIndex.py:107-117, 350-365).
+//
+// Persistent grid; work item = (bucket b, query tile qt of 128 columns, chunk ch of chunk_rb
+// row-blocks), query tile fastest so that concurrently running items share the chunk's vectors
+// in L2/MALL.  Per item: for each 128-row vector tile, S^T = X.Q^T by v_mfma_f32_32x32x2_f32 over
+// K in 32-wide stages, both operands staged by LDS-DMA (global_load_lds_dwordx4) into a 2-deep
+// ring; epilogue = threshold test against the lane's running 10th-best + rare sorted insert.
+// Block = 4 waves stacked along the vectors (wave w owns row-block 4*vt+w, all 4 col-blocks), so
+// dead col-blocks of a ragged query tile are skipped uniformly by the whole block.
+// ------------------------------------------------------------------------------------------------
+struct ScanParams {
+    const float4* slab;
+    const float4* qfrag;
+    int KG;  // k-groups per row-block (multiple of STAGE_G)
+    int L;
+    int chunk_rb;
+    const int* rb_start;
+    const int* nb_rows;
+    const int* nch;
+    const int* m;
+    const int* cb_start;
+    const int* item_base;
+    const long long* part_base;
+    unsigned* head;
+    float* part_score;
+    unsigned* part_row;
+};
+
+__device__ __forceinline__ void glds16(const float4* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)gsrc,
+        (__attribute__((address_space(3))) void*)(uintptr_t)lds_wave_base, 16, 0, 0);
+}
+
+// sorted (descending) insert of (s,row) into a 10-entry register list; caller checked s > v[9].
+__device__ __forceinline__ void list_insert(float (&v)[KPB], unsigned (&id)[KPB], float s, unsigned row) {
+#pragma unroll
+    for (int t = KPB - 1; t > 0; --t) {
+        const bool shift = s > v[t - 1];  // strict: an equal, earlier row stays in front
+        const bool here = s > v[t];
+        id[t] = shift ? id[t - 1] : (here ? row : id[t]);
+        v[t] = shift ? v[t - 1] : (here ? s : v[t]);
+    }
+    const bool top = s > v[0];
+    id[0] = top ? row : id[0];
+    v[0] = top ? s : v[0];
+}
+
+__device__ __forceinline__ bool better(float s, unsigned r, float s2, unsigned r2) {
+    return s > s2 || (s == s2 && r < r2);
+}
+
+template <int NCB>
+__device__ __forceinline__ void scan_item(const ScanParams& P, char* smem, int b, int qt, int ch) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, c = lane & 31;
+    const int KG = P.KG, NS = KG / STAGE_G;
+    const int n_b = P.nb_rows[b];
+    const int nrb_b = (n_b + 31) >> 5;
+    const int rb_in_b0 = ch * P.chunk_rb;                       // first row-block of the chunk
+    const int nrb = min(P.chunk_rb, nrb_b - rb_in_b0);          // row-blocks in this chunk
+    const int nvt = (nrb + 3) >> 2;                             // 128-row tiles
+    const int cb0 = P.cb_start[b] + qt * 4;
+    const float4* abase = P.slab + ((size_t)(P.rb_start[b] + rb_in_b0 + w) * KG) * 64 + lane;
+    const float4* bbase = P.qfrag + ((size_t)(cb0 + w) * KG) * 64 + lane;  // wave w stages col-block w
+
+    float lv[NCB][KPB];
+    unsigned li[NCB][KPB];
+#pragma unroll
+    for (int n = 0; n < NCB; ++n)
+#pragma unroll
+        for (int j = 0; j < KPB; ++j) { lv[n][j] = -INFINITY; li[n][j] = NOROW; }
+
+    f32x16 acc[NCB];
+#pragma unroll
+    for (int n = 0; n < NCB; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+
+    const int total = nvt * NS;
+    // stage u -> buffer u&1
+    auto stage = [&](int u) {
+        const int vt = u / NS, t = u - vt * NS;
+        char* buf = smem + (u & 1) * STAGE_BYTES;
+        if (vt * 4 + w < nrb) {
+            const float4* a = abase + ((size_t)vt * 4 * KG + t * STAGE_G) * 64;
+#pragma unroll
+            for (int g = 0; g < STAGE_G; ++g) glds16(a + (size_t)g * 64, buf + (w * STAGE_G + g) * 1024);
+        }
+        if (w < NCB) {
+            const float4* q = bbase + (size_t)(t * STAGE_G) * 64;
+#pragma unroll
+            for (int g = 0; g < STAGE_G; ++g)
+                glds16(q + (size_t)g * 64, buf + 16384 + (w * STAGE_G + g) * 1024);
+        }
+    };
+
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int u = 0; u < total; ++u) {
+        const int vt = u / NS, t = u - vt * NS;
+        if (u + 1 < total) stage(u + 1);
+        const bool live = vt * 4 + w < nrb;  // wave-uniform
+        if (live) {
+            const char* buf = smem + (u & 1) * STAGE_BYTES;
+#pragma unroll
+            for (int g = 0; g < STAGE_G; ++g) {
+                const float4 a = *reinterpret_cast<const float4*>(buf + (w * STAGE_G + g) * 1024 + lane * 16);
+                float4 bq[NCB];
+#pragma unroll
+                for (int n = 0; n < NCB; ++n)
+                    bq[n] = *reinterpret_cast<const float4*>(buf + 16384 + (n * STAGE_G + g) * 1024 + lane * 16);
+                const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                    for (int n = 0; n < NCB; ++n) {
+                        const float bv = s == 0 ? bq[n].x : s == 1 ? bq[n].y : s == 2 ? bq[n].z : bq[n].w;
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv, acc[n], 0, 0, 0);
+                    }
+                }
+            }
+            if (t == NS - 1) {  // tile finished: filter the 16 x NCB scores of this lane
+                const unsigned rowbase = (unsigned)((rb_in_b0 + vt * 4 + w) * 32);
+#pragma unroll
+                for (int n = 0; n < NCB; ++n) {
+                    const float thr = lv[n][KPB - 1];
+                    unsigned mask = 0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        mask |= (unsigned)(acc[n][r] > thr && rowbase + acc_row(r, h) < (unsigned)n_b) << r;
+                    while (mask) {  // rare after warm-up; ascending r == ascending row
+                        const int r = __builtin_ctz(mask);
+                        mask &= mask - 1;
+                        float s = acc[n][0];
+#pragma unroll
+                        for (int i = 1; i < 16; ++i) s = (r == i) ? acc[n][i] : s;
+                        if (s > lv[n][KPB - 1]) list_insert(lv[n], li[n], s, rowbase + acc_row(r, h));
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- merge the 8 (wave, half) lists of every column through LDS, two col-blocks per pass ----
+    float* ms = reinterpret_cast<float*>(smem);                 // [2][32][8][KPB]
+    unsigned* mr = reinterpret_cast<unsigned*>(smem + 2 * 32 * 8 * KPB * 4);
+    const int m_b = P.m[b];
+    const int nch_b = P.nch[b];
+    const long long pbase = P.part_base[b];
+#pragma unroll
+    for (int pass = 0; pass < (NCB + 1) / 2; ++pass) {
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) {
+            const int n = pass * 2 + n2;
+            if (n < NCB) {
+                const int o = ((n2 * 32 + c) * 8 + (w * 2 + h)) * KPB;
+#pragma unroll
+                for (int j = 0; j < KPB; ++j) { ms[o + j] = lv[n][j]; mr[o + j] = li[n][j]; }
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int n2 = tid >> 5, cc = tid & 31, n = pass * 2 + n2;
+            const int col_in_b = qt * TILE_COLS + n * 32 + cc;
+            if (n < NCB && col_in_b < m_b) {
+                const int o = (n2 * 32 + cc) * 8 * KPB;
+                unsigned heads = 0;  // 4 bits per source list
+                const long long dst = (pbase + (long long)col_in_b * nch_b + ch) * KPB;
+                for (int j = 0; j < KPB; ++j) {
+                    float bs = -INFINITY;
+                    unsigned br = NOROW;
+                    int bsrc = 0;
+#pragma unroll
+                    for (int src = 0; src < 8; ++src) {
+                        const int hd = (heads >> (4 * src)) & 15;
+                        if (hd < KPB) {
+                            const float s = ms[o + src * KPB + hd];
+                            const unsigned r = mr[o + src * KPB + hd];
+                            if (better(s, r, bs, br)) { bs = s; br = r; bsrc = src; }
+                        }
+                    }
+                    heads += 1u << (4 * bsrc);
+                    P.part_score[dst + j] = bs;
+                    P.part_row[dst + j] = br;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void scan_kernel(ScanParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* s_item = reinterpret_cast<int*>(smem + 2 * STAGE_BYTES);
+    const int total_items = P.item_base[P.L];
+    for (;;) {
+        if (threadIdx.x == 0) {
+            int it = (int)atomicAdd(P.head, 1u);
+            int b = -1, local = 0;
+            if (it < total_items) {
+                int lo = 0, hi = P.L;  // last b with item_base[b] <= it
+                while (hi - lo > 1) {
+                    int mid = (lo + hi) >> 1;
+                    if (P.item_base[mid] <= it) lo = mid; else hi = mid;
+                }
+                b = lo;
+                local = it - P.item_base[b];
+            }
+            s_item[0] = b;
+            s_item[1] = local;
+        }
+        __syncthreads();
+        const int b = s_item[0], local = s_item[1];
+        __syncthreads();
+        if (b < 0) return;
+        const int m_b = P.m[b];
+        const int nqt = (m_b + TILE_COLS - 1) / TILE_COLS;
+        const int qt = local % nqt, ch = local / nqt;
+        const int ncb = min(4, (m_b - qt * TILE_COLS + 31) >> 5);
+        switch (ncb) {
+            case 1: scan_item<1>(P, smem, b, qt, ch); break;
+            case 2: scan_item<2>(P, smem, b, qt, ch); break;
+            case 3: scan_item<3>(P, smem, b, qt, ch); break;
+            default: scan_item<4>(P, smem, b, qt, ch); break;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Merge (LearnedIndex.py:125-146, 368-371): one wave per query.
+//   phase A, per rank: chunk partials -> top-10 by (sim desc, row asc); dist = 1 - sim (binary32),
+//            id = ids[row]; short buckets padded like faiss (-FLT_MAX / last id);
+//            empty / unowned / invalid bucket -> (+inf, 0).
+//   phase B: ranks merged by (dist asc, rank asc, position asc) == the reference's repeated
+//            hstack + stable argsort; first kout entries.
+// raw != 0 (lmi_knn_ip): dist <- similarity, id <- row (NOROW on padding), no 1 - x.
+// ------------------------------------------------------------------------------------------------
+struct MergeParams {
+    const int* bucket_order;  // [nq][nb]
+    const int* slot_col;      // [nq][nb]
+    int nq, nb, L, kout, raw;
+    const int* rb_start;
+    const int* nb_rows;
+    const int* nch;
+    const int* cb_start;
+    const long long* part_base;
+    const float* part_score;
+    const unsigned* part_row;
+    const unsigned* ids_slab;
+    float* rank_d;      // scratch [nq][nb][KPB]
+    unsigned* rank_id;  // scratch [nq][nb][KPB]
+    float* out_d;       // [nq][kout]
+    unsigned* out_id;
+    unsigned* out_key;  // nullable
+};
+
+__global__ __launch_bounds__(64) void merge_kernel(MergeParams P) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    if (q >= P.nq) return;
+    float* rd = P.rank_d + (size_t)q * P.nb * KPB;
+    unsigned* ri = P.rank_id + (size_t)q * P.nb * KPB;
+    const float FMAXV = 3.402823466e+38f;
+    // ---------------- phase A ----------------
+    for (int r = 0; r < P.nb; ++r) {
+        const int p = q * P.nb + r;
+        const int b = P.bucket_order[p];
+        const int col = P.slot_col[p];
+        if (col < 0) {  // unvisited: LearnedIndex.py:340-341 initial values
+            if (lane < KPB) { rd[r * KPB + lane] = P.raw ? -FMAXV : INFINITY; ri[r * KPB + lane] = P.raw ? NOROW : 0u; }
+            continue;
+        }
+        const int n_b = P.nb_rows[b], nch = P.nch[b];
+        const long long l0 = P.part_base[b] + (long long)(col - P.cb_start[b] * 32) * nch;
+        // lane owns chunk lists lane, lane+64, ...; heads packed 4 bits each (<= 8 lists per lane)
+        unsigned long long heads = 0;
+        float my_s = 0.f;
+        unsigned my_r = 0;
+        for (int j = 0; j < KPB; ++j) {
+            float bs = -INFINITY;
+            unsigned br = NOROW;
+            int bl = -1;
+            int t = 0;
+            for (int chn = lane; chn < nch; chn += 64, ++t) {
+                const int hd = (int)((heads >> (4 * (t & 15))) & 15);
+                if (hd < KPB) {
+                    const float s = P.part_score[(l0 + chn) * KPB + hd];
+                    const unsigned rr = P.part_row[(l0 + chn) * KPB + hd];
+                    if (better(s, rr, bs, br)) { bs = s; br = rr; bl = t; }
+                }
+            }
+            int wl = lane;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float os = __shfl_xor(bs, o);
+                const unsigned orr = __shfl_xor(br, o);
+                const int ol = __shfl_xor(wl, o);
+                if (better(os, orr, bs, br) || (os == bs && orr == br && ol < wl)) { bs = os; br = orr; wl = ol; }
+            }
+            if (wl == lane && bl >= 0) heads += 1ull << (4 * (bl & 15));
+            if (lane == j) { my_s = bs; my_r = br; }
+        }
+        if (lane < KPB) {
+            float dv;
+            unsigned iv;
+            const bool real = my_r != NOROW && lane < n_b;
+            if (P.raw) {
+                dv = real ? my_s : -FMAXV;
+                iv = real ? my_r : NOROW;
+            } else if (real) {
+                dv = 1.0f - my_s;
+                iv = P.ids_slab[(size_t)P.rb_start[b] * 32 + my_r];
+            } else {  // faiss padding: sim = -FLT_MAX, idx = -1 -> last label of the bucket
+                dv = 1.0f - (-FMAXV);
+                iv = P.ids_slab[(size_t)P.rb_start[b] * 32 + (n_b - 1)];
+            }
+            rd[r * KPB + lane] = dv;
+            ri[r * KPB + lane] = iv;
+        }
+    }
+    __syncthreads();  // single wave: orders the global writes above before the reads below
+    // ---------------- phase B ----------------
+    // lane owns ranks lane, lane+64, ...; candidate key (dist, rank); position is implicit (heads)
+    unsigned long long heads = 0;
+    for (int j = 0; j < P.kout; ++j) {
+        float bd = INFINITY;
+        int brk = 0x7fffffff, bt = -1;
+        bool any = false;
+        int t = 0;
+        for (int r = lane; r < P.nb; r += 64, ++t) {
+            const int hd = (int)((heads >> (4 * (t & 15))) & 15);
+            if (hd < KPB) {
+                const float dv = rd[r * KPB + hd];
+                const bool bet = P.raw ? (!any || dv > bd) : (!any || dv < bd);
+                if (bet) { bd = dv; brk = r; bt = t; any = true; }
+            }
+        }
+        if (!any) { bd = P.raw ? -INFINITY : INFINITY; brk = 0x7fffffff; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float od = __shfl_xor(bd, o);
+            const int ork = __shfl_xor(brk, o);
+            const bool bet = P.raw ? (od > bd) : (od < bd);
+            if ((ork != 0x7fffffff) && (brk == 0x7fffffff || bet || (od == bd && ork < brk))) { bd = od; brk = ork; }
+        }
+        // winner rank brk (same on all lanes); its owner advances
+        int pos = 0;
+        if (brk != 0x7fffffff && (brk & 63) == lane) {
+            pos = (int)((heads >> (4 * (bt & 15))) & 15);
+            heads += 1ull << (4 * (bt & 15));
+        }
+        const int owner = brk == 0x7fffffff ? 0 : (brk & 63);
+        pos = __shfl(pos, owner);
+        if (lane == 0) {
+            const size_t o = (size_t)q * P.kout + j;
+            if (brk == 0x7fffffff) {
+                P.out_d[o] = P.raw ? -FMAXV : INFINITY;
+                P.out_id[o] = P.raw ? NOROW : 0u;
+                if (P.out_key) P.out_key[o] = 0xFFFFFFFFu;
+            } else {
+                P.out_d[o] = rd[brk * KPB + pos];
+                P.out_id[o] = ri[brk * KPB + pos];
+                if (P.out_key) P.out_key[o] = (unsigned)brk * 16u + (unsigned)pos;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Multi-GPU: merge of the all-gathered per-GPU results.  gathered [world][nq][kout], every list
+// sorted by (dist, key); output = first kout of the union by (dist asc, key asc).  One wave per
+// query, lane = source GPU (world <= 64).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void merge_gathered_kernel(const float* __restrict__ gd,
+                                                           const unsigned* __restrict__ gi,
+                                                           const unsigned* __restrict__ gk, int world,
+                                                           int nq, int kout, float* __restrict__ od,
+                                                           unsigned* __restrict__ oi) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    if (q >= nq) return;
+    int head = 0;
+    const size_t base = ((size_t)lane * nq + q) * kout;
+    for (int j = 0; j < kout; ++j) {
+        float d = INFINITY;
+        unsigned key = 0xFFFFFFFFu;
+        if (lane < world && head < kout) { d = gd[base + head]; key = gk[base + head]; }
+        int wl = lane;
+        float bd = d;
+        unsigned bk = key;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float odv = __shfl_xor(bd, o);
+            const unsigned okv = __shfl_xor(bk, o);
+            const int ol = __shfl_xor(wl, o);
+            if (odv < bd || (odv == bd && (okv < bk || (okv == bk && ol < wl)))) { bd = odv; bk = okv; wl = ol; }
+        }
+        unsigned idv = 0;
+        if (lane == wl && lane < world && head < kout) { idv = gi[base + head]; ++head; }
+        idv = __shfl(idv, wl);
+        if (lane == 0) { od[(size_t)q * kout + j] = bd; oi[(size_t)q * kout + j] = idv; }
+    }
+}
+
+}  // namespace lmi
