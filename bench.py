@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""bench.py -- queries/sec of the LearnedMetricIndex query hot path on MI355X.
+
+A "step" = one LearnedIndex.search of the whole query batch: MLP forward -> top-n_buckets ->
+routing -> bucket scan -> merge, inputs and outputs resident in HBM (the PCIe-inclusive figure is
+in DESIGN.md).  Default workload = BASELINE.json configs[1]: 10M x 768 synthetic unit-norm vectors
+(LAION-10M shape), 120 leaves, MLP-4 (768->512->120), top-4 buckets, 10k queries, 1 x MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: the index is bucket-sharded over the ranks, every rank answers the same batch on its own
+buckets and ONE RCCL all-gather + merge kernel produces the result (total work fixed: "strong").
+Rank 0 prints ONE JSON line (see the keys at the bottom).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+CONFIGS = {
+    # name: (N, d, leaves, hidden model, n_buckets, nq)
+    "c1": dict(n=100_000, d=768, leaves=120, model="MLP-4", nb=4, nq=1_000),
+    "c2": dict(n=10_000_000, d=768, leaves=120, model="MLP-4", nb=4, nq=10_000),
+    "c4": dict(n=100_000_000, d=768, leaves=1024, model="MLP-4", nb=8, nq=10_000),
+    "c5": dict(n=10_000_000, d=45, leaves=256, model="MLP-4", nb=4, nq=10_000),
+}
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+CHUNK = 1 << 19  # rows generated / ingested per piece
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--n", type=int)
+    ap.add_argument("--nq", type=int)
+    ap.add_argument("--nb", type=int)
+    ap.add_argument("--leaves", type=int)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--seed", type=int, default=2023)
+    ap.add_argument("--train-rows", type=int, default=200_000)
+    ap.add_argument("--epochs", type=int, default=200)
+    ap.add_argument("--recall-queries", type=int, default=1000)
+    ap.add_argument("--cpu-queries", type=int, default=48)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-recall", action="store_true")
+    ap.add_argument("--chunk-rows", type=int, default=None)
+    ap.add_argument("--traffic-json", default=None, help="PMC-derived HBM bytes per scan launch (profiles/*.json)")
+    args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    for key in ("n", "nq", "nb", "leaves"):
+        if getattr(args, key) is not None:
+            cfg[key] = getattr(args, key)
+    N, d, L, nb, nq, k = cfg["n"], cfg["d"], cfg["leaves"], cfg["nb"], cfg["nq"], args.k
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from learnedmetricindex_amd import _capi
+    from learnedmetricindex_amd.li.model import NeuralNetwork, linear_layers
+    from learnedmetricindex_amd.sharded import ShardedSearcher, assign_buckets
+
+    t_setup = time.time()
+    # ------------------------------------------------------------------ synthetic data
+    gcpu = torch.Generator().manual_seed(args.seed)
+    centres = torch.randn(L, d, generator=gcpu).to(dev)
+
+    def gen_rows(tag: int, piece: int, n: int):
+        g = torch.Generator(device=dev).manual_seed(args.seed * 1_000_003 + tag * 100_003 + piece)
+        a = torch.randint(0, L, (n,), generator=g, device=dev)
+        x = centres[a] + torch.randn(n, d, generator=g, device=dev)
+        return torch.nn.functional.normalize(x, dim=1).contiguous()
+
+    pieces = [(p, min(CHUNK, N - p * CHUNK)) for p in range((N + CHUNK - 1) // CHUNK)]
+    queries = gen_rows(7, 0, nq)  # fresh draws, not members of the set
+
+    # ------------------------------------------------------------------ MLP: k-means labels -> Adam/CE
+    net = NeuralNetwork(input_dim=d, output_dim=L, lr=0.01, model_type=cfg["model"])
+    if rank == 0:
+        torch.manual_seed(args.seed)
+        ntr = min(args.train_rows, N)
+        xtr = torch.cat([gen_rows(1, p, n) for p, n in pieces[: (ntr + CHUNK - 1) // CHUNK]])[:ntr]
+        cent = xtr[torch.randperm(ntr, device=dev)[:L]].clone()
+        for _ in range(10):  # Lloyd iterations (faiss/sklearn k-means stand-in; offline build step)
+            lab = (xtr @ cent.T).argmax(1)
+            cent = torch.zeros_like(cent).index_add_(0, lab, xtr)
+            cent = torch.nn.functional.normalize(cent, dim=1)
+        lab = (xtr @ cent.T).argmax(1)
+        net.train(xtr, lab, epochs=args.epochs)
+        del xtr, lab, cent
+    if world > 1:
+        for p_ in net.model.parameters():
+            dist.broadcast(p_.data, src=0)
+    layers = linear_layers(net.model)
+
+    # ------------------------------------------------------------------ placement: argmax MLP(x) over all N
+    eng = _capi.Index(local_rank, chunk_rows=args.chunk_rows)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.set_mlp(layers)
+    labels = torch.empty(N, dtype=torch.int32, device=dev)
+    for p, n in pieces:
+        x = gen_rows(1, p, n)
+        eng.mlp_topk_device(x, 1, labels[p * CHUNK: p * CHUNK + n])
+    torch.cuda.synchronize()
+    labels_h = labels.cpu().numpy().astype(np.int64)
+    sizes = np.bincount(labels_h, minlength=L)
+    owner = assign_buckets(sizes, world, weights=sizes.astype(np.float64) ** 2)
+    owned = (owner == rank).astype(np.uint8) if world > 1 else None
+    eng.buckets_begin(labels_h, d, L, owned=owned)
+    for p, n in pieces:
+        eng.add_rows(gen_rows(1, p, n), p * CHUNK)
+        torch.cuda.synchronize()
+    eng.buckets_end()
+    del labels
+    torch.cuda.empty_cache()
+    if rank == 0:
+        log(f"[bench] index built in {time.time() - t_setup:.1f}s: N={N} d={d} L={L} bucket sizes "
+            f"min/median/max = {sizes.min()}/{int(np.median(sizes))}/{sizes.max()}, empty={int((sizes == 0).sum())}")
+
+    # ------------------------------------------------------------------ the timed region
+    searcher = ShardedSearcher(eng, rank, world)
+
+    def step():
+        return searcher.search(queries, queries, nb, k)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    scan_ms, flops = [], 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out_d, out_i, bo = step()
+        scan_ms.append(float(eng.timings()[_capi.T_SCAN]))  # hipEvents on the kernel's own stream
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    tm = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    elapsed = float(tm.item())
+    flops, pairs, items = eng.scan_stats()
+    phases = eng.timings()
+
+    # ------------------------------------------------------------------ recall@10 vs exact brute force
+    recall = None
+    if not args.no_recall:
+        nr = min(args.recall_queries, nq)
+        gt_d, gt_i, _ = ShardedSearcher(eng, rank, world).search(queries[:nr].contiguous(), queries[:nr].contiguous(), L, k)
+        got = out_i[:nr].cpu().numpy().astype(np.int64)
+        gt = gt_i.cpu().numpy().astype(np.int64)
+        recall = float(np.mean([len(set(a) & set(b)) / float(k) for a, b in zip(got, gt)]))
+
+    # ------------------------------------------------------------------ CPU baseline (oracle), rank 0, N=1
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import lmi_oracle
+
+        ns = min(args.cpu_queries, nq)
+        qh = queries[:ns].cpu().numpy()
+        t_cpu = time.perf_counter()
+        order_o = lmi_oracle.precompute_bucket_order(layers, qh, nb, nthreads=1)
+        t_cpu = time.perf_counter() - t_cpu
+        assert np.array_equal(order_o[:, :, 0], bo[:ns].cpu().numpy()), "oracle bucket order differs from the GPU's"
+        # reference structure (LearnedIndex.py:107-146, 350-371): for every visited bucket, per rank,
+        # knn over the bucket + 1 - sim + id mapping, then the stable merge; only that work is timed,
+        # not the device->host copy of the bucket.
+        rank_d = np.full((nb, ns, 10), np.inf)
+        rank_i = np.zeros((nb, ns, 10), dtype=np.uint32)
+        for b in np.unique(order_o[:, :, 0]):
+            rows, ids = eng.read_bucket(int(b))
+            if rows.shape[0] == 0:
+                continue
+            t1 = time.perf_counter()
+            for r in range(nb):
+                rel = np.flatnonzero(order_o[:, r, 0] == b)
+                if rel.size:
+                    sim, idx = lmi_oracle.knn_ip(qh[rel], rows, 10, nthreads=1)
+                    rank_d[r, rel] = np.float32(1) - sim
+                    rank_i[r, rel] = ids[idx]
+            t_cpu += time.perf_counter() - t1
+        t1 = time.perf_counter()
+        fd = fi = None
+        for r in range(nb):
+            fd, fi = lmi_oracle.merge_rank(fd, fi, rank_d[r], rank_i[r], k)
+        t_cpu += time.perf_counter() - t1
+        same = bool(np.array_equal(fi, out_i[:ns].cpu().numpy().view(np.uint32)) and
+                    np.array_equal(fd, out_d[:ns].cpu().numpy().astype(np.float64)))
+        assert same, "CPU oracle and GPU results differ on the sampled queries"
+        cpu = {"value": round(ns / t_cpu, 3), "unit": "queries/s", "cores": 1, "kind": "port",
+               "sample": f"first {ns} of {nq} queries, all {nb} ranks, full {N}x{d} index; "
+                         f"oracle/lmi_oracle.c single thread; ids and distances identical to the GPU's"}
+
+    if rank == 0:
+        scan_s = float(np.mean(scan_ms)) * 1e-3
+        # sharded runs: rank 0's kernel sees only its own buckets' flops
+        achieved = flops / scan_s / 1e12 if scan_s > 0 else 0.0
+        visited = np.unique(bo.cpu().numpy())
+        visited = visited[(visited >= 0) & (owner[np.clip(visited, 0, L - 1)] == rank)]
+        compulsory = 4.0 * d * float(sizes[visited].sum())  # every visited bucket read once per batch
+        traffic = None
+        if args.traffic_json and os.path.exists(args.traffic_json):
+            traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_launch")
+        result = {
+            "metric": "queries/sec @ recall@10, 768-d 10M index, 10k query batch",
+            "value": round(nq * args.steps / elapsed, 2),
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "recall_at_10": None if recall is None else round(recall, 5),
+            "config": {"workload": f"{N}x{d} unit-norm gaussian-mixture vectors, 1-level LMI ({L} leaves, "
+                                   f"{cfg['model']} {d}->512->{L} trained {args.epochs} epochs), top-{nb} buckets, "
+                                   f"{nq}-query batch, k={k}",
+                       "baseline_config": args.config, "parallelism": "single GPU" if world == 1 else f"bucket-sharded x{world} + 1 all-gather",
+                       "scan_pairs": int(pairs), "scan_items": int(items)},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "kernel": "lmi::scan_kernel", "flops_per_launch": flops,
+                         "avg_launch_ms": round(scan_s * 1e3, 4),
+                         "hbm_frac_compulsory": round(compulsory / scan_s / 1e9 / PEAK_HBM_GBS, 4)},
+            "cpu_baseline": cpu,
+            "phases_ms": {"inference": round(float(phases[0]), 4), "route_pack": round(float(phases[1]), 4),
+                          "scan": round(float(phases[2]), 4), "merge": round(float(phases[3]), 4)},
+        }
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

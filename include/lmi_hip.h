@@ -9,6 +9,7 @@
  *   lmi_set_mlp / lmi_mlp_topk     NeuralNetwork.predict_proba            model.py:226-241
  *                                  (Sequential(Linear,ReLU,..)(x), softmax, topk)  model.py:45-49,97-99
  *                                  + _precompute_bucket_order 1-level     LearnedIndex.py:197-214
+ *   lmi_mlp_proba                  NeuralNetwork.predict_proba (probabilities + full class order)
  *   lmi_buckets_*                  data_navigation.groupby(category_L*) + data_search.loc[...]
  *                                                                         LearnedIndex.py:101-104,350,357
  *   lmi_scan_topk                  the `for rank` x `for bucket` loop: filter_path_idxs, faiss.knn,
@@ -85,11 +86,20 @@ int lmi_buckets_add_rows(lmi_index *h, const float *rows, int64_t row0, int64_t 
 int lmi_buckets_end(lmi_index *h);
 /* sizes[L] <- number of objects per bucket (0 for buckets not owned). */
 int lmi_bucket_sizes(lmi_index *h, int64_t *sizes);
+/* Reads one bucket back to the host in bucket order (what `data_search.loc[g.index].to_numpy()`
+ * and `g.index.to_numpy()` return, LearnedIndex.py:351,357): rows[n_b][d], ids[n_b]; either may
+ * be NULL. */
+int lmi_bucket_read(lmi_index *h, int bucket, float *rows, uint32_t *ids);
 
 /* Navigation: bucket_order[nq][nb] <- the nb most probable classes per query, most probable first.
  * logits (nullable) [nq][L] <- raw outputs of the last Linear layer. */
 int lmi_mlp_topk(lmi_index *h, const float *queries_nav, int nq, int nb, int32_t *bucket_order,
                  float *logits, int on_device);
+
+/* NeuralNetwork.predict_proba (model.py:226-241): probs[nq][L] = softmax of the outputs sorted
+ * descending, classes[nq][L] = the matching class indices (int32; the reference returns int64). */
+int lmi_mlp_proba(lmi_index *h, const float *queries_nav, int nq, float *probs, int32_t *classes,
+                  int on_device);
 
 /* Scan: for every query, top-LMI_K_PER_BUCKET by inner product inside each of its nb buckets,
  * dist = 1 - ip (binary32), merged over the ranks to k results (k <= LMI_MAX_K).
@@ -104,11 +114,12 @@ int lmi_search(lmi_index *h, const float *queries_nav, const float *queries_sear
                int k, float *dists, uint32_t *ids, uint32_t *keys, int32_t *bucket_order,
                int on_device);
 
-/* Multi-GPU: gathered_{dists,ids,keys} are [world][nq][kout] (the all-gather of every rank's
- * lmi_scan_topk outputs); writes the merged dists/ids [nq][kout]. */
+/* Multi-GPU: gathered_{dists,ids,keys}[w] is rank w's lmi_scan_topk output [nq][kout], found
+ * world_stride elements after rank w-1's (0 -> dense, nq*kout; a packed all-gather of
+ * [dists|ids|keys] per rank uses 3*nq*kout); writes the merged dists/ids [nq][kout]. */
 int lmi_merge_gathered(lmi_index *h, const float *gathered_dists, const uint32_t *gathered_ids,
-                       const uint32_t *gathered_keys, int world, int nq, int kout, float *dists,
-                       uint32_t *ids, int on_device);
+                       const uint32_t *gathered_keys, int world, int64_t world_stride, int nq,
+                       int kout, float *dists, uint32_t *ids, int on_device);
 
 /* faiss.knn(xq, xb, k, metric=METRIC_INNER_PRODUCT) on host pointers: D[nq][k] similarities in
  * descending order, I[nq][k] row numbers; nb < k pads with D = -FLT_MAX, I = -1.  k <= 10. */

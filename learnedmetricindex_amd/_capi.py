@@ -39,12 +39,14 @@ SIGNATURES = {
     "lmi_buckets_end": (ctypes.c_int, [_vp]),
     "lmi_bucket_sizes": (ctypes.c_int, [_vp, _vp]),
     "lmi_mlp_topk": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int]),
+    "lmi_mlp_proba": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int]),
     "lmi_scan_topk": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp,
                                      ctypes.c_int]),
     "lmi_search": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp,
                                   ctypes.c_int]),
-    "lmi_merge_gathered": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp,
-                                          ctypes.c_int]),
+    "lmi_merge_gathered": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
+                                          ctypes.c_int, _vp, _vp, ctypes.c_int]),
+    "lmi_bucket_read": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp]),
     "lmi_knn_ip": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int64, _vp, ctypes.c_int64, ctypes.c_int,
                                   ctypes.c_int, _vp, _vp]),
     "lmi_timings": (ctypes.c_int, [_vp, _vp]),
@@ -184,6 +186,14 @@ class Index:
         _check(lib().lmi_mlp_topk(self._h, _ptr(q), q.shape[0], int(nb), _ptr(order), _ptr(logits), 0))
         return (order, logits) if want_logits else order
 
+    def mlp_proba(self, queries_nav):
+        """(probs f32[n,L] descending, classes i32[n,L]) -- NeuralNetwork.predict_proba."""
+        q = _np(queries_nav, np.float32)
+        probs = np.empty((q.shape[0], self.n_classes), dtype=np.float32)
+        classes = np.empty((q.shape[0], self.n_classes), dtype=np.int32)
+        _check(lib().lmi_mlp_proba(self._h, _ptr(q), q.shape[0], _ptr(probs), _ptr(classes), 0))
+        return probs, classes
+
     @staticmethod
     def kout(nb: int, k: int) -> int:
         return K_PER_BUCKET if nb == 1 else k
@@ -224,10 +234,18 @@ class Index:
         _check(lib().lmi_scan_topk(self._h, _ptr(qs_t), int(qs_t.shape[0]), _ptr(bo_t), int(nb), int(k), _ptr(d_t),
                                    _ptr(i_t), _ptr(keys_t), 1))
 
-    def merge_gathered(self, gd, gi, gk, world: int, nq: int, kout: int, out_d, out_i) -> None:
+    def merge_gathered(self, gd, gi, gk, world: int, nq: int, kout: int, out_d, out_i, world_stride: int = 0) -> None:
         on_device = 0 if isinstance(gd, np.ndarray) else 1
-        _check(lib().lmi_merge_gathered(self._h, _ptr(gd), _ptr(gi), _ptr(gk), int(world), int(nq), int(kout),
-                                        _ptr(out_d), _ptr(out_i), on_device))
+        _check(lib().lmi_merge_gathered(self._h, _ptr(gd), _ptr(gi), _ptr(gk), int(world), int(world_stride),
+                                        int(nq), int(kout), _ptr(out_d), _ptr(out_i), on_device))
+
+    def read_bucket(self, b: int):
+        """(rows f32[n_b,d], ids u32[n_b]) of bucket b, in bucket order."""
+        n = int(self.bucket_sizes()[b])
+        rows = np.empty((n, self.d), dtype=np.float32)
+        ids = np.empty(n, dtype=np.uint32)
+        _check(lib().lmi_bucket_read(self._h, int(b), _ptr(rows), _ptr(ids)))
+        return rows, ids
 
     def timings(self) -> np.ndarray:
         ms = np.zeros(T_COUNT, dtype=np.float32)

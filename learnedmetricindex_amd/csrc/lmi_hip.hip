@@ -307,6 +307,25 @@ extern "C" int lmi_bucket_sizes(lmi_index* h, int64_t* sizes) {
     return 0;
 }
 
+extern "C" int lmi_bucket_read(lmi_index* h, int bucket, float* rows, uint32_t* ids) {
+    if (!h || !h->built) return fail("lmi_bucket_read: the bucket index is not built");
+    if (bucket < 0 || bucket >= h->L) return fail("lmi_bucket_read: bucket %d outside [0,%d)", bucket, h->L);
+    const int64_t n = h->h_nb_rows[bucket];
+    if (n == 0) return 0;
+    CHK(set_dev(h));
+    const int64_t p0 = (int64_t)h->h_rb_start[bucket] * 32;
+    if (rows) {
+        CHK(h->stage.reserve((size_t)n * h->d * 4));
+        long long total = n * cdiv(h->d, 8);
+        unpack_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(h->slab.as<float4>(), h->KGs, p0, n, h->d, h->stage.as<float>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(rows, h->stage.p, (size_t)n * h->d * 4, hipMemcpyDeviceToHost, h->stream));
+    }
+    if (ids) HIPCHK(hipMemcpyAsync(ids, h->ids_slab.as<uint32_t>() + p0, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 static int record(lmi_index* h, int i) {
     HIPCHK(hipEventRecord(h->ev[i], h->stream));
@@ -388,6 +407,38 @@ extern "C" int lmi_mlp_topk(lmi_index* h, const float* queries_nav, int nq, int 
     if (!on_device) {
         HIPCHK(hipMemcpyAsync(bucket_order, d_order, (size_t)nq * nb * 4, hipMemcpyDeviceToHost, h->stream));
         if (logits) HIPCHK(hipMemcpyAsync(logits, d_logits, (size_t)nq * L * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return 0;
+}
+
+extern "C" int lmi_mlp_proba(lmi_index* h, const float* queries_nav, int nq, float* probs, int32_t* classes,
+                             int on_device) {
+    if (!h) return fail("lmi_mlp_proba: NULL handle");
+    if (nq < 0) return fail("lmi_mlp_proba: nq < 0");
+    if (nq == 0) return 0;
+    CHK(set_dev(h));
+    if (h->n_layers == 0) return fail("lmi_mlp_proba: no MLP set (lmi_set_mlp)");
+    const int L = h->dims[h->n_layers];
+    const void* d_q = nullptr;
+    CHK(input_ptr(h, queries_nav, (size_t)nq * h->dims[0] * 4, on_device, h->q_nav, &d_q));
+    int* d_order = classes;
+    float* d_probs = probs;
+    if (!on_device) {
+        CHK(h->order.reserve((size_t)nq * L * 4));
+        CHK(h->out_d.reserve((size_t)nq * L * 4));
+        d_order = h->order.as<int>();
+        d_probs = h->out_d.as<float>();
+    }
+    for (int i = 0; i < 6; ++i) h->ev_valid[i] = false;
+    CHK(record(h, 0));
+    CHK(mlp_enqueue(h, static_cast<const float*>(d_q), nq, L, d_order, nullptr));
+    softmax_ranked_kernel<<<cdiv(nq, 64), 64, 0, h->stream>>>(h->logits.as<float>(), d_order, nq, L, d_probs);
+    HIPCHK(hipGetLastError());
+    CHK(record(h, 1));
+    if (!on_device) {
+        HIPCHK(hipMemcpyAsync(classes, d_order, (size_t)nq * L * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(probs, d_probs, (size_t)nq * L * 4, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     return 0;
@@ -579,17 +630,20 @@ extern "C" int lmi_search(lmi_index* h, const float* queries_nav, const float* q
 }
 
 extern "C" int lmi_merge_gathered(lmi_index* h, const float* gd, const uint32_t* gi, const uint32_t* gk, int world,
-                                  int nq, int kout, float* dists, uint32_t* ids, int on_device) {
+                                  int64_t world_stride, int nq, int kout, float* dists, uint32_t* ids,
+                                  int on_device) {
     if (!h) return fail("lmi_merge_gathered: NULL handle");
     if (world < 1 || world > 64) return fail("lmi_merge_gathered: world %d outside [1,64]", world);
     if (nq <= 0 || kout < 1) return nq == 0 ? 0 : fail("lmi_merge_gathered: bad nq/kout");
     CHK(set_dev(h));
     const size_t nin = (size_t)world * nq * kout * 4, nout = (size_t)nq * kout * 4;
+    if (world_stride == 0) world_stride = (int64_t)nq * kout;
     if (on_device) {
-        merge_gathered_kernel<<<nq, 64, 0, h->stream>>>(gd, gi, gk, world, nq, kout, dists, ids);
+        merge_gathered_kernel<<<nq, 64, 0, h->stream>>>(gd, gi, gk, world, world_stride, nq, kout, dists, ids);
         HIPCHK(hipGetLastError());
         return 0;
     }
+    if (world_stride != (int64_t)nq * kout) return fail("lmi_merge_gathered: host buffers must be dense (world_stride 0)");
     DevBuf in, out;
     CHK(in.reserve(3 * nin));
     CHK(out.reserve(2 * nout));
@@ -598,7 +652,7 @@ extern "C" int lmi_merge_gathered(lmi_index* h, const float* gd, const uint32_t*
     HIPCHK(hipMemcpyAsync(ip + nin, gi, nin, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(ip + 2 * nin, gk, nin, hipMemcpyHostToDevice, h->stream));
     merge_gathered_kernel<<<nq, 64, 0, h->stream>>>(reinterpret_cast<float*>(ip), reinterpret_cast<unsigned*>(ip + nin),
-                                                   reinterpret_cast<unsigned*>(ip + 2 * nin), world, nq, kout,
+                                                   reinterpret_cast<unsigned*>(ip + 2 * nin), world, world_stride, nq, kout,
                                                    out.as<float>(), reinterpret_cast<unsigned*>(out.as<char>() + nout));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(dists, out.p, nout, hipMemcpyDeviceToHost, h->stream));

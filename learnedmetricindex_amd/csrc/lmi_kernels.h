@@ -76,6 +76,22 @@ __global__ void pack_scatter_kernel(const float* __restrict__ src, int d, const 
     f[32] = make_float4(v[1], v[3], v[5], v[7]);
 }
 
+// inverse of pack: fragment-major rows [p0, p0+n) -> row-major [n][d]  (lmi_bucket_read)
+__global__ void unpack_kernel(const float4* __restrict__ src, int KG, long long p0, long long n, int d,
+                              float* __restrict__ dst) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int KGd = (d + 7) >> 3;
+    if (idx >= n * KGd) return;
+    int g = (int)(idx % KGd);
+    long long i = idx / KGd, p = p0 + i;
+    const float4* f = src + ((size_t)(p >> 5) * KG + g) * 64 + (p & 31);
+    const float4 e = f[0], o = f[32];
+    const float v[8] = {e.x, o.x, e.y, o.y, e.z, o.z, e.w, o.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (g * 8 + j < d) dst[i * d + g * 8 + j] = v[j];
+}
+
 // ------------------------------------------------------------------------------------------------
 // MLP layer:  Y^T = W . X^T + b  (ReLU unless last).   model.py:45-49, 97-99, 232
 //   Wf   [n_rb][KG][64]  weights, rows = output features (padded with zero rows)
@@ -181,6 +197,44 @@ __global__ __launch_bounds__(64) void rank_classes_kernel(const float* __restric
         pv = bv;
         pi = bi;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Canonical softmax (model.py:238) + gather in ranked order -> predict_proba's `probs`.
+// lmi_expf is the SAME sequence of binary32 operations as oracle/lmi_oracle.c:lmi_oracle_expf
+// (Cody-Waite reduction and a degree-6 Horner polynomial, all fmaf), so probabilities are
+// bit-identical on both sides; the row sum runs in class-index order.  One thread per query.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lmi_expf(float x) {
+    if (!(x > -87.0f)) return 0.0f;
+    if (x > 88.0f) return INFINITY;
+    const float log2e = 1.44269502162933349609375f;
+    const float ln2hi = 0.693145751953125f;
+    const float ln2lo = 1.42860677279532e-06f;
+    const float nf = __builtin_rintf(x * log2e);
+    float r = __builtin_fmaf(-nf, ln2hi, x);
+    r = __builtin_fmaf(-nf, ln2lo, r);
+    float p = 1.0f / 720.0f;
+    p = __builtin_fmaf(p, r, 1.0f / 120.0f);
+    p = __builtin_fmaf(p, r, 1.0f / 24.0f);
+    p = __builtin_fmaf(p, r, 1.0f / 6.0f);
+    p = __builtin_fmaf(p, r, 0.5f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    const int ni = (int)nf;
+    return p * __uint_as_float((unsigned)(ni + 127) << 23);
+}
+
+__global__ void softmax_ranked_kernel(const float* __restrict__ logits, const int* __restrict__ order, int nq,
+                                      int L, float* __restrict__ probs) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const float* l = logits + (size_t)q * L;
+    float m = l[0];
+    for (int j = 1; j < L; ++j) m = l[j] > m ? l[j] : m;
+    float s = 0.0f;
+    for (int j = 0; j < L; ++j) s += lmi_expf(l[j] - m);
+    for (int t = 0; t < L; ++t) probs[(size_t)q * L + t] = lmi_expf(l[order[(size_t)q * L + t]] - m) / s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -646,12 +700,12 @@ __global__ __launch_bounds__(64) void merge_kernel(MergeParams P) {
 __global__ __launch_bounds__(64) void merge_gathered_kernel(const float* __restrict__ gd,
                                                            const unsigned* __restrict__ gi,
                                                            const unsigned* __restrict__ gk, int world,
-                                                           int nq, int kout, float* __restrict__ od,
-                                                           unsigned* __restrict__ oi) {
+                                                           long long world_stride, int nq, int kout,
+                                                           float* __restrict__ od, unsigned* __restrict__ oi) {
     const int q = blockIdx.x, lane = threadIdx.x;
     if (q >= nq) return;
     int head = 0;
-    const size_t base = ((size_t)lane * nq + q) * kout;
+    const size_t base = (size_t)lane * world_stride + (size_t)q * kout;
     for (int j = 0; j < kout; ++j) {
         float d = INFINITY;
         unsigned key = 0xFFFFFFFFu;

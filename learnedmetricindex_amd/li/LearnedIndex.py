@@ -1,0 +1,169 @@
+"""LearnedIndex.search on the MI355X (reference: li/LearnedIndex.py:22-373).
+
+Drop-in for the reference class: same constructor, same `search(...)` signature and return
+values `(dists f64[nq,k], nns u32[nq,k], measured_time)`.  What changes underneath:
+
+* the index lives in HBM: on the first `search` (or an explicit `prepare`) the scan vectors are
+  uploaded once into a bucket-contiguous, fragment-major slab together with the 1-based labels
+  (the reference instead re-groups the DataFrame and copies every visited bucket on every rank
+  of every call, LearnedIndex.py:350-357);
+* one `lmi_search` call does MLP forward -> top-n_buckets -> routing -> bucket scan -> merge on the
+  GPU (LearnedIndex.py:87-146 + 163-214 + 328-373);
+* `data_navigation` is never mutated (the reference adds/drops `category_L*` columns,
+  :101-104/:153-157), so passing the same frame for navigation and scan works.
+
+Reference quirks kept on purpose: ids are the DataFrame's index labels as uint32, unvisited slots
+are (inf, 0) (Q2); the per-bucket k is always 10 and a single-bucket search returns 10 columns
+whatever `k` is (Q3); buckets with < 10 objects are padded like faiss does (Q4); dist = 1 - ip in
+float32 stored as float64 (Q5/Q6).
+"""
+import time
+from collections import defaultdict
+from logging import INFO
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import numpy.typing as npt
+import pandas as pd
+
+from .Logger import Logger
+from .model import NeuralNetwork, linear_layers
+from .PriorityQueue import EMPTY_VALUE
+from .utils import log_runtime
+
+try:
+    from .. import _capi
+except ImportError:  # pragma: no cover
+    import _capi  # type: ignore
+
+np.random.seed(2023)
+
+
+def _feature_columns(df: pd.DataFrame) -> list:
+    return [c for c in df.columns if not (isinstance(c, str) and c.startswith("category_L"))]
+
+
+class LearnedIndex(Logger):
+    def __init__(self, root_model: NeuralNetwork, internal_models: Dict[Tuple, NeuralNetwork],
+                 bucket_paths: List[Tuple]):
+        self.root_model = root_model
+        """The root model of the index."""
+        self.internal_models = internal_models
+        """path (padded with EMPTY_VALUE) -> internal model."""
+        self.bucket_paths = bucket_paths
+        """List of paths to the buckets."""
+        self._engine = None
+        self._engine_key = None
+
+    def __getstate__(self):  # picklable like the reference object (search.py:234-241)
+        state = dict(self.__dict__)
+        state["_engine"] = None
+        state["_engine_key"] = None
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self.__dict__.setdefault("_engine", None)
+        self.__dict__.setdefault("_engine_key", None)
+
+    # ------------------------------------------------------------------------------------------
+    def close(self) -> None:
+        """Frees the HBM-resident index."""
+        if self._engine is not None:
+            self._engine.close()
+        self._engine = None
+        self._engine_key = None
+
+    def prepare(self, data_navigation: pd.DataFrame, data_search: pd.DataFrame,
+                data_prediction: npt.NDArray[np.int64], n_categories: List[int], device: int = 0):
+        """Uploads the scan vectors bucket-contiguously (the one-time replacement of the
+        reference's per-call groupby + `.loc` gather).  Called by `search` when needed."""
+        assert self.root_model is not None, "Model is not trained, call `build` first."
+        dp = np.asarray(data_prediction)
+        if dp.ndim == 1:
+            dp = dp[:, None]
+        assert dp.shape[0] == data_navigation.shape[0] == data_search.shape[0]
+        key = (id(data_search), tuple(data_search.shape), dp.__array_interface__["data"][0], dp.shape,
+               int(dp[:: max(1, dp.shape[0] // 1024), 0].sum()), tuple(n_categories), device)
+        if self._engine is not None and key == self._engine_key:
+            return self._engine
+        self.close()
+        if len(n_categories) != 1:
+            raise NotImplementedError(
+                "multi-level navigation (len(n_categories) > 1) is not on the MI355X path yet "
+                "(SURVEY.md section 8f, N1)")
+        L = int(n_categories[0])
+        eng = _capi.Index(device)
+        eng.set_mlp(linear_layers(self.root_model.model))
+        assert eng.n_classes >= int(dp[:, 0].max(initial=0)) + 1, "data_prediction outside the model's classes"
+        labels = data_navigation.index.to_numpy()
+        assert labels.min(initial=0) >= 0 and labels.max(initial=0) < 2 ** 32, "ids must fit uint32"
+        cols = _feature_columns(data_search)
+        if data_search.index.equals(data_navigation.index):
+            frame = data_search
+        else:  # the reference fetches scan rows by label: data_search.loc[g.index] (:357)
+            frame = data_search.loc[data_navigation.index]
+        eng.buckets_begin(dp[:, 0], len(cols), max(L, eng.n_classes), ids=labels.astype(np.uint32))
+        piece = max(1, (256 << 20) // (4 * max(1, len(cols))))
+        for r0 in range(0, frame.shape[0], piece):
+            block = frame.iloc[r0: r0 + piece]
+            eng.add_rows(np.ascontiguousarray(block[cols].to_numpy(dtype=np.float32)), r0)
+        eng.buckets_end()
+        self._engine, self._engine_key = eng, key
+        return eng
+
+    # ------------------------------------------------------------------------------------------
+    def search(
+        self,
+        data_navigation: pd.DataFrame,
+        queries_navigation: npt.NDArray[np.float32],
+        data_search: pd.DataFrame,
+        queries_search: npt.NDArray[np.float32],
+        data_prediction: npt.NDArray[np.int64],
+        n_categories: List[int],
+        n_buckets: int = 1,
+        k: int = 10,
+    ) -> Tuple[npt.NDArray, npt.NDArray[np.uint32], Dict[str, float]]:
+        """Searches for `k` nearest neighbors of every query in its `n_buckets` most probable buckets.
+        Parameters and return values as the reference (LearnedIndex.py:41-83)."""
+        measured_time = defaultdict(float)
+        s = time.time()
+        eng = self.prepare(data_navigation, data_search, data_prediction, n_categories)
+        qn = np.ascontiguousarray(queries_navigation, dtype=np.float32)
+        qs = qn if queries_search is queries_navigation else np.ascontiguousarray(queries_search, dtype=np.float32)
+        assert qn.shape[0] == qs.shape[0]
+        nq = qs.shape[0]
+        if n_buckets >= 2:
+            # LearnedIndex.py:142-146: after the first merge the arrays must be (nq, k)
+            assert k <= 2 * _capi.K_PER_BUCKET, "k > 20 cannot be merged from two 10-result ranks"
+        assert n_buckets <= eng.n_classes, "n_buckets exceeds the number of classes"  # :213 would fail to broadcast
+        if nq == 0:
+            kout = _capi.Index.kout(n_buckets, k)
+            return np.empty((0, kout)), np.empty((0, kout), dtype=np.uint32), measured_time
+        d32, nns, _ = eng.search(qn, qs, n_buckets, k)
+        t = eng.timings() * 1e-3
+        measured_time["inference"] = float(t[_capi.T_INFERENCE])
+        measured_time["search_within_buckets"] = float(t[_capi.T_ROUTE] + t[_capi.T_SCAN] + t[_capi.T_MERGE])
+        measured_time["seq_search"] = float(t[_capi.T_SCAN])
+        measured_time["sort"] = float(t[_capi.T_MERGE])
+        dists = d32.astype(np.float64)  # float32 values in a float64 array, like the reference (Q6)
+        assert dists.shape == nns.shape
+        measured_time["search"] = time.time() - s
+        return dists, nns, measured_time
+
+    # ------------------------------------------------------------------------------------------
+    @log_runtime(INFO, "Precomputed bucket order time: {}")
+    def _precompute_bucket_order(self, queries_navigation: npt.NDArray[np.float32], n_buckets: int,
+                                 n_categories: List[int]) -> Tuple[npt.NDArray[np.int32], float]:
+        """(bucket_order int32[nq, n_buckets, n_levels], inference seconds) -- 1-level branch of
+        LearnedIndex.py:163-214, computed by lmi_mlp_topk."""
+        assert self.root_model is not None, "Model is not trained, call `build` first."
+        if len(n_categories) != 1:
+            raise NotImplementedError("multi-level navigation: SURVEY.md section 8f, N1")
+        eng = self.root_model.engine()
+        qn = np.ascontiguousarray(queries_navigation, dtype=np.float32)
+        order = eng.mlp_topk(qn, n_buckets)
+        t = float(eng.timings()[_capi.T_INFERENCE]) * 1e-3
+        bucket_order = np.full((qn.shape[0], n_buckets, 1), EMPTY_VALUE, dtype=np.int32)
+        bucket_order[:, :, 0] = order
+        return bucket_order, t

@@ -1,0 +1,93 @@
+"""Bucket-sharded multi-GPU search (no counterpart in the reference).
+
+One process per GPU.  Bucket b lives on rank owner[b]; the MLP weights and the query batch are
+replicated, every rank runs the (cheap) MLP itself and scans only the (query, rank) pairs whose
+bucket it owns, then ONE all-gather (RCCL over xGMI; `gloo` in the CPU tests) moves every rank's
+`[dists | ids | keys]` block of nq*k*12 bytes and a merge kernel orders the union by
+(distance, bucket rank, position) -- the same total order the single-GPU merge uses, so results
+are byte-identical for every world size.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import numpy as np
+
+
+def assign_buckets(sizes, world: int, weights=None) -> np.ndarray:
+    """owner[L]: greedy longest-processing-time assignment of buckets to ranks.
+
+    `weights` (default: sizes) is the expected scan work of a bucket; ties and zero-weight buckets
+    are spread round-robin so that every rank's result is deterministic and identical on all ranks."""
+    sizes = np.asarray(sizes, dtype=np.int64)
+    w = sizes.astype(np.float64) if weights is None else np.asarray(weights, dtype=np.float64)
+    owner = np.zeros(sizes.shape[0], dtype=np.int32)
+    load = np.zeros(world, dtype=np.float64)
+    count = np.zeros(world, dtype=np.int64)
+    for b in np.argsort(-w, kind="stable"):
+        r = int(np.lexsort((np.arange(world), count, load))[0])  # least load, then fewest buckets, then rank
+        owner[b] = r
+        load[r] += w[b]
+        count[r] += 1
+    return owner
+
+
+def pack_block(xp, dists, ids, keys):
+    """[3, nq, kout] int32 block: float32 distance bits | uint32 ids | uint32 keys (xp: numpy or torch)."""
+    if xp is np:
+        return np.stack([dists.view(np.int32), ids.view(np.int32), keys.view(np.int32)])
+    import torch
+
+    return torch.stack([dists.view(torch.int32), ids.view(torch.int32), keys.view(torch.int32)])
+
+
+def all_gather_blocks(block, world: int, group=None):
+    """The one collective of the path: [world, 3, nq, kout] <- all_gather(block)."""
+    import torch
+    import torch.distributed as dist
+
+    out = torch.empty((world,) + tuple(block.shape), dtype=block.dtype, device=block.device)
+    dist.all_gather_into_tensor(out, block.contiguous(), group=group)
+    return out
+
+
+def merge_blocks_numpy(gathered: np.ndarray, kout: int):
+    """Host restatement of merge_gathered_kernel, used by the CPU (gloo) tests only."""
+    world, three, nq, kk = gathered.shape
+    assert three == 3 and kk == kout
+    d = gathered[:, 0].view(np.float32).transpose(1, 0, 2).reshape(nq, world * kout).astype(np.float64)
+    i = gathered[:, 1].view(np.uint32).transpose(1, 0, 2).reshape(nq, world * kout)
+    k = gathered[:, 2].view(np.uint32).transpose(1, 0, 2).reshape(nq, world * kout).astype(np.int64)
+    src = np.broadcast_to(np.repeat(np.arange(world), kout)[None, :], k.shape)
+    order = np.lexsort((src, k, d), axis=1)[:, :kout]
+    return np.take_along_axis(d, order, 1).astype(np.float32), np.take_along_axis(i, order, 1)
+
+
+class ShardedSearcher:
+    """Device-side driver of the sharded search for one rank (torch tensors in, torch tensors out)."""
+
+    def __init__(self, index, rank: int, world: int, group=None):
+        self.index, self.rank, self.world, self.group = index, rank, world, group
+        self._buf = None
+
+    def search(self, qn_t, qs_t, nb: int, k: int):
+        import torch
+
+        nq = qn_t.shape[0]
+        kout = self.index.kout(nb, k)
+        if self._buf is None or self._buf[0].shape != (3, nq, kout):
+            dev = qn_t.device
+            self._buf = (torch.empty((3, nq, kout), dtype=torch.int32, device=dev),
+                         torch.empty((nq, kout), dtype=torch.float32, device=dev),
+                         torch.empty((nq, kout), dtype=torch.int32, device=dev),
+                         torch.empty((nq, nb), dtype=torch.int32, device=dev))
+        blk, out_d, out_i, bo = self._buf
+        # the three planes of `blk` are written in place by lmi_search
+        self.index.search_device(qn_t, qs_t, nb, k, blk[0], blk[1], blk[2], bo)
+        if self.world == 1:
+            return blk[0].view(torch.float32), blk[1], bo
+        g = all_gather_blocks(blk, self.world, self.group)  # [world, 3, nq, kout]
+        plane = nq * kout
+        self.index.merge_gathered(g[0, 0], g[0, 1], g[0, 2], self.world, nq, kout, out_d, out_i,
+                                  world_stride=3 * plane)
+        return out_d, out_i, bo

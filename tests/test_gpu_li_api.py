@@ -1,0 +1,136 @@
+"""GPU (`-m gpu`): the drop-in `li` API (LearnedIndex.search, NeuralNetwork.predict*) against the
+reference-generated fixtures and the oracle.  Reads like a test of the reference would: build the
+objects the way search.py does (DataFrames with a 1-based index) and call `search`."""
+import pickle
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from helpers import compare_modulo_near_ties, inputs_for, layers_from, load_golden
+
+pytestmark = pytest.mark.gpu
+
+MODEL_OF = {"G1": "MLP", "G3": "MLP-4", "G4": "MLP", "G5": "MLP-4", "G6": "MLP-5"}
+
+
+def frame(X):
+    df = pd.DataFrame(X)
+    df.index += 1  # search.py:190-191
+    return df
+
+
+def make_index(name, g):
+    from learnedmetricindex_amd.li.LearnedIndex import LearnedIndex
+    from learnedmetricindex_amd.li.model import NeuralNetwork
+
+    layers = layers_from(g)
+    net = NeuralNetwork(input_dim=layers[0][0].shape[1], output_dim=layers[-1][0].shape[0], model_type=MODEL_OF[name])
+    lin = [m for m in net.model.layers if isinstance(m, torch.nn.Linear)]
+    with torch.no_grad():
+        for m, (W, b) in zip(lin, layers):
+            m.weight.copy_(torch.from_numpy(W))
+            m.bias.copy_(torch.from_numpy(b))
+    L = layers[-1][0].shape[0]
+    return LearnedIndex(net, {}, [(i,) for i in range(L)]), net
+
+
+@pytest.mark.parametrize("name", ["G1", "G3", "G4", "G5", "G6"])
+def test_search_dropin(oracle, name):
+    g = load_golden(name)
+    Xn, Qn, Xs, Qs = inputs_for(name, g)
+    li, net = make_index(name, g)
+    nb, k = int(g["n_buckets"]), int(g["k"])
+    dp = g["data_prediction"].astype(np.int64)
+    nav, srch = frame(Xn), frame(Xs)
+    cols_before = list(nav.columns)
+    dists, nns, mt = li.search(data_navigation=nav, queries_navigation=Qn, data_search=srch, queries_search=Qs,
+                               data_prediction=dp, n_categories=[int(g["n_categories"][0])], n_buckets=nb, k=k)
+    assert dists.dtype == np.float64 and nns.dtype == np.uint32 and dists.shape == nns.shape == (Qs.shape[0], k)
+    assert list(nav.columns) == cols_before  # never mutated
+    for key in ("inference", "search_within_buckets", "seq_search", "sort", "search"):
+        assert key in mt and mt[key] >= 0.0
+    compare_modulo_near_ties(g["ref_dists"], g["ref_nns"], dists, nns)
+    do, no, _ = oracle.search(layers_from(g), Qn, Xs, Qs, dp, nb, k, nthreads=4)
+    np.testing.assert_array_equal(nns, no)
+    np.testing.assert_array_equal(dists, do)
+    # second call reuses the HBM-resident index; results are reproducible
+    d2, n2, _ = li.search(nav, Qn, srch, Qs, dp, [int(g["n_categories"][0])], nb, k)
+    np.testing.assert_array_equal(n2, nns)
+    np.testing.assert_array_equal(d2, dists)
+    bo, t_inf = li._precompute_bucket_order(Qn, nb, [int(g["n_categories"][0])])
+    np.testing.assert_array_equal(bo, g["ref_bucket_order"])
+    li.close()
+
+
+def test_aliased_frames_and_custom_labels(oracle):
+    """the reference cannot run with data_search is data_navigation; the drop-in can.
+    Ids are the DataFrame's index labels (Q2), whatever they are."""
+    g = load_golden("G1")
+    Xn, Qn, Xs, Qs = inputs_for("G1", g)
+    li, _ = make_index("G1", g)
+    dp = g["data_prediction"].astype(np.int64)
+    df = frame(Xs)
+    d, n, _ = li.search(df, Qn, df, Qs, dp, [12], 3, 10)
+    compare_modulo_near_ties(g["ref_dists"], g["ref_nns"], d, n)
+    df2 = pd.DataFrame(Xs, index=np.arange(Xs.shape[0]) * 3 + 1000)
+    d2, n2, _ = li.search(df2, Qn, df2, Qs, dp, [12], 3, 10)
+    np.testing.assert_array_equal(n2, (n.astype(np.int64) - 1) * 3 + 1000)
+    np.testing.assert_array_equal(d2, d)
+    li.close()
+
+
+def test_predict_and_predict_proba(oracle):
+    for name in ("G1", "G6"):
+        g = load_golden(name)
+        Xn, Qn, Xs, Qs = inputs_for(name, g)
+        li, net = make_index(name, g)
+        layers = layers_from(g)
+        probs, classes = net.predict_proba(torch.from_numpy(Qn))
+        po, co = oracle.predict_proba(layers, Qn)
+        assert probs.dtype == np.float32 and classes.dtype == np.int64
+        np.testing.assert_array_equal(classes, co)
+        np.testing.assert_array_equal(probs, po)  # same binary32 operation sequence on both sides
+        nb = int(g["n_buckets"])
+        np.testing.assert_array_equal(classes[:, :nb], g["ref_classes_top"])
+        np.testing.assert_allclose(probs[:, :nb], g["ref_probs_top"], rtol=2e-5, atol=1e-7)
+        pred = net.predict(torch.from_numpy(Xn[:3000]))
+        np.testing.assert_array_equal(pred, g["data_prediction"][:3000, 0] if name != "G4" else pred)
+        np.testing.assert_array_equal(pred, oracle.predict(layers, Xn[:3000]))
+
+
+def test_pickle_roundtrip_and_k_quirks():
+    g = load_golden("G4")
+    Xn, Qn, Xs, Qs = inputs_for("G4", g)
+    li, _ = make_index("G4", g)
+    dp = g["data_prediction"].astype(np.int64)
+    df = frame(Xs)
+    d, n, _ = li.search(df, Qn, df, Qs, dp, [12], 1, 5)     # Q3: single bucket ignores k
+    assert d.shape == (Qs.shape[0], 10)
+    compare_modulo_near_ties(g["nb1_k5_dists"], g["nb1_k5_nns"], d, n)
+    with pytest.raises(AssertionError):
+        li.search(df, Qn, df, Qs, dp, [12], 2, 25)           # LearnedIndex.py:142-146
+    li2 = pickle.loads(pickle.dumps(li))                      # search.py:234-241 pickles the index
+    d2, n2, _ = li2.search(df, Qn, df, Qs, dp, [12], 3, 15)
+    compare_modulo_near_ties(g["nb3_k15_dists"], g["nb3_k15_nns"], d2, n2)
+    li.close()
+    li2.close()
+
+
+def test_bucket_read_roundtrip():
+    from learnedmetricindex_amd import _capi
+
+    rs = np.random.RandomState(3)
+    X = rs.randn(1000, 45).astype(np.float32)
+    lab = rs.randint(0, 7, size=1000)
+    lab[lab == 4] = 5  # bucket 4 empty
+    idx = _capi.Index(0, chunk_rows=128)
+    idx.set_buckets(X, lab, 7)
+    np.testing.assert_array_equal(idx.bucket_sizes(), np.bincount(lab, minlength=7))
+    for b in range(7):
+        rows, ids = idx.read_bucket(b)
+        sel = np.flatnonzero(lab == b)
+        np.testing.assert_array_equal(rows, X[sel])
+        np.testing.assert_array_equal(ids, sel + 1)
+    idx.close()
