@@ -46,9 +46,10 @@ def all_gather_blocks(block, world: int, group=None):
     import torch
     import torch.distributed as dist
 
-    out = torch.empty((world,) + tuple(block.shape), dtype=block.dtype, device=block.device)
-    dist.all_gather_into_tensor(out, block.contiguous(), group=group)
-    return out
+    shape = tuple(block.shape)
+    out = torch.empty((world * shape[0],) + shape[1:], dtype=block.dtype, device=block.device)
+    dist.all_gather_into_tensor(out, block.contiguous(), group=group)  # rank-major concatenation
+    return out.view((world,) + shape)
 
 
 def merge_blocks_numpy(gathered: np.ndarray, kout: int):

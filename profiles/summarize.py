@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 output (gpurun_out/prof_rNN/) into the small files committed under profiles/.
+
+  python profiles/summarize.py gpurun_out/prof_r01 r01
+
+Writes profiles/<tag>_kernel_stats.csv (top kernels by total time, names shortened),
+profiles/<tag>_scan_pmc.json (per-launch FETCH_SIZE / WRITE_SIZE of lmi::scan_kernel and the HBM
+bytes derived as /opt/skills/guides/MI355X_MICROARCH.md section "HBM" prescribes: both counters are
+in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of 16-B-per-lane coalesced streaming reads --
+which is what both operand streams of the scan kernel are -- so it is doubled; WRITE_SIZE is exact).
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def one(pattern):
+    files = glob.glob(pattern, recursive=True)
+    return files[0] if files else None
+
+
+def main(src, tag):
+    out_dir = os.path.dirname(os.path.abspath(__file__))
+    stats = one(os.path.join(src, "trace", "**", "*_kernel_stats.csv"))
+    if stats:
+        rows = list(csv.DictReader(open(stats)))
+        with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w", newline="") as fh:
+            w = csv.writer(fh)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+            for r in rows[:25]:
+                w.writerow([r["Name"][:96], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
+                            r["MinNs"], r["MaxNs"]])
+    pmc = {}
+    for name, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+        f = one(os.path.join(src, sub, "**", "*_counter_collection.csv"))
+        if not f:
+            continue
+        vals, durs, meta = [], [], None
+        for r in csv.DictReader(open(f)):
+            if r["Kernel_Name"].startswith("lmi::scan_kernel(") and r["Counter_Name"] == name:
+                vals.append(float(r["Counter_Value"]))
+                durs.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count",
+                                          "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size")}
+        if vals:
+            pmc[name] = {"launches": len(vals), "avg_kib": sum(vals) / len(vals), "min_kib": min(vals),
+                         "max_kib": max(vals), "avg_duration_ms_profiled": sum(durs) / len(durs) / 1e6}
+            pmc["dispatch"] = meta
+    if "FETCH_SIZE" in pmc:
+        fetch = pmc["FETCH_SIZE"]["avg_kib"] * 1024.0 * 2.0  # gfx950: half-counted 16-B/lane streams
+        write = pmc.get("WRITE_SIZE", {}).get("avg_kib", 0.0) * 1024.0
+        pmc["hbm_bytes_per_launch"] = fetch + write
+        pmc["note"] = ("(2 * FETCH_SIZE + WRITE_SIZE) KiB -> bytes; FETCH_SIZE counts L2 misses, Infinity-Cache "
+                       "hits included, so this is an upper bound on true HBM reads")
+    with open(os.path.join(out_dir, f"{tag}_scan_pmc.json"), "w") as fh:
+        json.dump(pmc, fh, indent=1)
+    print(json.dumps(pmc, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])

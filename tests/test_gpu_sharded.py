@@ -1,0 +1,72 @@
+"""GPU (`-m gpu`): bucket-sharded mode on one card.  The one GPU of the test box plays every rank in
+turn (one handle per rank with its `owned` mask); the all-gather is a `torch.stack` of the ranks'
+blocks -- bit-identical to what RCCL delivers -- and lmi_merge_gathered must reproduce the
+single-handle result exactly for world sizes 2, 3 and 8 (SURVEY section 8e identity requirement)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import inputs_for, layers_from, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,nb,k,world", [("G3", 4, 10, 2), ("G3", 4, 10, 8), ("G4", 4, 10, 3),
+                                              ("G4", 3, 15, 2), ("G4", 1, 5, 2), ("G5", 4, 10, 8)])
+def test_sharded_equals_single(oracle, name, nb, k, world):
+    from learnedmetricindex_amd import _capi
+    from learnedmetricindex_amd.sharded import ShardedSearcher, assign_buckets
+
+    g = load_golden(name)
+    Xn, Qn, Xs, Qs = inputs_for(name, g)
+    layers = layers_from(g)
+    dp = g["data_prediction"]
+    L = layers[-1][0].shape[0]
+    sizes = np.bincount(dp[:, 0], minlength=L)
+    owner = assign_buckets(sizes, world, weights=sizes.astype(np.float64) ** 2)
+    dev = torch.device("cuda", 0)
+    qn, qs = torch.from_numpy(Qn).to(dev), torch.from_numpy(Qs).to(dev)
+    nq = Qn.shape[0]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    single = _capi.Index(0, chunk_rows=256)
+    single.set_stream(stream)
+    single.set_mlp(layers)
+    single.set_buckets(Xs, dp[:, 0], L)
+    sd, si, sbo = ShardedSearcher(single, 0, 1).search(qn, qs, nb, k)
+    torch.cuda.synchronize()
+    kout = si.shape[1]
+    do, io, _ = oracle.search(layers, Qn, Xs, Qs, dp, nb, k, nthreads=4)
+    np.testing.assert_array_equal(si.cpu().numpy().view(np.uint32), io)
+    np.testing.assert_array_equal(sd.cpu().numpy().astype(np.float64), do)
+
+    blocks = []
+    handles = []
+    for r in range(world):
+        h = _capi.Index(0, chunk_rows=256)
+        h.set_stream(stream)
+        h.set_mlp(layers)
+        h.set_buckets(Xs, dp[:, 0], L, owned=(owner == r).astype(np.uint8))
+        assert h.bucket_sizes().sum() == sizes[owner == r].sum()
+        blk = torch.empty((3, nq, kout), dtype=torch.int32, device=dev)
+        h.search_device(qn, qs, nb, k, blk[0], blk[1], blk[2], None)
+        blocks.append(blk)
+        handles.append(h)
+    gathered = torch.stack(blocks).contiguous()  # == all_gather_into_tensor's result
+    out_d = torch.empty((nq, kout), dtype=torch.float32, device=dev)
+    out_i = torch.empty((nq, kout), dtype=torch.int32, device=dev)
+    handles[0].merge_gathered(gathered[0, 0], gathered[0, 1], gathered[0, 2], world, nq, kout, out_d, out_i,
+                              world_stride=3 * nq * kout)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out_i.cpu().numpy(), si.cpu().numpy())
+    np.testing.assert_array_equal(out_d.cpu().numpy(), sd.cpu().numpy())
+    # host-pointer form of the merge (dense layout)
+    gd = np.ascontiguousarray(gathered[:, 0].cpu().numpy().view(np.float32))
+    gi = np.ascontiguousarray(gathered[:, 1].cpu().numpy().view(np.uint32))
+    gk = np.ascontiguousarray(gathered[:, 2].cpu().numpy().view(np.uint32))
+    hd = np.empty((nq, kout), np.float32)
+    hi = np.empty((nq, kout), np.uint32)
+    handles[0].merge_gathered(gd, gi, gk, world, nq, kout, hd, hi)
+    np.testing.assert_array_equal(hi, io)
+    for h in handles + [single]:
+        h.close()

@@ -1,0 +1,105 @@
+"""CPU (`-m "not gpu"`): the N>1 path with world_size 2 over `gloo`.
+
+Covers the host logic of the bucket-sharded mode -- deterministic bucket assignment, the
+[dists|ids|keys] block packing, the ONE all-gather, the (dist, key) merge order -- and the identity
+requirement of SURVEY section 8e: the merged result equals the single-process result bit for bit.
+The per-rank scan itself is played by the CPU oracle here (there is no GPU in this container); on
+the GPU the same `sharded.py` code drives lmi_search / lmi_merge_gathered (tests/test_gpu_sharded.py).
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def local_block(oracle, layers, Qn, Xs, Qs, dp, nb, kout, owned):
+    """What lmi_search(+keys) returns on a rank owning `owned` buckets: oracle restatement."""
+    bo = oracle.precompute_bucket_order(layers, Qn, nb)
+    groups = [(p, rows) for p, rows in oracle.group_buckets(dp) if owned[p[0]]]
+    ids = np.arange(1, Xs.shape[0] + 1)
+    nq = Qs.shape[0]
+    D = np.empty((nq, nb * 10), dtype=np.float64)
+    I = np.empty((nq, nb * 10), dtype=np.uint32)
+    K = np.empty((nq, nb * 10), dtype=np.int64)
+    for r in range(nb):
+        d, n = oracle.search_single_bucket(Xs, ids, groups, Qs, bo[:, r, :])
+        D[:, r * 10:(r + 1) * 10], I[:, r * 10:(r + 1) * 10] = d, n
+        K[:, r * 10:(r + 1) * 10] = r * 16 + np.arange(10)[None, :]
+    order = np.lexsort((K, D), axis=1)[:, :kout]
+    return (np.take_along_axis(D, order, 1).astype(np.float32), np.take_along_axis(I, order, 1),
+            np.take_along_axis(K, order, 1).astype(np.uint32))
+
+
+def _worker(rank, world, port, name, nb, k, out_dir):
+    sys.path[:0] = [ROOT, HERE, os.path.join(HERE, "golden")]
+    from helpers import inputs_for, layers_from, load_golden
+    from learnedmetricindex_amd import sharded
+    from oracle import lmi_oracle as oracle
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        g = load_golden(name)
+        Xn, Qn, Xs, Qs = inputs_for(name, g)
+        layers = layers_from(g)
+        dp = g["data_prediction"]
+        L = layers[-1][0].shape[0]
+        sizes = np.bincount(dp[:, 0], minlength=L)
+        owner = sharded.assign_buckets(sizes, world)
+        kout = 10 if nb == 1 else k
+        d, i, keys = local_block(oracle, layers, Qn, Xs, Qs, dp, nb, kout, owner == rank)
+        blk = torch.from_numpy(sharded.pack_block(np, d, i, keys))
+        gathered = sharded.all_gather_blocks(blk, world)            # the one collective
+        md, mi = sharded.merge_blocks_numpy(gathered.numpy(), kout)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), d=md, i=mi, owner=owner)
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("name,nb,k", [("G1", 3, 10), ("G4", 4, 10), ("G4", 3, 15), ("G4", 1, 5)])
+def test_two_rank_result_identical_to_single(oracle, tmp_path, name, nb, k):
+    from helpers import inputs_for, layers_from, load_golden
+
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), name, nb, k, str(tmp_path)), nprocs=world, join=True)
+    g = load_golden(name)
+    Xn, Qn, Xs, Qs = inputs_for(name, g)
+    do, io, _ = oracle.search(layers_from(g), Qn, Xs, Qs, g["data_prediction"], nb, k)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    np.testing.assert_array_equal(r0["owner"], r1["owner"])          # same assignment on every rank
+    assert set(np.unique(r0["owner"])) == {0, 1}
+    for r in (r0, r1):
+        np.testing.assert_array_equal(r["i"], io)
+        np.testing.assert_array_equal(r["d"].astype(np.float64), do)
+
+
+def test_assign_buckets_balances_and_is_deterministic():
+    from learnedmetricindex_amd.sharded import assign_buckets
+
+    rs = np.random.RandomState(0)
+    sizes = rs.randint(0, 200_000, size=120)
+    sizes[[3, 77]] = 0
+    for world in (1, 2, 4, 8):
+        owner = assign_buckets(sizes, world)
+        assert owner.min() >= 0 and owner.max() < world
+        np.testing.assert_array_equal(owner, assign_buckets(sizes, world))
+        load = np.bincount(owner, weights=sizes, minlength=world)
+        assert load.max() <= load.mean() * 1.05 + sizes.max() / world
+    w2 = assign_buckets(sizes, 8, weights=sizes.astype(float) ** 2)
+    load = np.bincount(w2, weights=sizes.astype(float) ** 2, minlength=8)
+    assert load.max() <= load.mean() * 1.15
