@@ -126,8 +126,6 @@ extern "C" int lmi_create(int device, lmi_index** out) {
     lmi_index* h = new lmi_index();
     h->device = device;
     h->num_cus = prop.multiProcessorCount;
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS));
     int occ = 0;
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_kernel, 256, SCAN_LDS));
     h->scan_blocks_per_cu = std::max(1, std::min(occ, 2));

@@ -28,7 +28,7 @@ constexpr int TILE_ROWS = 128;  // vectors per block tile (4 waves x 32)
 constexpr int TILE_COLS = 128;  // queries per block tile (4 col-blocks x 32)
 constexpr int STAGE_G = 4;      // k-groups (of 8) per LDS stage -> BK = 32
 constexpr int STAGE_BYTES = 32768;  // A: 4 waves x 4 g x 1 KiB, B: 4 col-blocks x 4 g x 1 KiB
-constexpr int SCAN_LDS = 2 * STAGE_BYTES + 64;
+constexpr int SCAN_LDS = 0;  // all LDS is static (four 16 KiB stage arrays)
 constexpr unsigned NOROW = 0xFFFFFFFFu;
 
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -348,10 +348,10 @@ struct ScanParams {
     unsigned* part_row;
 };
 
-__device__ __forceinline__ void glds16(const float4* gsrc, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)gsrc,
-        (__attribute__((address_space(3))) void*)(uintptr_t)lds_wave_base, 16, 0, 0);
+__device__ __forceinline__ void glds16(const float4* gsrc, float4* lds_wave_base) {
+    // LDS destination = wave-uniform base + lane*16; the source address is per lane.
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
 // sorted (descending) insert of (s,row) into a 10-entry register list; caller checked s > v[9].
@@ -372,153 +372,184 @@ __device__ __forceinline__ bool better(float s, unsigned r, float s2, unsigned r
     return s > s2 || (s == s2 && r < r2);
 }
 
-template <int NCB>
-__device__ __forceinline__ void scan_item(const ScanParams& P, char* smem, int b, int qt, int ch) {
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, c = lane & 31;
-    const int KG = P.KG, NS = KG / STAGE_G;
-    const int n_b = P.nb_rows[b];
-    const int nrb_b = (n_b + 31) >> 5;
-    const int rb_in_b0 = ch * P.chunk_rb;                       // first row-block of the chunk
-    const int nrb = min(P.chunk_rb, nrb_b - rb_in_b0);          // row-blocks in this chunk
-    const int nvt = (nrb + 3) >> 2;                             // 128-row tiles
-    const int cb0 = P.cb_start[b] + qt * 4;
-    const float4* abase = P.slab + ((size_t)(P.rb_start[b] + rb_in_b0 + w) * KG) * 64 + lane;
-    const float4* bbase = P.qfrag + ((size_t)(cb0 + w) * KG) * 64 + lane;  // wave w stages col-block w
+// The four stage buffers are FOUR DISTINCT __shared__ arrays (declared in scan_kernel) and the
+// buffer parity is a template constant: the compiler can then prove that the LDS-DMA writes of
+// stage u+1 (parity 1-PAR) do not alias the ds_reads of stage u (parity PAR) and does not drain
+// vmcnt(0) in front of them -- with one array + runtime offsets it did, serialising load and MFMA.
+struct ScanLds {
+    float4 *A0, *A1, *B0, *B1;  // each [16][64] float4 = 16 KiB: A: (wave, g), B: (col-block, g)
+};
 
+template <int NCB>
+struct ScanItem {
+    const ScanParams& P;
+    const ScanLds& S;
+    int lane, w, h, c;
+    int KG, NS, n_b, nrb, rb_in_b0, total;
+    const float4* abase;
+    const float4* bbase;
     float lv[NCB][KPB];
     unsigned li[NCB][KPB];
-#pragma unroll
-    for (int n = 0; n < NCB; ++n)
-#pragma unroll
-        for (int j = 0; j < KPB; ++j) { lv[n][j] = -INFINITY; li[n][j] = NOROW; }
-
     f32x16 acc[NCB];
-#pragma unroll
-    for (int n = 0; n < NCB; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
 
-    const int total = nvt * NS;
-    // stage u -> buffer u&1
-    auto stage = [&](int u) {
+    template <int PAR>
+    __device__ __forceinline__ void issue(int u) {  // DMA stage u into the parity-PAR buffers
+        float4* sA = PAR ? S.A1 : S.A0;
+        float4* sB = PAR ? S.B1 : S.B0;
         const int vt = u / NS, t = u - vt * NS;
-        char* buf = smem + (u & 1) * STAGE_BYTES;
         if (vt * 4 + w < nrb) {
             const float4* a = abase + ((size_t)vt * 4 * KG + t * STAGE_G) * 64;
 #pragma unroll
-            for (int g = 0; g < STAGE_G; ++g) glds16(a + (size_t)g * 64, buf + (w * STAGE_G + g) * 1024);
+            for (int g = 0; g < STAGE_G; ++g) glds16(a + (size_t)g * 64, sA + (w * STAGE_G + g) * 64);
         }
         if (w < NCB) {
             const float4* q = bbase + (size_t)(t * STAGE_G) * 64;
 #pragma unroll
-            for (int g = 0; g < STAGE_G; ++g)
-                glds16(q + (size_t)g * 64, buf + 16384 + (w * STAGE_G + g) * 1024);
+            for (int g = 0; g < STAGE_G; ++g) glds16(q + (size_t)g * 64, sB + (w * STAGE_G + g) * 64);
         }
-    };
+    }
 
-    stage(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int u = 0; u < total; ++u) {
+    template <int PAR>
+    __device__ __forceinline__ void compute(int u) {  // MFMAs of stage u from the parity-PAR buffers
+        const float4* sA = PAR ? S.A1 : S.A0;
+        const float4* sB = PAR ? S.B1 : S.B0;
         const int vt = u / NS, t = u - vt * NS;
-        if (u + 1 < total) stage(u + 1);
-        const bool live = vt * 4 + w < nrb;  // wave-uniform
-        if (live) {
-            const char* buf = smem + (u & 1) * STAGE_BYTES;
+        if (vt * 4 + w >= nrb) return;  // wave-uniform: this wave's row-block is past the chunk
 #pragma unroll
-            for (int g = 0; g < STAGE_G; ++g) {
-                const float4 a = *reinterpret_cast<const float4*>(buf + (w * STAGE_G + g) * 1024 + lane * 16);
-                float4 bq[NCB];
+        for (int g = 0; g < STAGE_G; ++g) {
+            const float4 a = sA[(w * STAGE_G + g) * 64 + lane];
+            float4 bq[NCB];
 #pragma unroll
-                for (int n = 0; n < NCB; ++n)
-                    bq[n] = *reinterpret_cast<const float4*>(buf + 16384 + (n * STAGE_G + g) * 1024 + lane * 16);
-                const float av[4] = {a.x, a.y, a.z, a.w};
+            for (int n = 0; n < NCB; ++n) bq[n] = sB[(n * STAGE_G + g) * 64 + lane];
+            const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-#pragma unroll
-                    for (int n = 0; n < NCB; ++n) {
-                        const float bv = s == 0 ? bq[n].x : s == 1 ? bq[n].y : s == 2 ? bq[n].z : bq[n].w;
-                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv, acc[n], 0, 0, 0);
-                    }
-                }
-            }
-            if (t == NS - 1) {  // tile finished: filter the 16 x NCB scores of this lane
-                const unsigned rowbase = (unsigned)((rb_in_b0 + vt * 4 + w) * 32);
+            for (int s = 0; s < 4; ++s) {
 #pragma unroll
                 for (int n = 0; n < NCB; ++n) {
-                    const float thr = lv[n][KPB - 1];
-                    unsigned mask = 0;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        mask |= (unsigned)(acc[n][r] > thr && rowbase + acc_row(r, h) < (unsigned)n_b) << r;
-                    while (mask) {  // rare after warm-up; ascending r == ascending row
-                        const int r = __builtin_ctz(mask);
-                        mask &= mask - 1;
-                        float s = acc[n][0];
-#pragma unroll
-                        for (int i = 1; i < 16; ++i) s = (r == i) ? acc[n][i] : s;
-                        if (s > lv[n][KPB - 1]) list_insert(lv[n], li[n], s, rowbase + acc_row(r, h));
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+                    const float bv = s == 0 ? bq[n].x : s == 1 ? bq[n].y : s == 2 ? bq[n].z : bq[n].w;
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv, acc[n], 0, 0, 0);
                 }
             }
         }
+        if (t == NS - 1) {  // tile finished: filter the 16 x NCB scores of this lane
+            const unsigned rowbase = (unsigned)((rb_in_b0 + vt * 4 + w) * 32);
+#pragma unroll
+            for (int n = 0; n < NCB; ++n) {
+                const float thr = lv[n][KPB - 1];
+                unsigned mask = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    mask |= (unsigned)(acc[n][r] > thr && rowbase + acc_row(r, h) < (unsigned)n_b) << r;
+                while (mask) {  // rare after warm-up; ascending r == ascending row
+                    const int r = __builtin_ctz(mask);
+                    mask &= mask - 1;
+                    float s = acc[n][0];
+#pragma unroll
+                    for (int i = 1; i < 16; ++i) s = (r == i) ? acc[n][i] : s;
+                    if (s > lv[n][KPB - 1]) list_insert(lv[n], li[n], s, rowbase + acc_row(r, h));
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+            }
+        }
+    }
+
+    template <int PAR>
+    __device__ __forceinline__ void step(int u) {
+        if (u + 1 < total) issue<1 - PAR>(u + 1);
+        compute<PAR>(u);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
-    // ---- merge the 8 (wave, half) lists of every column through LDS, two col-blocks per pass ----
-    float* ms = reinterpret_cast<float*>(smem);                 // [2][32][8][KPB]
-    unsigned* mr = reinterpret_cast<unsigned*>(smem + 2 * 32 * 8 * KPB * 4);
-    const int m_b = P.m[b];
-    const int nch_b = P.nch[b];
-    const long long pbase = P.part_base[b];
+    __device__ __forceinline__ void run(int b, int qt, int ch) {
+        const int tid = threadIdx.x;
+        lane = tid & 63; w = tid >> 6; h = lane >> 5; c = lane & 31;
+        KG = P.KG; NS = KG / STAGE_G;
+        n_b = P.nb_rows[b];
+        const int nrb_b = (n_b + 31) >> 5;
+        rb_in_b0 = ch * P.chunk_rb;                          // first row-block of the chunk
+        nrb = min(P.chunk_rb, nrb_b - rb_in_b0);             // row-blocks in this chunk
+        const int nvt = (nrb + 3) >> 2;                      // 128-row tiles
+        const int cb0 = P.cb_start[b] + qt * 4;
+        abase = P.slab + ((size_t)(P.rb_start[b] + rb_in_b0 + w) * KG) * 64 + lane;
+        bbase = P.qfrag + ((size_t)(cb0 + w) * KG) * 64 + lane;  // wave w stages col-block w
+        total = nvt * NS;
 #pragma unroll
-    for (int pass = 0; pass < (NCB + 1) / 2; ++pass) {
+        for (int n = 0; n < NCB; ++n) {
 #pragma unroll
-        for (int n2 = 0; n2 < 2; ++n2) {
-            const int n = pass * 2 + n2;
-            if (n < NCB) {
-                const int o = ((n2 * 32 + c) * 8 + (w * 2 + h)) * KPB;
+            for (int j = 0; j < KPB; ++j) { lv[n][j] = -INFINITY; li[n][j] = NOROW; }
 #pragma unroll
-                for (int j = 0; j < KPB; ++j) { ms[o + j] = lv[n][j]; mr[o + j] = li[n][j]; }
-            }
+            for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
         }
+
+        issue<0>(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid < 64) {
-            const int n2 = tid >> 5, cc = tid & 31, n = pass * 2 + n2;
-            const int col_in_b = qt * TILE_COLS + n * 32 + cc;
-            if (n < NCB && col_in_b < m_b) {
-                const int o = (n2 * 32 + cc) * 8 * KPB;
-                unsigned heads = 0;  // 4 bits per source list
-                const long long dst = (pbase + (long long)col_in_b * nch_b + ch) * KPB;
-                for (int j = 0; j < KPB; ++j) {
-                    float bs = -INFINITY;
-                    unsigned br = NOROW;
-                    int bsrc = 0;
+        for (int u = 0; u < total; u += 2) {
+            step<0>(u);
+            if (u + 1 < total) step<1>(u + 1);
+        }
+
+        // ---- merge the 8 (wave, half) lists of every column through LDS, two col-blocks per pass:
+        //      scores of col-block n2 in A<n2>, rows in B<n2>, each [32][8][KPB] ----
+        const int m_b = P.m[b];
+        const int nch_b = P.nch[b];
+        const long long pbase = P.part_base[b];
 #pragma unroll
-                    for (int src = 0; src < 8; ++src) {
-                        const int hd = (heads >> (4 * src)) & 15;
-                        if (hd < KPB) {
-                            const float s = ms[o + src * KPB + hd];
-                            const unsigned r = mr[o + src * KPB + hd];
-                            if (better(s, r, bs, br)) { bs = s; br = r; bsrc = src; }
-                        }
-                    }
-                    heads += 1u << (4 * bsrc);
-                    P.part_score[dst + j] = bs;
-                    P.part_row[dst + j] = br;
+        for (int pass = 0; pass < (NCB + 1) / 2; ++pass) {
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2) {
+                const int n = pass * 2 + n2;
+                if (n < NCB) {
+                    float* ms = reinterpret_cast<float*>(n2 ? S.A1 : S.A0);
+                    unsigned* mr = reinterpret_cast<unsigned*>(n2 ? S.B1 : S.B0);
+                    const int o = (c * 8 + (w * 2 + h)) * KPB;
+#pragma unroll
+                    for (int j = 0; j < KPB; ++j) { ms[o + j] = lv[n][j]; mr[o + j] = li[n][j]; }
                 }
             }
+            __syncthreads();
+            if (tid < 64) {
+                const int n2 = tid >> 5, cc = tid & 31, n = pass * 2 + n2;
+                const int col_in_b = qt * TILE_COLS + n * 32 + cc;
+                if (n < NCB && col_in_b < m_b) {
+                    const float* ms = reinterpret_cast<const float*>(n2 ? S.A1 : S.A0);
+                    const unsigned* mr = reinterpret_cast<const unsigned*>(n2 ? S.B1 : S.B0);
+                    const int o = cc * 8 * KPB;
+                    unsigned heads = 0;  // 4 bits per source list
+                    const long long dst = (pbase + (long long)col_in_b * nch_b + ch) * KPB;
+                    for (int j = 0; j < KPB; ++j) {
+                        float bs = -INFINITY;
+                        unsigned br = NOROW;
+                        int bsrc = 0;
+#pragma unroll
+                        for (int src = 0; src < 8; ++src) {
+                            const int hd = (heads >> (4 * src)) & 15;
+                            if (hd < KPB) {
+                                const float s = ms[o + src * KPB + hd];
+                                const unsigned r = mr[o + src * KPB + hd];
+                                if (better(s, r, bs, br)) { bs = s; br = r; bsrc = src; }
+                            }
+                        }
+                        heads += 1u << (4 * bsrc);
+                        P.part_score[dst + j] = bs;
+                        P.part_row[dst + j] = br;
+                    }
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
-}
+};
 
 __global__ __launch_bounds__(256, 2) void scan_kernel(ScanParams P) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* s_item = reinterpret_cast<int*>(smem + 2 * STAGE_BYTES);
+    __shared__ __attribute__((aligned(16))) float4 sA0[1024];
+    __shared__ __attribute__((aligned(16))) float4 sA1[1024];
+    __shared__ __attribute__((aligned(16))) float4 sB0[1024];
+    __shared__ __attribute__((aligned(16))) float4 sB1[1024];
+    const ScanLds S{sA0, sA1, sB0, sB1};
+    int* s_item = reinterpret_cast<int*>(sB1);  // item broadcast: no DMA is in flight between items
     const int total_items = P.item_base[P.L];
     for (;;) {
         if (threadIdx.x == 0) {
@@ -545,10 +576,10 @@ __global__ __launch_bounds__(256, 2) void scan_kernel(ScanParams P) {
         const int qt = local % nqt, ch = local / nqt;
         const int ncb = min(4, (m_b - qt * TILE_COLS + 31) >> 5);
         switch (ncb) {
-            case 1: scan_item<1>(P, smem, b, qt, ch); break;
-            case 2: scan_item<2>(P, smem, b, qt, ch); break;
-            case 3: scan_item<3>(P, smem, b, qt, ch); break;
-            default: scan_item<4>(P, smem, b, qt, ch); break;
+            case 1: { ScanItem<1> it{P, S}; it.run(b, qt, ch); break; }
+            case 2: { ScanItem<2> it{P, S}; it.run(b, qt, ch); break; }
+            case 3: { ScanItem<3> it{P, S}; it.run(b, qt, ch); break; }
+            default: { ScanItem<4> it{P, S}; it.run(b, qt, ch); break; }
         }
     }
 }
