@@ -44,6 +44,7 @@ extern "C" {
 #endif
 
 #define LMI_ABI_VERSION 1
+#define LMI_API __attribute__((visibility("default")))
 #define LMI_K_PER_BUCKET 10 /* LearnedIndex.py:334: k is never forwarded to the bucket scan */
 #define LMI_MAX_K 64
 #define LMI_MAX_LAYERS 8
@@ -60,17 +61,17 @@ enum {
     LMI_T_COUNT = 8
 };
 
-int lmi_abi_version(void);
-const char *lmi_last_error(void);
+LMI_API int lmi_abi_version(void);
+LMI_API const char *lmi_last_error(void);
 
 /* Lifetime. */
-int lmi_create(int device, lmi_index **out);
-int lmi_destroy(lmi_index *h);
-int lmi_set_stream(lmi_index *h, void *hip_stream);
+LMI_API int lmi_create(int device, lmi_index **out);
+LMI_API int lmi_destroy(lmi_index *h);
+LMI_API int lmi_set_stream(lmi_index *h, void *hip_stream);
 
 /* MLP weights (host pointers).  dims[0] = input dim, dims[n_layers] = number of classes L;
  * W[i] is [dims[i+1]][dims[i]], b[i] is [dims[i+1]].  ReLU between layers, none after the last. */
-int lmi_set_mlp(lmi_index *h, int n_layers, const int *dims, const float *const *W,
+LMI_API int lmi_set_mlp(lmi_index *h, int n_layers, const int *dims, const float *const *W,
                 const float *const *b);
 
 /* Bucket-contiguous index in HBM.
@@ -80,25 +81,25 @@ int lmi_set_mlp(lmi_index *h, int n_layers, const int *dims, const float *const 
  * add_rows: rows [nrows][d] are the original objects row0 .. row0+nrows-1 (any order of calls, each
  *        object exactly once); they are scattered to their bucket-contiguous position on device.
  * end:   finishes the build; the index is immutable afterwards. */
-int lmi_buckets_begin(lmi_index *h, int64_t N, int d, int L, const int64_t *labels,
+LMI_API int lmi_buckets_begin(lmi_index *h, int64_t N, int d, int L, const int64_t *labels,
                       const uint32_t *ids, const uint8_t *owned);
-int lmi_buckets_add_rows(lmi_index *h, const float *rows, int64_t row0, int64_t nrows, int on_device);
-int lmi_buckets_end(lmi_index *h);
+LMI_API int lmi_buckets_add_rows(lmi_index *h, const float *rows, int64_t row0, int64_t nrows, int on_device);
+LMI_API int lmi_buckets_end(lmi_index *h);
 /* sizes[L] <- number of objects per bucket (0 for buckets not owned). */
-int lmi_bucket_sizes(lmi_index *h, int64_t *sizes);
+LMI_API int lmi_bucket_sizes(lmi_index *h, int64_t *sizes);
 /* Reads one bucket back to the host in bucket order (what `data_search.loc[g.index].to_numpy()`
  * and `g.index.to_numpy()` return, LearnedIndex.py:351,357): rows[n_b][d], ids[n_b]; either may
  * be NULL. */
-int lmi_bucket_read(lmi_index *h, int bucket, float *rows, uint32_t *ids);
+LMI_API int lmi_bucket_read(lmi_index *h, int bucket, float *rows, uint32_t *ids);
 
 /* Navigation: bucket_order[nq][nb] <- the nb most probable classes per query, most probable first.
  * logits (nullable) [nq][L] <- raw outputs of the last Linear layer. */
-int lmi_mlp_topk(lmi_index *h, const float *queries_nav, int nq, int nb, int32_t *bucket_order,
+LMI_API int lmi_mlp_topk(lmi_index *h, const float *queries_nav, int nq, int nb, int32_t *bucket_order,
                  float *logits, int on_device);
 
 /* NeuralNetwork.predict_proba (model.py:226-241): probs[nq][L] = softmax of the outputs sorted
  * descending, classes[nq][L] = the matching class indices (int32; the reference returns int64). */
-int lmi_mlp_proba(lmi_index *h, const float *queries_nav, int nq, float *probs, int32_t *classes,
+LMI_API int lmi_mlp_proba(lmi_index *h, const float *queries_nav, int nq, float *probs, int32_t *classes,
                   int on_device);
 
 /* Scan: for every query, top-LMI_K_PER_BUCKET by inner product inside each of its nb buckets,
@@ -106,33 +107,33 @@ int lmi_mlp_proba(lmi_index *h, const float *queries_nav, int nq, float *probs, 
  * dists[nq][kout], ids[nq][kout] with kout = (nb == 1 ? LMI_K_PER_BUCKET : k).
  * Unvisited slots: dist = +inf, id = 0.  keys (nullable) [nq][kout] <- rank*16 + position, the
  * tie-break key needed by lmi_merge_gathered. */
-int lmi_scan_topk(lmi_index *h, const float *queries_search, int nq, const int32_t *bucket_order,
+LMI_API int lmi_scan_topk(lmi_index *h, const float *queries_search, int nq, const int32_t *bucket_order,
                   int nb, int k, float *dists, uint32_t *ids, uint32_t *keys, int on_device);
 
 /* lmi_mlp_topk followed by lmi_scan_topk, nothing leaves the device in between. */
-int lmi_search(lmi_index *h, const float *queries_nav, const float *queries_search, int nq, int nb,
+LMI_API int lmi_search(lmi_index *h, const float *queries_nav, const float *queries_search, int nq, int nb,
                int k, float *dists, uint32_t *ids, uint32_t *keys, int32_t *bucket_order,
                int on_device);
 
 /* Multi-GPU: gathered_{dists,ids,keys}[w] is rank w's lmi_scan_topk output [nq][kout], found
  * world_stride elements after rank w-1's (0 -> dense, nq*kout; a packed all-gather of
  * [dists|ids|keys] per rank uses 3*nq*kout); writes the merged dists/ids [nq][kout]. */
-int lmi_merge_gathered(lmi_index *h, const float *gathered_dists, const uint32_t *gathered_ids,
+LMI_API int lmi_merge_gathered(lmi_index *h, const float *gathered_dists, const uint32_t *gathered_ids,
                        const uint32_t *gathered_keys, int world, int64_t world_stride, int nq,
                        int kout, float *dists, uint32_t *ids, int on_device);
 
 /* faiss.knn(xq, xb, k, metric=METRIC_INNER_PRODUCT) on host pointers: D[nq][k] similarities in
  * descending order, I[nq][k] row numbers; nb < k pads with D = -FLT_MAX, I = -1.  k <= 10. */
-int lmi_knn_ip(int device, const float *xq, int64_t nq, const float *xb, int64_t nb, int d, int k,
+LMI_API int lmi_knn_ip(int device, const float *xq, int64_t nq, const float *xb, int64_t nb, int d, int k,
                float *D, int64_t *I);
 
 /* Timings of the last lmi_mlp_topk / lmi_scan_topk / lmi_search call (synchronises the stream). */
-int lmi_timings(lmi_index *h, float *ms /* [LMI_T_COUNT] */);
+LMI_API int lmi_timings(lmi_index *h, float *ms /* [LMI_T_COUNT] */);
 /* Work done by the last scan: flops = 2 * d * sum over (query, rank) of the bucket size;
  * items = work items executed by the persistent scan kernel. */
-int lmi_scan_stats(lmi_index *h, double *flops, int64_t *pairs, int64_t *items);
-/* Tuning: rows per scan chunk (multiple of 128; default 4096). */
-int lmi_set_chunk_rows(lmi_index *h, int rows);
+LMI_API int lmi_scan_stats(lmi_index *h, double *flops, int64_t *pairs, int64_t *items);
+/* Tuning: rows per scan chunk (multiple of the 256-row block tile; default 2048). */
+LMI_API int lmi_set_chunk_rows(lmi_index *h, int rows);
 
 #ifdef __cplusplus
 }

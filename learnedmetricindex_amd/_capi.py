@@ -69,7 +69,7 @@ def lib() -> ctypes.CDLL:
                 "(or __graft_entry__.build()); there is no CPU fallback")
         import torch  # noqa: F401  (loads PyTorch-ROCm's libamdhip64 first)
 
-        L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype = res

@@ -2,12 +2,12 @@
 # Builds liblmi_hip.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-out="${here}/../liblmi_hip.so"
+out="${LMI_OUT:-${here}/../liblmi_hip.so}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-"${HIPCC}" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off \
+"${HIPCC}" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fvisibility=hidden \
   -I"${here}/../../include" -I"${here}" \
   -Wall -Wno-unused-function \
   ${LMI_EXTRA_FLAGS:-} \
   -o "${out}" "${here}/lmi_hip.hip" \
-  -Wl,-rpath,/opt/rocm/lib
+  -Wl,-rpath,/opt/rocm/lib -Wl,-Bsymbolic
 echo "built ${out}"

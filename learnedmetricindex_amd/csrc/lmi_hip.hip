@@ -88,7 +88,7 @@ struct lmi_index {
     bool building = false, built = false;
     int64_t N = 0;
     int d = 0, L = 0, KGs = 0;
-    int chunk_rows = 4096;
+    int chunk_rows = 2048;
     int64_t n_rb_total = 0;
     std::vector<int> h_nb_rows, h_rb_start, h_nch;
     DevBuf slab, ids_slab, pos, d_nb_rows, d_rb_start, d_nch;
@@ -97,7 +97,7 @@ struct lmi_index {
 
     // ---- per-call workspaces ----
     DevBuf act[2], xfrag, logits, order, q_nav, q_srch;
-    DevBuf m, cb_start, item_base, part_base, stats, head, slot_local, slot_col, colmap, qfrag;
+    DevBuf m, cb_start, item_base, part_base, stats, head, slot_local, slot_col, colmap, qfrag, grp;
     DevBuf part_score, part_row, rank_d, rank_id, out_d, out_id, out_key;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_valid[6] = {false, false, false, false, false, false};
@@ -110,10 +110,10 @@ static int set_dev(lmi_index* h) {
     return 0;
 }
 
-extern "C" int lmi_abi_version(void) { return LMI_ABI_VERSION; }
-extern "C" const char* lmi_last_error(void) { return g_err.c_str(); }
+extern "C" LMI_API int lmi_abi_version(void) { return LMI_ABI_VERSION; }
+extern "C" LMI_API const char* lmi_last_error(void) { return g_err.c_str(); }
 
-extern "C" int lmi_create(int device, lmi_index** out) {
+extern "C" LMI_API int lmi_create(int device, lmi_index** out) {
     if (!out) return fail("lmi_create: out is NULL");
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
@@ -128,13 +128,13 @@ extern "C" int lmi_create(int device, lmi_index** out) {
     h->num_cus = prop.multiProcessorCount;
     int occ = 0;
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_kernel, 256, SCAN_LDS));
-    h->scan_blocks_per_cu = std::max(1, std::min(occ, 2));
+    h->scan_blocks_per_cu = std::max(1, std::min(occ, RB == 1 ? 2 : 1));
     for (int i = 0; i < 6; ++i) HIPCHK(hipEventCreate(&h->ev[i]));
     *out = h;
     return 0;
 }
 
-extern "C" int lmi_destroy(lmi_index* h) {
+extern "C" LMI_API int lmi_destroy(lmi_index* h) {
     if (!h) return 0;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
@@ -143,7 +143,7 @@ extern "C" int lmi_destroy(lmi_index* h) {
     DevBuf* bufs[] = {&h->slab, &h->ids_slab, &h->pos, &h->d_nb_rows, &h->d_rb_start, &h->d_nch, &h->stage,
                       &h->act[0], &h->act[1], &h->xfrag, &h->logits, &h->order, &h->q_nav, &h->q_srch, &h->m,
                       &h->cb_start, &h->item_base, &h->part_base, &h->stats, &h->head, &h->slot_local,
-                      &h->slot_col, &h->colmap, &h->qfrag, &h->part_score, &h->part_row, &h->rank_d,
+                      &h->slot_col, &h->colmap, &h->qfrag, &h->grp, &h->part_score, &h->part_row, &h->rank_d,
                       &h->rank_id, &h->out_d, &h->out_id, &h->out_key};
     for (DevBuf* b : bufs) b->release();
     for (int i = 0; i < 6; ++i)
@@ -152,15 +152,15 @@ extern "C" int lmi_destroy(lmi_index* h) {
     return 0;
 }
 
-extern "C" int lmi_set_stream(lmi_index* h, void* s) {
+extern "C" LMI_API int lmi_set_stream(lmi_index* h, void* s) {
     if (!h) return fail("lmi_set_stream: NULL handle");
     h->stream = reinterpret_cast<hipStream_t>(s);
     return 0;
 }
 
-extern "C" int lmi_set_chunk_rows(lmi_index* h, int rows) {
+extern "C" LMI_API int lmi_set_chunk_rows(lmi_index* h, int rows) {
     if (!h) return fail("lmi_set_chunk_rows: NULL handle");
-    if (rows < 128 || rows % 128) return fail("lmi_set_chunk_rows: rows must be a positive multiple of 128");
+    if (rows < TILE_ROWS || rows % TILE_ROWS) return fail("lmi_set_chunk_rows: rows must be a positive multiple of %d", TILE_ROWS);
     if (h->building || h->built) return fail("lmi_set_chunk_rows: must be called before lmi_buckets_begin");
     h->chunk_rows = rows;
     return 0;
@@ -179,7 +179,7 @@ static int pack_from_host(lmi_index* h, const float* src, int rows, int cols, in
     return 0;
 }
 
-extern "C" int lmi_set_mlp(lmi_index* h, int n_layers, const int* dims, const float* const* W,
+extern "C" LMI_API int lmi_set_mlp(lmi_index* h, int n_layers, const int* dims, const float* const* W,
                            const float* const* b) {
     if (!h) return fail("lmi_set_mlp: NULL handle");
     if (n_layers < 1 || n_layers > LMI_MAX_LAYERS) return fail("lmi_set_mlp: n_layers %d out of range", n_layers);
@@ -207,7 +207,7 @@ extern "C" int lmi_set_mlp(lmi_index* h, int n_layers, const int* dims, const fl
     return 0;
 }
 
-extern "C" int lmi_buckets_begin(lmi_index* h, int64_t N, int d, int L, const int64_t* labels,
+extern "C" LMI_API int lmi_buckets_begin(lmi_index* h, int64_t N, int d, int L, const int64_t* labels,
                                  const uint32_t* ids, const uint8_t* owned) {
     if (!h) return fail("lmi_buckets_begin: NULL handle");
     if (N < 0 || d < 1 || L < 1 || (N > 0 && !labels)) return fail("lmi_buckets_begin: bad arguments");
@@ -264,7 +264,7 @@ extern "C" int lmi_buckets_begin(lmi_index* h, int64_t N, int d, int L, const in
     return 0;
 }
 
-extern "C" int lmi_buckets_add_rows(lmi_index* h, const float* rows, int64_t row0, int64_t nrows, int on_device) {
+extern "C" LMI_API int lmi_buckets_add_rows(lmi_index* h, const float* rows, int64_t row0, int64_t nrows, int on_device) {
     if (!h || !h->building) return fail("lmi_buckets_add_rows: call lmi_buckets_begin first");
     if (row0 < 0 || nrows < 0 || row0 + nrows > h->N) return fail("lmi_buckets_add_rows: rows [%lld,%lld) outside [0,%lld)", (long long)row0, (long long)(row0 + nrows), (long long)h->N);
     if (nrows == 0) return 0;
@@ -288,7 +288,7 @@ extern "C" int lmi_buckets_add_rows(lmi_index* h, const float* rows, int64_t row
     return 0;
 }
 
-extern "C" int lmi_buckets_end(lmi_index* h) {
+extern "C" LMI_API int lmi_buckets_end(lmi_index* h) {
     if (!h || !h->building) return fail("lmi_buckets_end: call lmi_buckets_begin first");
     if (h->rows_added != h->N) return fail("lmi_buckets_end: %lld of %lld rows were added", (long long)h->rows_added, (long long)h->N);
     CHK(set_dev(h));
@@ -299,13 +299,13 @@ extern "C" int lmi_buckets_end(lmi_index* h) {
     return 0;
 }
 
-extern "C" int lmi_bucket_sizes(lmi_index* h, int64_t* sizes) {
+extern "C" LMI_API int lmi_bucket_sizes(lmi_index* h, int64_t* sizes) {
     if (!h || !(h->built || h->building)) return fail("lmi_bucket_sizes: no buckets");
     for (int b = 0; b < h->L; ++b) sizes[b] = h->h_nb_rows[b];
     return 0;
 }
 
-extern "C" int lmi_bucket_read(lmi_index* h, int bucket, float* rows, uint32_t* ids) {
+extern "C" LMI_API int lmi_bucket_read(lmi_index* h, int bucket, float* rows, uint32_t* ids) {
     if (!h || !h->built) return fail("lmi_bucket_read: the bucket index is not built");
     if (bucket < 0 || bucket >= h->L) return fail("lmi_bucket_read: bucket %d outside [0,%d)", bucket, h->L);
     const int64_t n = h->h_nb_rows[bucket];
@@ -381,7 +381,7 @@ static int mlp_enqueue(lmi_index* h, const float* d_q, int nq, int nb, int* d_or
     return 0;
 }
 
-extern "C" int lmi_mlp_topk(lmi_index* h, const float* queries_nav, int nq, int nb, int32_t* bucket_order,
+extern "C" LMI_API int lmi_mlp_topk(lmi_index* h, const float* queries_nav, int nq, int nb, int32_t* bucket_order,
                             float* logits, int on_device) {
     if (!h) return fail("lmi_mlp_topk: NULL handle");
     if (nq < 0) return fail("lmi_mlp_topk: nq < 0");
@@ -410,7 +410,7 @@ extern "C" int lmi_mlp_topk(lmi_index* h, const float* queries_nav, int nq, int 
     return 0;
 }
 
-extern "C" int lmi_mlp_proba(lmi_index* h, const float* queries_nav, int nq, float* probs, int32_t* classes,
+extern "C" LMI_API int lmi_mlp_proba(lmi_index* h, const float* queries_nav, int nq, float* probs, int32_t* classes,
                              int on_device) {
     if (!h) return fail("lmi_mlp_proba: NULL handle");
     if (nq < 0) return fail("lmi_mlp_proba: nq < 0");
@@ -460,7 +460,9 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     CHK(h->item_base.reserve((L + 1) * 4));
     CHK(h->part_base.reserve((L + 1) * 8));
     CHK(h->stats.reserve(16));
-    CHK(h->head.reserve(16));
+    CHK(h->head.reserve(64));
+    const size_t grp_ints = (size_t)NGRP * L + (size_t)NGRP * (L + 1) + 2 * NGRP + L;
+    CHK(h->grp.reserve(grp_ints * 4));
     CHK(h->slot_local.reserve((size_t)nslots * 4));
     CHK(h->slot_col.reserve((size_t)nslots * 4));
     CHK(h->colmap.reserve((size_t)ncb_bound * 32 * 4));
@@ -478,13 +480,20 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     R.item_base = h->item_base.as<int>();
     R.part_base = h->part_base.as<long long>();
     R.stats = h->stats.as<long long>();
+    R.grp_bucket = h->grp.as<int>();
+    R.grp_base = R.grp_bucket + (size_t)NGRP * L;
+    R.grp_n = R.grp_base + (size_t)NGRP * (L + 1);
+    R.grp_total = R.grp_n + NGRP;
+    R.order_tmp = R.grp_total + NGRP;
 
     HIPCHK(hipMemsetAsync(h->m.p, 0, L * 4, h->stream));
-    HIPCHK(hipMemsetAsync(h->head.p, 0, 16, h->stream));
+    HIPCHK(hipMemsetAsync(h->head.p, 0, 64, h->stream));
     HIPCHK(hipMemsetAsync(h->colmap.p, 0xFF, (size_t)ncb_bound * 32 * 4, h->stream));
     route_count_kernel<<<cdiv(nslots, 256), 256, 0, h->stream>>>(d_order, nslots, L, R, h->slot_local.as<int>());
     HIPCHK(hipGetLastError());
     route_scan_kernel<<<1, 256, 0, h->stream>>>(L, R);
+    HIPCHK(hipGetLastError());
+    route_group_kernel<<<1, 1024, 0, h->stream>>>(L, R);
     HIPCHK(hipGetLastError());
     route_fill_kernel<<<cdiv(nslots, 256), 256, 0, h->stream>>>(d_order, h->slot_local.as<int>(), nslots, nb,
                                                                R.cb_start, h->colmap.as<int>(), h->slot_col.as<int>());
@@ -507,7 +516,10 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     S.nch = R.nch;
     S.m = R.m;
     S.cb_start = R.cb_start;
-    S.item_base = R.item_base;
+    S.grp_bucket = R.grp_bucket;
+    S.grp_base = R.grp_base;
+    S.grp_n = R.grp_n;
+    S.grp_total = R.grp_total;
     S.part_base = R.part_base;
     S.head = h->head.as<unsigned>();
     S.part_score = h->part_score.as<float>();
@@ -553,7 +565,7 @@ static int check_scan_args(lmi_index* h, int nq, int nb, int k, int* kout) {
     return 0;
 }
 
-extern "C" int lmi_scan_topk(lmi_index* h, const float* queries_search, int nq, const int32_t* bucket_order,
+extern "C" LMI_API int lmi_scan_topk(lmi_index* h, const float* queries_search, int nq, const int32_t* bucket_order,
                              int nb, int k, float* dists, uint32_t* ids, uint32_t* keys, int on_device) {
     if (!h) return fail("lmi_scan_topk: NULL handle");
     int kout = 0;
@@ -586,7 +598,7 @@ extern "C" int lmi_scan_topk(lmi_index* h, const float* queries_search, int nq, 
     return 0;
 }
 
-extern "C" int lmi_search(lmi_index* h, const float* queries_nav, const float* queries_search, int nq, int nb,
+extern "C" LMI_API int lmi_search(lmi_index* h, const float* queries_nav, const float* queries_search, int nq, int nb,
                           int k, float* dists, uint32_t* ids, uint32_t* keys, int32_t* bucket_order, int on_device) {
     if (!h) return fail("lmi_search: NULL handle");
     int kout = 0;
@@ -627,7 +639,7 @@ extern "C" int lmi_search(lmi_index* h, const float* queries_nav, const float* q
     return 0;
 }
 
-extern "C" int lmi_merge_gathered(lmi_index* h, const float* gd, const uint32_t* gi, const uint32_t* gk, int world,
+extern "C" LMI_API int lmi_merge_gathered(lmi_index* h, const float* gd, const uint32_t* gi, const uint32_t* gk, int world,
                                   int64_t world_stride, int nq, int kout, float* dists, uint32_t* ids,
                                   int on_device) {
     if (!h) return fail("lmi_merge_gathered: NULL handle");
@@ -661,7 +673,7 @@ extern "C" int lmi_merge_gathered(lmi_index* h, const float* gd, const uint32_t*
     return 0;
 }
 
-extern "C" int lmi_knn_ip(int device, const float* xq, int64_t nq, const float* xb, int64_t nb, int d, int k,
+extern "C" LMI_API int lmi_knn_ip(int device, const float* xq, int64_t nq, const float* xb, int64_t nb, int d, int k,
                           float* D, int64_t* I) {
     if (k < 1 || k > KPB) return fail("lmi_knn_ip: k %d outside [1,%d]", k, KPB);
     if (nq < 0 || nb < 0 || d < 1) return fail("lmi_knn_ip: bad sizes");
@@ -704,7 +716,7 @@ extern "C" int lmi_knn_ip(int device, const float* xq, int64_t nq, const float* 
     return rc;
 }
 
-extern "C" int lmi_timings(lmi_index* h, float* ms) {
+extern "C" LMI_API int lmi_timings(lmi_index* h, float* ms) {
     if (!h || !ms) return fail("lmi_timings: NULL argument");
     CHK(set_dev(h));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -723,7 +735,7 @@ extern "C" int lmi_timings(lmi_index* h, float* ms) {
     return 0;
 }
 
-extern "C" int lmi_scan_stats(lmi_index* h, double* flops, int64_t* pairs, int64_t* items) {
+extern "C" LMI_API int lmi_scan_stats(lmi_index* h, double* flops, int64_t* pairs, int64_t* items) {
     if (!h) return fail("lmi_scan_stats: NULL handle");
     CHK(set_dev(h));
     if (h->stats_pending) {

@@ -24,12 +24,16 @@ namespace lmi {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int KPB = 10;         // results per (query, bucket): LearnedIndex.py:334
-constexpr int TILE_ROWS = 128;  // vectors per block tile (4 waves x 32)
+#ifndef LMI_SCAN_RB
+#define LMI_SCAN_RB 1
+#endif
+constexpr int RB = LMI_SCAN_RB;       // row-blocks (of 32 vectors) per wave: 2 -> 1 block/CU, 1 -> 2 blocks/CU
+constexpr int TILE_ROWS = 128 * RB;   // vectors per block tile (4 waves x RB x 32)
 constexpr int TILE_COLS = 128;  // queries per block tile (4 col-blocks x 32)
 constexpr int STAGE_G = 4;      // k-groups (of 8) per LDS stage -> BK = 32
-constexpr int STAGE_BYTES = 32768;  // A: 4 waves x 4 g x 1 KiB, B: 4 col-blocks x 4 g x 1 KiB
-constexpr int SCAN_LDS = 0;  // all LDS is static (four 16 KiB stage arrays)
+constexpr int SCAN_LDS = 0;           // all LDS is static: 2 x (A 16*RB KiB + B 16 KiB)
 constexpr unsigned NOROW = 0xFFFFFFFFu;
+constexpr int NGRP = 8;               // work-queue groups = XCDs of the MI355X
 
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -249,6 +253,12 @@ struct RouteArrays {
     int* item_base;       // [L+1] work-item prefix
     long long* part_base; // [L+1] partial-list prefix
     long long* stats;     // [0] = sum m_b * n_b (pairs), [1] = items
+    // XCD-affine work queues (route_group_kernel): NGRP groups of buckets, heaviest first
+    int* grp_bucket;      // [NGRP][L]   bucket ids of the group, in processing order
+    int* grp_base;        // [NGRP][L+1] prefix of the buckets' item counts inside the group
+    int* grp_n;           // [NGRP]      buckets in the group
+    int* grp_total;       // [NGRP]      items in the group
+    int* order_tmp;       // [L] scratch: buckets sorted by work
 };
 
 __global__ void route_count_kernel(const int* __restrict__ bucket_order, int nslots, int L, RouteArrays R,
@@ -304,6 +314,46 @@ __global__ __launch_bounds__(256) void route_scan_kernel(int L, RouteArrays R) {
     }
 }
 
+// Buckets -> NGRP work queues.  All items of a bucket go to ONE queue and each queue is served
+// first by the blocks of one XCD (scan_kernel), so that the blocks sharing an XCD's 4 MiB L2 work
+// on the same few buckets: their query tiles (384 KiB each) then stay L2-resident and a chunk's
+// vectors are fetched once for all of its query tiles.  Heaviest buckets first (LPT) balances the
+// queues; blocks of a drained queue steal from the others, so placement only affects speed.
+__global__ __launch_bounds__(1024) void route_group_kernel(int L, RouteArrays R) {
+    const int t = threadIdx.x;
+    // rank of every bucket by (work desc, id asc); work = item count x rows is a fine proxy
+    for (int b = t; b < L; b += 1024) {
+        const long long wb = (long long)R.m[b] * R.nb_rows[b];
+        int rank = 0;
+        for (int o = 0; o < L; ++o) {
+            const long long wo = (long long)R.m[o] * R.nb_rows[o];
+            rank += (wo > wb) || (wo == wb && o < b);
+        }
+        R.order_tmp[rank] = b;
+    }
+    __syncthreads();
+    if (t == 0) {
+        long long load[NGRP];
+        int cnt[NGRP], items[NGRP];
+        for (int g = 0; g < NGRP; ++g) { load[g] = 0; cnt[g] = 0; items[g] = 0; R.grp_base[g * (L + 1)] = 0; }
+        for (int i = 0; i < L; ++i) {
+            const int b = R.order_tmp[i];
+            const int m = R.m[b];
+            if (m == 0) break;  // sorted by work: nothing but idle buckets from here on
+            int g = 0;
+            for (int o = 1; o < NGRP; ++o)
+                if (load[o] < load[g]) g = o;
+            const int it = ((m + TILE_COLS - 1) / TILE_COLS) * R.nch[b];
+            R.grp_bucket[g * L + cnt[g]] = b;
+            items[g] += it;
+            cnt[g] += 1;
+            R.grp_base[g * (L + 1) + cnt[g]] = items[g];
+            load[g] += (long long)m * R.nb_rows[b];
+        }
+        for (int g = 0; g < NGRP; ++g) { R.grp_n[g] = cnt[g]; R.grp_total[g] = items[g]; }
+    }
+}
+
 __global__ void route_fill_kernel(const int* __restrict__ bucket_order, const int* __restrict__ slot_local,
                                   int nslots, int nb, const int* __restrict__ cb_start,
                                   int* __restrict__ colmap, int* __restrict__ slot_col) {
@@ -341,9 +391,12 @@ struct ScanParams {
     const int* nch;
     const int* m;
     const int* cb_start;
-    const int* item_base;
     const long long* part_base;
-    unsigned* head;
+    const int* grp_bucket;
+    const int* grp_base;
+    const int* grp_n;
+    const int* grp_total;
+    unsigned* head;  // [NGRP] queue heads, zeroed before the launch
     float* part_score;
     unsigned* part_row;
 };
@@ -377,7 +430,8 @@ __device__ __forceinline__ bool better(float s, unsigned r, float s2, unsigned r
 // stage u+1 (parity 1-PAR) do not alias the ds_reads of stage u (parity PAR) and does not drain
 // vmcnt(0) in front of them -- with one array + runtime offsets it did, serialising load and MFMA.
 struct ScanLds {
-    float4 *A0, *A1, *B0, *B1;  // each [16][64] float4 = 16 KiB: A: (wave, g), B: (col-block, g)
+    float4 *A0, *A1;  // each [4 waves][RB][STAGE_G][64] float4
+    float4 *B0, *B1;  // each [4 col-blocks][STAGE_G][64] float4
 };
 
 template <int NCB>
@@ -385,22 +439,34 @@ struct ScanItem {
     const ScanParams& P;
     const ScanLds& S;
     int lane, w, h, c;
-    int KG, NS, n_b, nrb, rb_in_b0, total;
-    const float4* abase;
+    int KG, NS, n_b, nrb_b, rb_in_b0, total;
+    const float4* aslab;   // bucket's first row-block, + lane
     const float4* bbase;
     float lv[NCB][KPB];
     unsigned li[NCB][KPB];
-    f32x16 acc[NCB];
+    f32x16 acc[RB][NCB];
 
     template <int PAR>
     __device__ __forceinline__ void issue(int u) {  // DMA stage u into the parity-PAR buffers
+#ifdef LMI_ABL_NOLOAD  // timing-only ablation build: no operand traffic (results are garbage)
+        return;
+#endif
         float4* sA = PAR ? S.A1 : S.A0;
         float4* sB = PAR ? S.B1 : S.B0;
         const int vt = u / NS, t = u - vt * NS;
-        if (vt * 4 + w < nrb) {
-            const float4* a = abase + ((size_t)vt * 4 * KG + t * STAGE_G) * 64;
 #pragma unroll
-            for (int g = 0; g < STAGE_G; ++g) glds16(a + (size_t)g * 64, sA + (w * STAGE_G + g) * 64);
+        for (int j = 0; j < RB; ++j) {
+            // row-blocks past the bucket's end are clamped to its last one: their scores are
+            // discarded by the row < n_b test of the epilogue (logical rows >= n_b)
+#ifdef LMI_ABL_HOTA  // timing-only ablation: every block streams the same 16 row-blocks (L2-resident)
+            const int rb = (rb_in_b0 + (vt * 4 + w) * RB + j) & 15;
+#else
+            const int rb = min(rb_in_b0 + (vt * 4 + w) * RB + j, nrb_b - 1);
+#endif
+            const float4* a = aslab + ((size_t)rb * KG + t * STAGE_G) * 64;
+#pragma unroll
+            for (int g = 0; g < STAGE_G; ++g)
+                glds16(a + (size_t)g * 64, sA + ((w * RB + j) * STAGE_G + g) * 64);
         }
         if (w < NCB) {
             const float4* q = bbase + (size_t)(t * STAGE_G) * 64;
@@ -409,55 +475,93 @@ struct ScanItem {
         }
     }
 
+    // the same DMA, one k-group at a time, so that it can be interleaved with the MFMAs of the
+    // running stage instead of being issued as one burst (each LDS-DMA costs ~64 issue cycles)
     template <int PAR>
-    __device__ __forceinline__ void compute(int u) {  // MFMAs of stage u from the parity-PAR buffers
-        const float4* sA = PAR ? S.A1 : S.A0;
-        const float4* sB = PAR ? S.B1 : S.B0;
+    __device__ __forceinline__ void issue_part(int u, int g) {
+#ifdef LMI_ABL_NOLOAD
+        return;
+#endif
+        float4* sA = PAR ? S.A1 : S.A0;
+        float4* sB = PAR ? S.B1 : S.B0;
         const int vt = u / NS, t = u - vt * NS;
-        if (vt * 4 + w >= nrb) return;  // wave-uniform: this wave's row-block is past the chunk
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            const int rb = min(rb_in_b0 + (vt * 4 + w) * RB + j, nrb_b - 1);
+            glds16(aslab + ((size_t)rb * KG + t * STAGE_G + g) * 64, sA + ((w * RB + j) * STAGE_G + g) * 64);
+        }
+        if (w < NCB) glds16(bbase + (size_t)(t * STAGE_G + g) * 64, sB + (w * STAGE_G + g) * 64);
+    }
+
+    template <int PAR, bool INTERLEAVE = false>
+    __device__ __forceinline__ void compute(int u, bool more = false) {  // MFMAs of stage u (parity-PAR buffers)
+        const float4* sA = (PAR ? S.A1 : S.A0) + (w * RB) * STAGE_G * 64 + lane;
+        const float4* sB = (PAR ? S.B1 : S.B0) + lane;
+        const int vt = u / NS, t = u - vt * NS;
+        float4 fa[2][RB], fb[2][NCB];  // fragment registers, double-buffered over g
+#pragma unroll
+        for (int j = 0; j < RB; ++j) fa[0][j] = sA[(j * STAGE_G) * 64];
+#pragma unroll
+        for (int n = 0; n < NCB; ++n) fb[0][n] = sB[(n * STAGE_G) * 64];
 #pragma unroll
         for (int g = 0; g < STAGE_G; ++g) {
-            const float4 a = sA[(w * STAGE_G + g) * 64 + lane];
-            float4 bq[NCB];
+            const int cur = g & 1, nxt = cur ^ 1;
+            if (g + 1 < STAGE_G) {
 #pragma unroll
-            for (int n = 0; n < NCB; ++n) bq[n] = sB[(n * STAGE_G + g) * 64 + lane];
-            const float av[4] = {a.x, a.y, a.z, a.w};
+                for (int j = 0; j < RB; ++j) fa[nxt][j] = sA[(j * STAGE_G + g + 1) * 64];
+#pragma unroll
+                for (int n = 0; n < NCB; ++n) fb[nxt][n] = sB[(n * STAGE_G + g + 1) * 64];
+            }
+            if (INTERLEAVE && more) issue_part<1 - PAR>(u + 1, g);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
 #pragma unroll
-                for (int n = 0; n < NCB; ++n) {
-                    const float bv = s == 0 ? bq[n].x : s == 1 ? bq[n].y : s == 2 ? bq[n].z : bq[n].w;
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv, acc[n], 0, 0, 0);
+                for (int j = 0; j < RB; ++j) {
+                    const float4 a = fa[cur][j];
+                    const float av = s == 0 ? a.x : s == 1 ? a.y : s == 2 ? a.z : a.w;
+#pragma unroll
+                    for (int n = 0; n < NCB; ++n) {
+                        const float4 b = fb[cur][n];
+                        const float bv = s == 0 ? b.x : s == 1 ? b.y : s == 2 ? b.z : b.w;
+                        acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j][n], 0, 0, 0);
+                    }
                 }
             }
         }
-        if (t == NS - 1) {  // tile finished: filter the 16 x NCB scores of this lane
-            const unsigned rowbase = (unsigned)((rb_in_b0 + vt * 4 + w) * 32);
+        if (t == NS - 1) {  // tile finished: filter the 16 x RB x NCB scores of this lane
 #pragma unroll
-            for (int n = 0; n < NCB; ++n) {
-                const float thr = lv[n][KPB - 1];
-                unsigned mask = 0;
+            for (int j = 0; j < RB; ++j) {
+                const unsigned rowbase = (unsigned)((rb_in_b0 + (vt * 4 + w) * RB + j) * 32);
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    mask |= (unsigned)(acc[n][r] > thr && rowbase + acc_row(r, h) < (unsigned)n_b) << r;
-                while (mask) {  // rare after warm-up; ascending r == ascending row
-                    const int r = __builtin_ctz(mask);
-                    mask &= mask - 1;
-                    float s = acc[n][0];
+                for (int n = 0; n < NCB; ++n) {
+                    const float thr = lv[n][KPB - 1];
+                    unsigned mask = 0;
 #pragma unroll
-                    for (int i = 1; i < 16; ++i) s = (r == i) ? acc[n][i] : s;
-                    if (s > lv[n][KPB - 1]) list_insert(lv[n], li[n], s, rowbase + acc_row(r, h));
+                    for (int r = 0; r < 16; ++r)
+                        mask |= (unsigned)(acc[j][n][r] > thr && rowbase + acc_row(r, h) < (unsigned)n_b) << r;
+                    while (mask) {  // rare after warm-up; ascending r == ascending row
+                        const int r = __builtin_ctz(mask);
+                        mask &= mask - 1;
+                        float s = acc[j][n][0];
+#pragma unroll
+                        for (int i = 1; i < 16; ++i) s = (r == i) ? acc[j][n][i] : s;
+                        if (s > lv[n][KPB - 1]) list_insert(lv[n], li[n], s, rowbase + acc_row(r, h));
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.0f;
                 }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
             }
         }
     }
 
     template <int PAR>
     __device__ __forceinline__ void step(int u) {
+#ifdef LMI_DMA_INTERLEAVE
+        compute<PAR, true>(u, u + 1 < total);
+#else
         if (u + 1 < total) issue<1 - PAR>(u + 1);
         compute<PAR>(u);
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -467,12 +571,12 @@ struct ScanItem {
         lane = tid & 63; w = tid >> 6; h = lane >> 5; c = lane & 31;
         KG = P.KG; NS = KG / STAGE_G;
         n_b = P.nb_rows[b];
-        const int nrb_b = (n_b + 31) >> 5;
-        rb_in_b0 = ch * P.chunk_rb;                          // first row-block of the chunk
-        nrb = min(P.chunk_rb, nrb_b - rb_in_b0);             // row-blocks in this chunk
-        const int nvt = (nrb + 3) >> 2;                      // 128-row tiles
+        nrb_b = (n_b + 31) >> 5;
+        rb_in_b0 = ch * P.chunk_rb;                              // first row-block of the chunk
+        const int nrb = min(P.chunk_rb, nrb_b - rb_in_b0);       // row-blocks in this chunk
+        const int nvt = (nrb + 4 * RB - 1) / (4 * RB);           // TILE_ROWS-row tiles
         const int cb0 = P.cb_start[b] + qt * 4;
-        abase = P.slab + ((size_t)(P.rb_start[b] + rb_in_b0 + w) * KG) * 64 + lane;
+        aslab = P.slab + ((size_t)P.rb_start[b] * KG) * 64 + lane;
         bbase = P.qfrag + ((size_t)(cb0 + w) * KG) * 64 + lane;  // wave w stages col-block w
         total = nvt * NS;
 #pragma unroll
@@ -480,7 +584,9 @@ struct ScanItem {
 #pragma unroll
             for (int j = 0; j < KPB; ++j) { lv[n][j] = -INFINITY; li[n][j] = NOROW; }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+            for (int j = 0; j < RB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.0f;
         }
 
         issue<0>(0);
@@ -543,26 +649,35 @@ struct ScanItem {
     }
 };
 
-__global__ __launch_bounds__(256, 2) void scan_kernel(ScanParams P) {
-    __shared__ __attribute__((aligned(16))) float4 sA0[1024];
-    __shared__ __attribute__((aligned(16))) float4 sA1[1024];
-    __shared__ __attribute__((aligned(16))) float4 sB0[1024];
-    __shared__ __attribute__((aligned(16))) float4 sB1[1024];
+__global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void scan_kernel(ScanParams P) {
+    __shared__ __attribute__((aligned(16))) float4 sA0[4 * RB * STAGE_G * 64];
+    __shared__ __attribute__((aligned(16))) float4 sA1[4 * RB * STAGE_G * 64];
+    __shared__ __attribute__((aligned(16))) float4 sB0[4 * STAGE_G * 64];
+    __shared__ __attribute__((aligned(16))) float4 sB1[4 * STAGE_G * 64];
     const ScanLds S{sA0, sA1, sB0, sB1};
     int* s_item = reinterpret_cast<int*>(sB1);  // item broadcast: no DMA is in flight between items
-    const int total_items = P.item_base[P.L];
+    // home queue = this block's XCD (HW_REG_XCC_ID, id 20, bits [3:0]); any value works: speed only
+    int grp = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & (NGRP - 1));
     for (;;) {
         if (threadIdx.x == 0) {
-            int it = (int)atomicAdd(P.head, 1u);
             int b = -1, local = 0;
-            if (it < total_items) {
-                int lo = 0, hi = P.L;  // last b with item_base[b] <= it
-                while (hi - lo > 1) {
-                    int mid = (lo + hi) >> 1;
-                    if (P.item_base[mid] <= it) lo = mid; else hi = mid;
+            for (int tries = 0; tries < NGRP; ++tries) {
+                const int tot = P.grp_total[grp];
+                if (__hip_atomic_load(&P.head[grp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)tot) {
+                    const int it = (int)atomicAdd(&P.head[grp], 1u);
+                    if (it < tot) {
+                        const int* base = P.grp_base + grp * (P.L + 1);
+                        int lo = 0, hi = P.grp_n[grp];  // last i with base[i] <= it
+                        while (hi - lo > 1) {
+                            const int mid = (lo + hi) >> 1;
+                            if (base[mid] <= it) lo = mid; else hi = mid;
+                        }
+                        b = P.grp_bucket[grp * P.L + lo];
+                        local = it - base[lo];
+                        break;
+                    }
                 }
-                b = lo;
-                local = it - P.item_base[b];
+                grp = (grp + 1) & (NGRP - 1);  // queue drained: steal from the next one
             }
             s_item[0] = b;
             s_item[1] = local;

@@ -95,7 +95,7 @@ def test_k_variants_G4(capi, oracle):
     Xn, Qn, Xs, Qs = inputs_for("G4", g)
     layers = layers_from(g)
     dp = g["data_prediction"]
-    idx = capi.Index(0, chunk_rows=128)
+    idx = capi.Index(0, chunk_rows=256)
     idx.set_mlp(layers)
     idx.set_buckets(Xs, dp[:, 0], 12)
     for tag, nb, k in (("nb1_k5", 1, 5), ("nb3_k5", 3, 5), ("nb3_k15", 3, 15), ("nb12_k10", 12, 10)):

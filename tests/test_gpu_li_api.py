@@ -125,7 +125,7 @@ def test_bucket_read_roundtrip():
     X = rs.randn(1000, 45).astype(np.float32)
     lab = rs.randint(0, 7, size=1000)
     lab[lab == 4] = 5  # bucket 4 empty
-    idx = _capi.Index(0, chunk_rows=128)
+    idx = _capi.Index(0, chunk_rows=256)
     idx.set_buckets(X, lab, 7)
     np.testing.assert_array_equal(idx.bucket_sizes(), np.bincount(lab, minlength=7))
     for b in range(7):
