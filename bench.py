@@ -60,7 +60,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--chunk-rows", type=int, default=None)
-    ap.add_argument("--traffic-json", default=None, help="PMC-derived HBM bytes per scan launch (profiles/*.json)")
+    ap.add_argument("--traffic-json", default=None,
+                    help="PMC-derived HBM bytes per scan launch (default: profiles/scan_pmc_<config>.json, "
+                         "written by profiles/summarize.py from separate rocprofv3 --pmc passes of this bench)")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
     for key in ("n", "nq", "nb", "leaves"):
@@ -228,8 +230,10 @@ def main():
         visited = visited[(visited >= 0) & (owner[np.clip(visited, 0, L - 1)] == rank)]
         compulsory = 4.0 * d * float(sizes[visited].sum())  # every visited bucket read once per batch
         traffic = None
-        if args.traffic_json and os.path.exists(args.traffic_json):
-            traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_launch")
+        tj = args.traffic_json or os.path.join(ROOT, "profiles", f"scan_pmc_{args.config}.json")
+        overridden = any(getattr(args, key) is not None for key in ("n", "nq", "nb", "leaves"))
+        if world == 1 and not overridden and os.path.exists(tj):
+            traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
         result = {
             "metric": "queries/sec @ recall@10, 768-d 10M index, 10k query batch",
             "value": round(nq * args.steps / elapsed, 2),

@@ -97,7 +97,7 @@ struct lmi_index {
 
     // ---- per-call workspaces ----
     DevBuf act[2], xfrag, logits, order, q_nav, q_srch;
-    DevBuf m, cb_start, item_base, part_base, stats, head, slot_local, slot_col, colmap, qfrag, grp;
+    DevBuf m, cb_start, item_base, part_base, stats, head, slot_local, slot_col, colmap, qfrag, grp, col_thr;
     DevBuf part_score, part_row, rank_d, rank_id, out_d, out_id, out_key;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_valid[6] = {false, false, false, false, false, false};
@@ -143,7 +143,7 @@ extern "C" LMI_API int lmi_destroy(lmi_index* h) {
     DevBuf* bufs[] = {&h->slab, &h->ids_slab, &h->pos, &h->d_nb_rows, &h->d_rb_start, &h->d_nch, &h->stage,
                       &h->act[0], &h->act[1], &h->xfrag, &h->logits, &h->order, &h->q_nav, &h->q_srch, &h->m,
                       &h->cb_start, &h->item_base, &h->part_base, &h->stats, &h->head, &h->slot_local,
-                      &h->slot_col, &h->colmap, &h->qfrag, &h->grp, &h->part_score, &h->part_row, &h->rank_d,
+                      &h->slot_col, &h->colmap, &h->qfrag, &h->grp, &h->col_thr, &h->part_score, &h->part_row, &h->rank_d,
                       &h->rank_id, &h->out_d, &h->out_id, &h->out_key};
     for (DevBuf* b : bufs) b->release();
     for (int i = 0; i < 6; ++i)
@@ -466,6 +466,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     CHK(h->slot_local.reserve((size_t)nslots * 4));
     CHK(h->slot_col.reserve((size_t)nslots * 4));
     CHK(h->colmap.reserve((size_t)ncb_bound * 32 * 4));
+    CHK(h->col_thr.reserve((size_t)ncb_bound * 32 * 4));
     CHK(h->qfrag.reserve((size_t)ncb_bound * h->KGs * 1024));
     CHK(h->part_score.reserve((size_t)part_lists * KPB * 4));
     CHK(h->part_row.reserve((size_t)part_lists * KPB * 4));
@@ -489,6 +490,8 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     HIPCHK(hipMemsetAsync(h->m.p, 0, L * 4, h->stream));
     HIPCHK(hipMemsetAsync(h->head.p, 0, 64, h->stream));
     HIPCHK(hipMemsetAsync(h->colmap.p, 0xFF, (size_t)ncb_bound * 32 * 4, h->stream));
+    HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->col_thr.p), (int)0xFF800000u /* -inf */,
+                             (size_t)ncb_bound * 32, h->stream));
     route_count_kernel<<<cdiv(nslots, 256), 256, 0, h->stream>>>(d_order, nslots, L, R, h->slot_local.as<int>());
     HIPCHK(hipGetLastError());
     route_scan_kernel<<<1, 256, 0, h->stream>>>(L, R);
@@ -522,6 +525,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     S.grp_total = R.grp_total;
     S.part_base = R.part_base;
     S.head = h->head.as<unsigned>();
+    S.col_thr = h->col_thr.as<float>();
     S.part_score = h->part_score.as<float>();
     S.part_row = h->part_row.as<unsigned>();
     scan_kernel<<<h->num_cus * h->scan_blocks_per_cu, 256, SCAN_LDS, h->stream>>>(S);

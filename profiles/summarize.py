@@ -48,6 +48,24 @@ def main(src, tag):
             pmc[name] = {"launches": len(vals), "avg_kib": sum(vals) / len(vals), "min_kib": min(vals),
                          "max_kib": max(vals), "avg_duration_ms_profiled": sum(durs) / len(durs) / 1e6}
             pmc["dispatch"] = meta
+    extra = {}
+    for sub in ("pmc_sq", "pmc_tcc"):
+        f = one(os.path.join(src, sub, "**", "*_counter_collection.csv"))
+        if not f:
+            continue
+        acc = {}
+        for r in csv.DictReader(open(f)):
+            if r["Kernel_Name"].startswith("lmi::scan_kernel("):
+                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            extra[k] = sum(v) / len(v)
+    if extra:
+        pmc["per_launch_avg"] = extra
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in extra and "GRBM_GUI_ACTIVE" in extra:
+            # 1024 SIMDs; GRBM_GUI_ACTIVE sums the 8 XCDs
+            pmc["mfma_pipe_busy_frac"] = extra["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (extra["GRBM_GUI_ACTIVE"] / 8.0)
+        if "TCC_HIT" in extra and "TCC_MISS" in extra:
+            pmc["l2_hit_rate"] = extra["TCC_HIT"] / (extra["TCC_HIT"] + extra["TCC_MISS"])
     if "FETCH_SIZE" in pmc:
         fetch = pmc["FETCH_SIZE"]["avg_kib"] * 1024.0 * 2.0  # gfx950: half-counted 16-B/lane streams
         write = pmc.get("WRITE_SIZE", {}).get("avg_kib", 0.0) * 1024.0
