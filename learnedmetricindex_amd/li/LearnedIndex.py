@@ -9,6 +9,10 @@ values `(dists f64[nq,k], nns u32[nq,k], measured_time)`.  What changes undernea
   of every call, LearnedIndex.py:350-357);
 * one `lmi_search` call does MLP forward -> top-n_buckets -> routing -> bucket scan -> merge on the
   GPU (LearnedIndex.py:87-146 + 163-214 + 328-373);
+* multi-level indexes (`len(n_categories) > 1`): the priority-queue navigation keeps the
+  reference's host structure (LearnedIndex.py:216-325) with every model evaluated by the HIP MLP
+  kernels (`NeuralNetwork.predict_proba` -> lmi_mlp_proba), then ONE lmi_scan_topk call scans the
+  buckets of all ranks;
 * `data_navigation` is never mutated (the reference adds/drops `category_L*` columns,
   :101-104/:153-157), so passing the same frame for navigation and scan works.
 
@@ -27,9 +31,9 @@ import numpy.typing as npt
 import pandas as pd
 
 from .Logger import Logger
-from .model import NeuralNetwork, linear_layers
-from .PriorityQueue import EMPTY_VALUE
-from .utils import log_runtime
+from .model import NeuralNetwork, data_X_to_torch, linear_layers
+from .PriorityQueue import EMPTY_VALUE, PriorityQueue
+from .utils import filter_path_idxs, log_runtime
 
 try:
     from .. import _capi
@@ -54,17 +58,20 @@ class LearnedIndex(Logger):
         """List of paths to the buckets."""
         self._engine = None
         self._engine_key = None
+        self._path_ids = None
 
     def __getstate__(self):  # picklable like the reference object (search.py:234-241)
         state = dict(self.__dict__)
         state["_engine"] = None
         state["_engine_key"] = None
+        state["_path_ids"] = None
         return state
 
     def __setstate__(self, state):
         self.__dict__.update(state)
         self.__dict__.setdefault("_engine", None)
         self.__dict__.setdefault("_engine_key", None)
+        self.__dict__.setdefault("_path_ids", None)
 
     # ------------------------------------------------------------------------------------------
     def close(self) -> None:
@@ -88,14 +95,22 @@ class LearnedIndex(Logger):
         if self._engine is not None and key == self._engine_key:
             return self._engine
         self.close()
-        if len(n_categories) != 1:
-            raise NotImplementedError(
-                "multi-level navigation (len(n_categories) > 1) is not on the MI355X path yet "
-                "(SURVEY.md section 8f, N1)")
-        L = int(n_categories[0])
+        n_levels = len(n_categories)
+        assert dp.shape[1] == n_levels
         eng = _capi.Index(device)
-        eng.set_mlp(linear_layers(self.root_model.model))
-        assert eng.n_classes >= int(dp[:, 0].max(initial=0)) + 1, "data_prediction outside the model's classes"
+        if n_levels == 1:
+            # bucket id == class id: lmi_search can run MLP -> scan without leaving the device
+            eng.set_mlp(linear_layers(self.root_model.model))
+            assert eng.n_classes >= int(dp[:, 0].max(initial=0)) + 1, "data_prediction outside the model's classes"
+            bucket_of = dp[:, 0]
+            n_bucket_ids = max(int(n_categories[0]), eng.n_classes)
+            self._path_ids = None
+        else:
+            # a bucket is a distinct path; ids follow the sorted order pandas groupby yields (:343-350)
+            paths, bucket_of = np.unique(dp, axis=0, return_inverse=True)
+            bucket_of = np.asarray(bucket_of).reshape(-1)
+            n_bucket_ids = paths.shape[0]
+            self._path_ids = {tuple(int(v) for v in p): i for i, p in enumerate(paths)}
         labels = data_navigation.index.to_numpy()
         assert labels.min(initial=0) >= 0 and labels.max(initial=0) < 2 ** 32, "ids must fit uint32"
         cols = _feature_columns(data_search)
@@ -103,7 +118,7 @@ class LearnedIndex(Logger):
             frame = data_search
         else:  # the reference fetches scan rows by label: data_search.loc[g.index] (:357)
             frame = data_search.loc[data_navigation.index]
-        eng.buckets_begin(dp[:, 0], len(cols), max(L, eng.n_classes), ids=labels.astype(np.uint32))
+        eng.buckets_begin(bucket_of, len(cols), n_bucket_ids, ids=labels.astype(np.uint32))
         piece = max(1, (256 << 20) // (4 * max(1, len(cols))))
         for r0 in range(0, frame.shape[0], piece):
             block = frame.iloc[r0: r0 + piece]
@@ -136,13 +151,21 @@ class LearnedIndex(Logger):
         if n_buckets >= 2:
             # LearnedIndex.py:142-146: after the first merge the arrays must be (nq, k)
             assert k <= 2 * _capi.K_PER_BUCKET, "k > 20 cannot be merged from two 10-result ranks"
-        assert n_buckets <= eng.n_classes, "n_buckets exceeds the number of classes"  # :213 would fail to broadcast
+        if len(n_categories) == 1:
+            assert n_buckets <= eng.n_classes, "n_buckets exceeds the number of classes"  # :213 would fail to broadcast
         if nq == 0:
             kout = _capi.Index.kout(n_buckets, k)
             return np.empty((0, kout)), np.empty((0, kout), dtype=np.uint32), measured_time
-        d32, nns, _ = eng.search(qn, qs, n_buckets, k)
-        t = eng.timings() * 1e-3
-        measured_time["inference"] = float(t[_capi.T_INFERENCE])
+        if len(n_categories) == 1:
+            d32, nns, _ = eng.search(qn, qs, n_buckets, k)
+            t = eng.timings() * 1e-3
+            measured_time["inference"] = float(t[_capi.T_INFERENCE])
+        else:
+            bucket_order, measured_time["inference"] = self._precompute_bucket_order(
+                queries_navigation=qn, n_buckets=n_buckets, n_categories=n_categories)
+            ids = self._bucket_ids(bucket_order)
+            d32, nns = eng.scan_topk(qs, ids, k)
+            t = eng.timings() * 1e-3
         measured_time["search_within_buckets"] = float(t[_capi.T_ROUTE] + t[_capi.T_SCAN] + t[_capi.T_MERGE])
         measured_time["seq_search"] = float(t[_capi.T_SCAN])
         measured_time["sort"] = float(t[_capi.T_MERGE])
@@ -152,18 +175,79 @@ class LearnedIndex(Logger):
         return dists, nns, measured_time
 
     # ------------------------------------------------------------------------------------------
+    def _bucket_ids(self, bucket_order: npt.NDArray[np.int32]) -> npt.NDArray[np.int32]:
+        """paths [nq, nb, n_levels] -> slab bucket ids [nq, nb]; a path that holds no object -> -1
+        (the reference's groupby never yields it, so the slot stays unvisited)."""
+        nq, nb, _ = bucket_order.shape
+        flat = bucket_order.reshape(nq * nb, -1)
+        uniq, inv = np.unique(flat, axis=0, return_inverse=True)
+        ids = np.array([self._path_ids.get(tuple(int(v) for v in p), -1) for p in uniq], dtype=np.int32)
+        return ids[np.asarray(inv).reshape(-1)].reshape(nq, nb)
+
     @log_runtime(INFO, "Precomputed bucket order time: {}")
     def _precompute_bucket_order(self, queries_navigation: npt.NDArray[np.float32], n_buckets: int,
                                  n_categories: List[int]) -> Tuple[npt.NDArray[np.int32], float]:
-        """(bucket_order int32[nq, n_buckets, n_levels], inference seconds) -- 1-level branch of
-        LearnedIndex.py:163-214, computed by lmi_mlp_topk."""
+        """(bucket_order int32[nq, n_buckets, n_levels], inference seconds) -- LearnedIndex.py:163-252.
+
+        1 level: lmi_mlp_topk.  More levels: the reference's batched priority-queue walk; every
+        `predict_proba` is the HIP MLP (probabilities from the canonical softmax, so priorities
+        compare exactly like the oracle's)."""
         assert self.root_model is not None, "Model is not trained, call `build` first."
-        if len(n_categories) != 1:
-            raise NotImplementedError("multi-level navigation: SURVEY.md section 8f, N1")
-        eng = self.root_model.engine()
         qn = np.ascontiguousarray(queries_navigation, dtype=np.float32)
-        order = eng.mlp_topk(qn, n_buckets)
-        t = float(eng.timings()[_capi.T_INFERENCE]) * 1e-3
-        bucket_order = np.full((qn.shape[0], n_buckets, 1), EMPTY_VALUE, dtype=np.int32)
-        bucket_order[:, :, 0] = order
-        return bucket_order, t
+        n_queries, n_levels = qn.shape[0], len(n_categories)
+        if n_levels == 1:
+            eng = self.root_model.engine()
+            order = eng.mlp_topk(qn, n_buckets)
+            t = float(eng.timings()[_capi.T_INFERENCE]) * 1e-3
+            bucket_order = np.full((n_queries, n_buckets, 1), EMPTY_VALUE, dtype=np.int32)
+            bucket_order[:, :, 0] = order
+            return bucket_order, t
+
+        total_inference_t = 0.0
+        s = time.time()
+        pred_l1_prob, pred_l1_paths = self.root_model.predict_proba(data_X_to_torch(qn))
+        total_inference_t += time.time() - s
+        pq = PriorityQueue(n_queries, int(np.prod(n_categories)), n_levels)
+        # root children pushed least probable first: the tail is the most probable (:220-227)
+        for l1_idx in reversed(range(n_categories[0])):
+            l1_paths = np.full((n_queries, n_levels), EMPTY_VALUE, dtype=np.int32)
+            l1_paths[:, 0] = pred_l1_paths[:, l1_idx]
+            pq.add(np.arange(n_queries), l1_paths, pred_l1_prob[:, l1_idx])
+        bucket_order = np.full((n_queries, n_buckets, n_levels), EMPTY_VALUE, dtype=np.int32)
+        bucket_order_length = np.zeros(n_queries, dtype=np.int32)
+        while not np.all(bucket_order_length == n_buckets):
+            query_idxs = np.where(bucket_order_length < n_buckets)[0]
+            path_to_visit = pq.pop(query_idxs)
+            total_inference_t += self._visit_internal_nodes(qn, query_idxs, pq, path_to_visit, n_levels)
+            self._visit_buckets(query_idxs, path_to_visit, bucket_order, bucket_order_length)
+            pq.sort()
+        return bucket_order, total_inference_t
+
+    def _visit_internal_nodes(self, queries_navigation, all_query_idxs, pq: PriorityQueue, path_to_visit,
+                              n_levels: int) -> float:
+        """Expands the popped internal nodes: every child enters the queue with its LOCAL softmax
+        probability (LearnedIndex.py:254-301).  Returns the inference seconds."""
+        inference_t = 0.0
+        for path, model in self.internal_models.items():
+            query_idxs = all_query_idxs[filter_path_idxs(path_to_visit, path)]
+            if query_idxs.shape[0] == 0:
+                continue
+            s = time.time()
+            probabilities, categories = model.predict_proba(data_X_to_torch(queries_navigation[query_idxs]))
+            inference_t += time.time() - s
+            level = len(path) - list(path).count(EMPTY_VALUE)
+            for child_idx in range(categories.shape[1]):
+                child_paths = np.full((query_idxs.shape[0], n_levels), EMPTY_VALUE, dtype=np.int32)
+                child_paths[:] = np.array(path)
+                child_paths[:, level] = categories[:, child_idx]
+                pq.add(query_idxs, child_paths, probabilities[:, child_idx])
+        return inference_t
+
+    def _visit_buckets(self, all_query_idxs, path_to_visit, bucket_order, bucket_order_length) -> None:
+        """Records the popped bucket paths in visiting order (LearnedIndex.py:303-325)."""
+        for path in self.bucket_paths:
+            query_idxs = all_query_idxs[filter_path_idxs(path_to_visit, path)]
+            if query_idxs.shape[0] == 0:
+                continue
+            bucket_order[query_idxs, bucket_order_length[query_idxs], :] = np.array(path)
+            bucket_order_length[query_idxs] += 1

@@ -134,3 +134,44 @@ def test_bucket_read_roundtrip():
         np.testing.assert_array_equal(rows, X[sel])
         np.testing.assert_array_equal(ids, sel + 1)
     idx.close()
+
+
+def test_two_level_index_G2(oracle):
+    """len(n_categories) > 1 -- priority-queue navigation with the HIP MLP for every node,
+    one scan call for all ranks.  Bucket order and results identical to the oracle's restatement;
+    against the reference fixture modulo near-equal priorities / distances."""
+    from learnedmetricindex_amd.li.LearnedIndex import LearnedIndex
+    from learnedmetricindex_amd.li.model import NeuralNetwork
+    from test_oracle_multilevel import internal_of
+
+    g = load_golden("G2")
+    Xn, Qn, Xs, Qs = inputs_for("G2", g)
+    ncat = [int(v) for v in g["n_categories"]]
+    nb, k = int(g["n_buckets"]), int(g["k"])
+
+    def net_from(layers):
+        net = NeuralNetwork(input_dim=layers[0][0].shape[1], output_dim=layers[-1][0].shape[0], model_type="MLP")
+        lin = [m for m in net.model.layers if isinstance(m, torch.nn.Linear)]
+        with torch.no_grad():
+            for m, (W, b) in zip(lin, layers):
+                m.weight.copy_(torch.from_numpy(W))
+                m.bias.copy_(torch.from_numpy(b))
+        return net
+
+    internal = internal_of(g)
+    bucket_paths = [tuple(int(v) for v in p) for p in g["bucket_paths"]]
+    li = LearnedIndex(net_from(layers_from(g)), {p: net_from(l) for p, l in internal}, bucket_paths)
+    dp = g["data_prediction"].astype(np.int64)
+    nav, srch = frame(Xn), frame(Xs)
+    dists, nns, mt = li.search(nav, Qn, srch, Qs, dp, ncat, nb, k)
+    bo, _ = li._precompute_bucket_order(Qn, nb, ncat)
+    bo_o = oracle.precompute_bucket_order_multilevel(layers_from(g), internal, bucket_paths, Qn, nb, ncat)
+    np.testing.assert_array_equal(bo, bo_o)
+    do, no, _ = oracle.search(layers_from(g), Qn, Xs, Qs, dp, nb, k, bucket_order=bo_o)
+    np.testing.assert_array_equal(nns, no)
+    np.testing.assert_array_equal(dists, do)
+    same = (bo == g["ref_bucket_order"]).all(axis=(1, 2))
+    assert same.mean() > 0.99
+    compare_modulo_near_ties(g["ref_dists"][same], g["ref_nns"][same], dists[same], nns[same])
+    assert mt["inference"] > 0 and mt["seq_search"] > 0
+    li.close()

@@ -1,0 +1,104 @@
+"""GPU (`-m gpu`): size-independent properties at a size the oracle cannot check exhaustively
+(1M x 768, 120 buckets, 2 000 queries): sortedness, exact re-computation of sampled distances with
+the canonical chain, invariance to the chunking / work distribution, idempotence, and agreement of
+the all-buckets search with an independently built single-bucket (brute-force) index."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+N, D, L, NQ, NB = 1_000_000, 768, 120, 2000, 4
+
+
+@pytest.fixture(scope="module")
+def world():
+    from learnedmetricindex_amd import _capi
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(99)
+    centres = torch.randn(L, D, generator=g, device=dev)
+    a = torch.randint(0, L, (N,), generator=g, device=dev)
+    X = torch.nn.functional.normalize(centres[a] + torch.randn(N, D, generator=g, device=dev), dim=1).contiguous()
+    Q = torch.nn.functional.normalize(centres[torch.randint(0, L, (NQ,), generator=g, device=dev)]
+                                      + torch.randn(NQ, D, generator=g, device=dev), dim=1).contiguous()
+    # uneven buckets incl. an empty and a tiny one; routing = nearest centres (no MLP needed here)
+    labels = a.clone()
+    labels[labels == 7] = 8
+    tiny = torch.nonzero(labels == 9).flatten()
+    labels[tiny[5:]] = 10
+    order = (Q @ centres.T).topk(NB, dim=1).indices.to(torch.int32).contiguous()
+    return dict(capi=_capi, dev=dev, X=X, Q=Q, labels=labels.cpu().numpy().astype(np.int64), order=order)
+
+
+def build(world, chunk_rows, L_=L, labels=None):
+    idx = world["capi"].Index(0, chunk_rows=chunk_rows)
+    idx.set_stream(torch.cuda.current_stream().cuda_stream)
+    lab = world["labels"] if labels is None else labels
+    idx.buckets_begin(lab, D, L_)
+    step = 1 << 18
+    for r0 in range(0, N, step):
+        idx.add_rows(world["X"][r0: r0 + step], r0)
+    idx.buckets_end()
+    return idx
+
+
+def scan(world, idx, order, k=10):
+    nq, nb = order.shape
+    kout = idx.kout(nb, k)
+    d = torch.empty((nq, kout), dtype=torch.float32, device=world["dev"])
+    i = torch.empty((nq, kout), dtype=torch.int32, device=world["dev"])
+    idx.scan_topk_device(world["Q"][:nq], order, nb, k, d, i)
+    torch.cuda.synchronize()
+    return d.cpu().numpy(), i.cpu().numpy().view(np.uint32)
+
+
+def test_properties_at_scale(world, oracle):
+    idx = build(world, 2048)
+    d, i = scan(world, idx, world["order"])
+    # sorted ascending, finite where the visited buckets hold >= 10 objects
+    assert np.all(np.diff(d, axis=1) >= 0)
+    sizes = idx.bucket_sizes()
+    assert sizes[7] == 0 and sizes[9] == 5
+    # ids live in a visited bucket; sampled distances equal 1 - canonical chain bit for bit
+    order = world["order"].cpu().numpy()
+    Xh = world["X"][:1].cpu()  # noqa: F841  (keep torch initialised)
+    rs = np.random.RandomState(0)
+    for q in rs.choice(NQ, 40, replace=False):
+        for j in (0, 9):
+            if not np.isfinite(d[q, j]) or d[q, j] > 1e30:
+                continue
+            row = int(i[q, j]) - 1
+            assert world["labels"][row] in order[q]
+            sim = oracle.dot(world["Q"][q].cpu().numpy(), world["X"][row].cpu().numpy())
+            assert np.float32(1) - sim == d[q, j]
+    # idempotent
+    d2, i2 = scan(world, idx, world["order"])
+    assert np.array_equal(d, d2) and np.array_equal(i, i2)
+    # invariant to chunking (different work items, different partial lists, same answer)
+    for cr in (256, 8192):
+        other = build(world, cr)
+        d3, i3 = scan(world, other, world["order"])
+        assert np.array_equal(i, i3) and np.array_equal(d, d3)
+        other.close()
+    idx.close()
+
+
+def test_all_buckets_equals_bruteforce(world):
+    """Visiting every bucket must give the exact k-NN: compare with an independent index that
+    holds all objects in ONE bucket (a different slab order, different tiles, different merges)."""
+    nq = 256
+    idx = build(world, 2048)
+    full = torch.arange(L, dtype=torch.int32, device=world["dev"]).repeat(nq, 1).contiguous()
+    d, i = scan(world, idx, full)
+    one = build(world, 4096, L_=1, labels=np.zeros(N, dtype=np.int64))
+    d1, i1 = scan(world, one, torch.zeros((nq, 1), dtype=torch.int32, device=world["dev"]))
+    assert np.array_equal(d, d1)
+    # ties between different buckets are ordered by bucket rank in the reference's merge and by row
+    # in a single bucket; compare ids where distances are strictly increasing around the position
+    strict = np.ones_like(d, dtype=bool)
+    strict[:, 1:] &= d[:, 1:] > d[:, :-1]
+    strict[:, :-1] &= d[:, :-1] < d[:, 1:]
+    assert np.array_equal(i[strict], i1[strict]) and strict.mean() > 0.99
+    idx.close()
+    one.close()
