@@ -127,6 +127,14 @@ class LearnedIndex(Logger):
         self._engine, self._engine_key = eng, key
         return eng
 
+    def search_resident(self, queries_navigation, queries_search, n_categories: List[int], n_buckets: int = 1,
+                        k: int = 10):
+        """`search` against the index already resident in HBM (after `prepare`, a previous `search`
+        or `index_io.load_index`): no DataFrames needed.  Same return values as `search`."""
+        assert self._engine is not None, "no resident index: call prepare()/search() or index_io.load_index()"
+        return self._search_with(self._engine, queries_navigation, queries_search, n_categories, n_buckets, k,
+                                 time.time())
+
     # ------------------------------------------------------------------------------------------
     def search(
         self,
@@ -141,9 +149,12 @@ class LearnedIndex(Logger):
     ) -> Tuple[npt.NDArray, npt.NDArray[np.uint32], Dict[str, float]]:
         """Searches for `k` nearest neighbors of every query in its `n_buckets` most probable buckets.
         Parameters and return values as the reference (LearnedIndex.py:41-83)."""
-        measured_time = defaultdict(float)
         s = time.time()
         eng = self.prepare(data_navigation, data_search, data_prediction, n_categories)
+        return self._search_with(eng, queries_navigation, queries_search, n_categories, n_buckets, k, s)
+
+    def _search_with(self, eng, queries_navigation, queries_search, n_categories, n_buckets, k, s):
+        measured_time = defaultdict(float)
         qn = np.ascontiguousarray(queries_navigation, dtype=np.float32)
         qs = qn if queries_search is queries_navigation else np.ascontiguousarray(queries_search, dtype=np.float32)
         assert qn.shape[0] == qs.shape[0]

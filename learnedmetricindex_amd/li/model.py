@@ -112,6 +112,24 @@ def linear_layers(module) -> List[Tuple[np.ndarray, np.ndarray]]:
     return out
 
 
+def network_from_layers(layers, lr: float = 0.1) -> "NeuralNetwork":
+    """A NeuralNetwork holding the given [(W [out,in], b [out])] stack: the matching `MLP*` variant
+    when the hidden widths are one of the reference's, otherwise a custom Linear/ReLU Sequential."""
+    dims = [layers[0][0].shape[1]] + [W.shape[0] for W, _ in layers]
+    hidden = tuple(dims[1:-1])
+    name = next((k for k, v in _HIDDEN.items() if v == hidden), None)
+    net = NeuralNetwork(input_dim=dims[0], output_dim=dims[-1], lr=lr, model_type=name or "MLP")
+    if name is None:
+        net.model.layers = _stack(hidden)(dims[0], dims[-1]).to(net.device)
+        net.optimizer = torch.optim.Adam(net.model.parameters(), lr=lr)
+    lin = [m for m in net.model.layers if isinstance(m, nn.Linear)]
+    with torch.no_grad():
+        for m, (W, b) in zip(lin, layers):
+            m.weight.copy_(torch.from_numpy(np.ascontiguousarray(W, dtype=np.float32)))
+            m.bias.copy_(torch.from_numpy(np.ascontiguousarray(b, dtype=np.float32)))
+    return net
+
+
 class NeuralNetwork(Logger):
     """One node's classifier (model.py:130-241).  Constructor arguments as in the reference."""
 
