@@ -52,6 +52,8 @@ SIGNATURES = {
     "lmi_timings": (ctypes.c_int, [_vp, _vp]),
     "lmi_scan_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double), _i64p, _i64p]),
     "lmi_set_chunk_rows": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "lmi_set_prefilter": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "lmi_prefilter_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), _i64p, _i64p]),
 }
 
 
@@ -101,7 +103,7 @@ def _np(a, dtype) -> np.ndarray:
 class Index:
     """One device-resident index: thin, typed wrapper over an `lmi_index*`."""
 
-    def __init__(self, device: int = 0, chunk_rows: Optional[int] = None):
+    def __init__(self, device: int = 0, chunk_rows: Optional[int] = None, prefilter: Optional[bool] = None):
         self._h = _vp()
         _check(lib().lmi_create(int(device), ctypes.byref(self._h)))
         self.device = int(device)
@@ -111,6 +113,10 @@ class Index:
         self.L = None
         if chunk_rows is not None:
             _check(lib().lmi_set_chunk_rows(self._h, int(chunk_rows)))
+        if prefilter is None and os.environ.get("LMI_PREFILTER") is not None:
+            prefilter = os.environ["LMI_PREFILTER"] not in ("0", "off", "false")
+        if prefilter is not None:
+            self.set_prefilter(prefilter)
 
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h:
@@ -122,6 +128,18 @@ class Index:
             self.close()
         except Exception:  # noqa: BLE001
             pass
+
+    def set_prefilter(self, on: bool) -> None:
+        """fp16 prefilter + exact re-rank (default) or f32 MFMA for every similarity; same results."""
+        _check(lib().lmi_set_prefilter(self._h, 1 if on else 0))
+
+    def prefilter_stats(self):
+        """(active, survivors re-scored exactly, slots that fell back to exact brute force)."""
+        a = ctypes.c_int(0)
+        sv = ctypes.c_int64(0)
+        fb = ctypes.c_int64(0)
+        _check(lib().lmi_prefilter_stats(self._h, ctypes.byref(a), ctypes.byref(sv), ctypes.byref(fb)))
+        return bool(a.value), sv.value, fb.value
 
     def set_stream(self, stream_ptr: int) -> None:
         _check(lib().lmi_set_stream(self._h, _vp(stream_ptr)))

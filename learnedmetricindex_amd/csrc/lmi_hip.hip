@@ -2,6 +2,7 @@
 // Owns the device-resident index (fragment-major slab, ids, CSR of buckets), the packed MLP
 // weights and the per-call workspaces; enqueues the kernels of lmi_kernels.h on one HIP stream.
 #include "lmi_kernels.h"
+#include "lmi_prefilter.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -94,6 +95,12 @@ struct lmi_index {
     DevBuf slab, ids_slab, pos, d_nb_rows, d_rb_start, d_nch;
     int64_t rows_added = 0;
     DevBuf stage;  // H2D staging for add_rows / host query uploads
+    // ---- fp16 prefilter (lmi_prefilter.h) ----
+    bool prefilter = true;   // lmi_set_prefilter
+    bool have16 = false;     // slab16 built by lmi_buckets_end
+    int KG16 = 0;
+    DevBuf slab16, xscale, xmaxbits, bnorm;
+    DevBuf qnorm, qmaxbits, qscale, qfrag16, eps2, cand_cnt, cand_row, cand_s, fallback;
 
     // ---- per-call workspaces ----
     DevBuf act[2], xfrag, logits, order, q_nav, q_srch;
@@ -101,7 +108,7 @@ struct lmi_index {
     DevBuf part_score, part_row, rank_d, rank_id, out_d, out_id, out_key;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_valid[6] = {false, false, false, false, false, false};
-    long long h_stats[2] = {0, 0};
+    long long h_stats[4] = {0, 0, 0, 0};
     bool stats_pending = false;
 };
 
@@ -143,7 +150,7 @@ extern "C" LMI_API int lmi_destroy(lmi_index* h) {
     DevBuf* bufs[] = {&h->slab, &h->ids_slab, &h->pos, &h->d_nb_rows, &h->d_rb_start, &h->d_nch, &h->stage,
                       &h->act[0], &h->act[1], &h->xfrag, &h->logits, &h->order, &h->q_nav, &h->q_srch, &h->m,
                       &h->cb_start, &h->item_base, &h->part_base, &h->stats, &h->head, &h->slot_local,
-                      &h->slot_col, &h->colmap, &h->qfrag, &h->grp, &h->col_thr, &h->part_score, &h->part_row, &h->rank_d,
+                      &h->slot_col, &h->colmap, &h->qfrag, &h->grp, &h->col_thr, &h->slab16, &h->xscale, &h->xmaxbits, &h->bnorm, &h->qnorm, &h->qmaxbits, &h->qscale, &h->qfrag16, &h->eps2, &h->cand_cnt, &h->cand_row, &h->cand_s, &h->fallback, &h->part_score, &h->part_row, &h->rank_d,
                       &h->rank_id, &h->out_d, &h->out_id, &h->out_key};
     for (DevBuf* b : bufs) b->release();
     for (int i = 0; i < 6; ++i)
@@ -160,9 +167,16 @@ extern "C" LMI_API int lmi_set_stream(lmi_index* h, void* s) {
 
 extern "C" LMI_API int lmi_set_chunk_rows(lmi_index* h, int rows) {
     if (!h) return fail("lmi_set_chunk_rows: NULL handle");
-    if (rows < TILE_ROWS || rows % TILE_ROWS) return fail("lmi_set_chunk_rows: rows must be a positive multiple of %d", TILE_ROWS);
+    if (rows < PF_TILE_ROWS || rows % PF_TILE_ROWS) return fail("lmi_set_chunk_rows: rows must be a positive multiple of %d", PF_TILE_ROWS);
     if (h->building || h->built) return fail("lmi_set_chunk_rows: must be called before lmi_buckets_begin");
     h->chunk_rows = rows;
+    return 0;
+}
+
+extern "C" LMI_API int lmi_set_prefilter(lmi_index* h, int on) {
+    if (!h) return fail("lmi_set_prefilter: NULL handle");
+    if (on && h->built && !h->have16) return fail("lmi_set_prefilter: the fp16 slab was not built (enable before lmi_buckets_end)");
+    h->prefilter = on != 0;
     return 0;
 }
 
@@ -294,6 +308,33 @@ extern "C" LMI_API int lmi_buckets_end(lmi_index* h) {
     CHK(set_dev(h));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->pos.release();
+    h->have16 = false;
+    if (h->prefilter && h->n_rb_total > 0) {
+        // fp16 copy of the slab for the prefilter: one power-of-two scale for the whole index
+        h->KG16 = (int)rup(cdiv(h->d, 16), PF_STAGE_G);
+        const long long n4 = (long long)h->n_rb_total * h->KGs * 64;
+        CHK(h->xmaxbits.reserve(16));
+        CHK(h->xscale.reserve(16));
+        CHK(h->bnorm.reserve((size_t)h->L * 4));
+        CHK(h->slab16.reserve((size_t)h->n_rb_total * h->KG16 * 1024));
+        HIPCHK(hipMemsetAsync(h->xmaxbits.p, 0, 16, h->stream));
+        HIPCHK(hipMemsetAsync(h->bnorm.p, 0, (size_t)h->L * 4, h->stream));
+        absmax_kernel<<<h->num_cus * 8, 256, 0, h->stream>>>(h->slab.as<float4>(), n4, h->xmaxbits.as<unsigned>());
+        HIPCHK(hipGetLastError());
+        make_scale_kernel<<<1, 1, 0, h->stream>>>(h->xmaxbits.as<unsigned>(), h->xscale.as<float>());
+        HIPCHK(hipGetLastError());
+        const long long total = (long long)h->n_rb_total * h->KG16 * 64;
+        convert16_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(h->slab.as<float4>(), h->KGs, h->n_rb_total, h->KG16,
+                                                                 h->xscale.as<float>(), h->slab16.as<uint4>());
+        HIPCHK(hipGetLastError());
+        dim3 g(64, h->L);
+        bucket_norm_kernel<<<g, 256, 0, h->stream>>>(h->slab.as<float4>(), h->KGs, h->d_rb_start.as<int>(),
+                                                    h->d_nb_rows.as<int>(), h->L, h->xscale.as<float>(),
+                                                    h->bnorm.as<unsigned>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->have16 = true;
+    }
     h->building = false;
     h->built = true;
     return 0;
@@ -459,9 +500,9 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     CHK(h->cb_start.reserve((L + 1) * 4));
     CHK(h->item_base.reserve((L + 1) * 4));
     CHK(h->part_base.reserve((L + 1) * 8));
-    CHK(h->stats.reserve(16));
+    CHK(h->stats.reserve(32));
     CHK(h->head.reserve(64));
-    const size_t grp_ints = (size_t)NGRP * L + (size_t)NGRP * (L + 1) + 2 * NGRP + L;
+    const size_t grp_ints = (size_t)NGRP * L + (size_t)NGRP * (L + 1) + 2 * NGRP + L + (L + 1);
     CHK(h->grp.reserve(grp_ints * 4));
     CHK(h->slot_local.reserve((size_t)nslots * 4));
     CHK(h->slot_col.reserve((size_t)nslots * 4));
@@ -486,6 +527,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     R.grp_n = R.grp_base + (size_t)NGRP * (L + 1);
     R.grp_total = R.grp_n + NGRP;
     R.order_tmp = R.grp_total + NGRP;
+    R.qt_base = R.order_tmp + L;
 
     HIPCHK(hipMemsetAsync(h->m.p, 0, L * 4, h->stream));
     HIPCHK(hipMemsetAsync(h->head.p, 0, 64, h->stream));
@@ -501,13 +543,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     route_fill_kernel<<<cdiv(nslots, 256), 256, 0, h->stream>>>(d_order, h->slot_local.as<int>(), nslots, nb,
                                                                R.cb_start, h->colmap.as<int>(), h->slot_col.as<int>());
     HIPCHK(hipGetLastError());
-    {
-        long long total = ncb_bound * 32 * h->KGs;
-        pack_gather_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(d_qs, h->d, h->colmap.as<int>(), nq, ncb_bound * 32,
-                                                                   h->KGs, h->qfrag.as<float4>());
-        HIPCHK(hipGetLastError());
-    }
-    CHK(record(h, 2));
+    const bool fast = h->prefilter && h->have16;
     ScanParams S;
     S.slab = h->slab.as<float4>();
     S.qfrag = h->qfrag.as<float4>();
@@ -528,9 +564,98 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     S.col_thr = h->col_thr.as<float>();
     S.part_score = h->part_score.as<float>();
     S.part_row = h->part_row.as<unsigned>();
-    scan_kernel<<<h->num_cus * h->scan_blocks_per_cu, 256, SCAN_LDS, h->stream>>>(S);
-    HIPCHK(hipGetLastError());
-    CHK(record(h, 3));
+    if (!fast) {
+        long long total = ncb_bound * 32 * h->KGs;
+        pack_gather_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(d_qs, h->d, h->colmap.as<int>(), nq, ncb_bound * 32,
+                                                                   h->KGs, h->qfrag.as<float4>());
+        HIPCHK(hipGetLastError());
+        CHK(record(h, 2));
+        scan_kernel<<<h->num_cus * h->scan_blocks_per_cu, 256, SCAN_LDS, h->stream>>>(S);
+        HIPCHK(hipGetLastError());
+        CHK(record(h, 3));
+    } else {
+        // fp16 prefilter + exact re-rank (lmi_prefilter.h)
+        const size_t ncols = (size_t)ncb_bound * 32;
+        CHK(h->qnorm.reserve((size_t)nq * 4));
+        CHK(h->qmaxbits.reserve(16));
+        CHK(h->qscale.reserve(16));
+        CHK(h->qfrag16.reserve((size_t)ncb_bound * h->KG16 * 1024));
+        CHK(h->eps2.reserve(ncols * 4));
+        CHK(h->cand_cnt.reserve(ncols * 4));
+        CHK(h->cand_row.reserve(ncols * PF_CAP * 4));
+        CHK(h->cand_s.reserve(ncols * PF_CAP * 4));
+        CHK(h->fallback.reserve((size_t)nslots * 4));
+        HIPCHK(hipMemsetAsync(h->qmaxbits.p, 0, 16, h->stream));
+        HIPCHK(hipMemsetAsync(h->cand_cnt.p, 0, ncols * 4, h->stream));
+        HIPCHK(hipMemsetAsync(h->stats.as<long long>() + 2, 0, 16, h->stream));
+        query_norm_kernel<<<cdiv(nq, 64), 64, 0, h->stream>>>(d_qs, nq, h->d, h->qnorm.as<float>(), h->qmaxbits.as<unsigned>());
+        HIPCHK(hipGetLastError());
+        make_scale_kernel<<<1, 1, 0, h->stream>>>(h->qmaxbits.as<unsigned>(), h->qscale.as<float>());
+        HIPCHK(hipGetLastError());
+        {
+            long long total = (long long)ncols * h->KG16 * 2;
+            pack_queries16_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(d_qs, h->d, h->colmap.as<int>(), (long long)ncols,
+                                                                          h->KG16, h->qscale.as<float>(), h->qfrag16.as<uint4>());
+            HIPCHK(hipGetLastError());
+        }
+        slot_bound_kernel<<<cdiv(nslots, 256), 256, 0, h->stream>>>(d_order, h->slot_col.as<int>(), nslots, nb, h->KG16 * 16,
+                                                                   h->qnorm.as<float>(), h->qscale.as<float>(),
+                                                                   h->bnorm.as<unsigned>(), h->eps2.as<float>());
+        HIPCHK(hipGetLastError());
+        CHK(record(h, 2));
+        PrefilterParams F;
+        F.slab16 = h->slab16.as<uint4>();
+        F.qfrag16 = h->qfrag16.as<uint4>();
+        F.KG16 = h->KG16;
+        F.L = L;
+        F.chunk_rb = S.chunk_rb;
+        F.rb_start = S.rb_start;
+        F.nb_rows = R.nb_rows;
+        F.nch = R.nch;
+        F.m = R.m;
+        F.cb_start = R.cb_start;
+        F.grp_bucket = R.grp_bucket;
+        F.grp_base = R.grp_base;
+        F.grp_n = R.grp_n;
+        F.grp_total = R.grp_total;
+        F.qt_base = R.qt_base;
+        F.head = S.head;
+        F.bound = S.col_thr;
+        F.eps2 = h->eps2.as<float>();
+        F.cand_cnt = h->cand_cnt.as<unsigned>();
+        F.cand_row = h->cand_row.as<unsigned>();
+        F.cand_s = h->cand_s.as<float>();
+        prefilter_kernel<true><<<h->num_cus * 2, 256, 0, h->stream>>>(F);   // pass 1: bounds from a sample
+        HIPCHK(hipGetLastError());
+        prefilter_kernel<false><<<h->num_cus * 2, 256, 0, h->stream>>>(F);  // pass 2: candidates
+        HIPCHK(hipGetLastError());
+        RescoreParams Q;
+        Q.bucket_order = d_order;
+        Q.slot_col = h->slot_col.as<int>();
+        Q.nslots = nslots;
+        Q.nb = nb;
+        Q.d = h->d;
+        Q.KG = h->KGs;
+        Q.raw = raw;
+        Q.rb_start = S.rb_start;
+        Q.nb_rows = R.nb_rows;
+        Q.cand_cnt = F.cand_cnt;
+        Q.cand_row = F.cand_row;
+        Q.cand_s = F.cand_s;
+        Q.eps2 = F.eps2;
+        Q.slab = S.slab;
+        Q.q = d_qs;
+        Q.ids_slab = h->ids_slab.as<unsigned>();
+        Q.rank_d = h->rank_d.as<float>();
+        Q.rank_id = h->rank_id.as<unsigned>();
+        Q.fallback = h->fallback.as<int>();
+        Q.stats = R.stats;
+        select_rescore_kernel<<<nslots, 64, 0, h->stream>>>(Q);
+        HIPCHK(hipGetLastError());
+        fallback_kernel<<<nslots, 256, 0, h->stream>>>(Q);
+        HIPCHK(hipGetLastError());
+        CHK(record(h, 3));
+    }
     MergeParams M;
     M.bucket_order = d_order;
     M.slot_col = h->slot_col.as<int>();
@@ -539,6 +664,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     M.L = L;
     M.kout = kout;
     M.raw = raw;
+    M.skip_a = fast ? 1 : 0;
     M.rb_start = S.rb_start;
     M.nb_rows = R.nb_rows;
     M.nch = R.nch;
@@ -739,12 +865,26 @@ extern "C" LMI_API int lmi_timings(lmi_index* h, float* ms) {
     return 0;
 }
 
+extern "C" LMI_API int lmi_prefilter_stats(lmi_index* h, int* active, int64_t* survivors, int64_t* fallbacks) {
+    if (!h) return fail("lmi_prefilter_stats: NULL handle");
+    CHK(set_dev(h));
+    if (h->stats_pending) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(h->h_stats, h->stats.p, 32, hipMemcpyDeviceToHost));
+        h->stats_pending = false;
+    }
+    if (active) *active = (h->prefilter && h->have16) ? 1 : 0;
+    if (survivors) *survivors = h->h_stats[2];
+    if (fallbacks) *fallbacks = h->h_stats[3];
+    return 0;
+}
+
 extern "C" LMI_API int lmi_scan_stats(lmi_index* h, double* flops, int64_t* pairs, int64_t* items) {
     if (!h) return fail("lmi_scan_stats: NULL handle");
     CHK(set_dev(h));
     if (h->stats_pending) {
         HIPCHK(hipStreamSynchronize(h->stream));
-        HIPCHK(hipMemcpy(h->h_stats, h->stats.p, 16, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(h->h_stats, h->stats.p, 32, hipMemcpyDeviceToHost));
         h->stats_pending = false;
     }
     if (pairs) *pairs = h->h_stats[0];

@@ -259,6 +259,7 @@ struct RouteArrays {
     int* grp_n;           // [NGRP]      buckets in the group
     int* grp_total;       // [NGRP]      items in the group
     int* order_tmp;       // [L] scratch: buckets sorted by work
+    int* qt_base;         // [L+1] prefix of the buckets' query-tile counts (prefilter pass-1 items)
 };
 
 __global__ void route_count_kernel(const int* __restrict__ bucket_order, int nslots, int L, RouteArrays R,
@@ -330,6 +331,11 @@ __global__ __launch_bounds__(1024) void route_group_kernel(int L, RouteArrays R)
             rank += (wo > wb) || (wo == wb && o < b);
         }
         R.order_tmp[rank] = b;
+    }
+    if (t == 1) {  // query-tile prefix in bucket order (one thread; L is small)
+        int q = 0;
+        for (int b = 0; b < L; ++b) { R.qt_base[b] = q; q += (R.m[b] + TILE_COLS - 1) / TILE_COLS; }
+        R.qt_base[L] = q;
     }
     __syncthreads();
     if (t == 0) {
@@ -990,6 +996,7 @@ struct MergeParams {
     const int* bucket_order;  // [nq][nb]
     const int* slot_col;      // [nq][nb]
     int nq, nb, L, kout, raw;
+    int skip_a;  // rank lists were already written (prefilter path): phase B only
     const int* rb_start;
     const int* nb_rows;
     const int* nch;
@@ -1012,7 +1019,7 @@ __global__ __launch_bounds__(64) void merge_kernel(MergeParams P) {
     unsigned* ri = P.rank_id + (size_t)q * P.nb * KPB;
     const float FMAXV = 3.402823466e+38f;
     // ---------------- phase A ----------------
-    for (int r = 0; r < P.nb; ++r) {
+    for (int r = 0; r < (P.skip_a ? 0 : P.nb); ++r) {
         const int p = q * P.nb + r;
         const int b = P.bucket_order[p];
         const int col = P.slot_col[p];

@@ -1,0 +1,663 @@
+// lmi_prefilter.h -- fp16-MFMA prefilter + exact fp32 re-rank for the bucket scan (gfx950).
+//
+// Why: the exact scan is bound by the f32 MFMA rate (157 TFLOP/s); v_mfma_f32_32x32x16_f16 runs 16x
+// faster.  The prefilter computes APPROXIMATE similarities with fp16 operands (f32 accumulate),
+// keeps every row that could still be among a (query, bucket)'s 10 best given a PROVEN error bound,
+// and the survivors (typically 10-20 per slot) are re-scored with the canonical k-ordered binary32
+// fmaf chain -- so ids and distances are bit-identical to the exact path (tests assert equality of
+// the two modes and of both with the oracle).  Slots whose candidate sets overflow fall back to an
+// exact brute-force kernel; nothing is ever approximate in the output.
+//
+// Scaled units.  Index vectors are stored as x' = sx * x in fp16 (sx = one power of two per index
+// with max|x'| in [0.5, 1)), queries as q' = sq * q (one power of two per batch); shat = sum q^_k x^_k
+// approximates s' = sx*sq*s.  With u = 2^-11 (fp16 unit roundoff), sub = 2^-25 (half the fp16
+// subnormal spacing), N = ||q'||*||x'||:
+//   |q^_k - q'_k| <= u|q'_k| + sub (same for x), fp16 x fp16 products are exact in binary32, and any
+//   binary32 summation of d terms errs by at most d*2^-24 * sum|terms| (first order), so
+//   |shat - s'_canonical| <= eps' := (2u + u^2 + 2.5*d*2^-24) * N + 1.001*sub*sqrt(d)*(||q'||+||x'||) + d*sub^2
+//   (the 2.5*d*2^-24 covers the MFMA's accumulation AND the canonical chain's own rounding).
+// Candidate rule.  Let That be the 10th largest shat of the bucket.  The 10 rows with shat >= That have
+// s'_c >= That - eps', hence the canonical 10th best T_c >= That - eps', hence every row of the
+// canonical top-10 has shat >= T_c - eps' >= That - 2 eps'.  Any lower bound of That may replace it:
+// the 10th best shat of any SUBSET of the bucket's rows is (pass 1 uses every 16th 256-row tile).
+#pragma once
+#include "lmi_kernels.h"
+
+namespace lmi {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+constexpr int PF_RB = 2;            // row-blocks per wave: block tile = 4 waves x 2 x 32 = 256 vectors
+constexpr int PF_TILE_ROWS = 256;
+constexpr int PF_STAGE_G = 2;       // k16-groups per stage -> BK = 32
+constexpr int PF_CAP = 1024;        // candidate slots per (query, rank); overflow -> exact fallback
+constexpr int PF_KEEP = 64;         // survivors re-scored per slot; more -> exact fallback
+
+// ---- ingest: global max |x| of the f32 slab (bits of a non-negative float order like ints) -------
+__global__ void absmax_kernel(const float4* __restrict__ slab, long long n4, unsigned* __restrict__ out) {
+    float m = 0.0f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 v = slab[i];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+// scale[0] <- power of two s with max*s in [0.5, 1) (1 if max == 0); scale[1] <- 1/s
+__global__ void make_scale_kernel(const unsigned* __restrict__ maxbits, float* __restrict__ scale) {
+    const float m = __uint_as_float(*maxbits);
+    int e = 0;
+    float s = 1.0f;
+    if (m > 0.0f && m < INFINITY) { (void)frexpf(m, &e); s = ldexpf(1.0f, -e); }
+    scale[0] = s;
+    scale[1] = 1.0f / s;
+}
+
+// f32 fragment-major -> fp16 fragment-major (x scale).  One thread per (row, k16-group, half).
+//   f32: F[rb][k/8][(k&1)*32 + r].comp((k&7)>>1);  f16: H[rb][k/16][((k>>3)&1)*32 + r][k&7]
+__global__ void convert16_kernel(const float4* __restrict__ src, int KG, long long n_rb, int KG16,
+                                 const float* __restrict__ scale, uint4* __restrict__ dst) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = n_rb * KG16 * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63), r = lane & 31, hh = lane >> 5;
+    const int g = (int)((idx >> 6) % KG16);
+    const long long rb = (idx >> 6) / KG16;
+    const int g8 = 2 * g + hh;  // f32 k-group holding k = 16g + 8hh .. +7
+    float4 e = make_float4(0.f, 0.f, 0.f, 0.f), o = e;
+    if (g8 < KG) {
+        const float4* f = src + ((size_t)rb * KG + g8) * 64 + r;
+        e = f[0];   // k even: +0,+2,+4,+6
+        o = f[32];  // k odd : +1,+3,+5,+7
+    }
+    const float s = scale[0];
+    half8 h;
+    h[0] = (_Float16)(e.x * s); h[1] = (_Float16)(o.x * s); h[2] = (_Float16)(e.y * s); h[3] = (_Float16)(o.y * s);
+    h[4] = (_Float16)(e.z * s); h[5] = (_Float16)(o.z * s); h[6] = (_Float16)(e.w * s); h[7] = (_Float16)(o.w * s);
+    dst[idx] = *reinterpret_cast<uint4*>(&h);
+}
+
+// per-bucket max of the scaled row norm, rounded up (bits of non-negative floats order like ints)
+__global__ void bucket_norm_kernel(const float4* __restrict__ slab, int KG, const int* __restrict__ rb_start,
+                                   const int* __restrict__ nb_rows, int L, const float* __restrict__ scale,
+                                   unsigned* __restrict__ bnorm_bits) {
+    const int b = blockIdx.y;
+    const int n_b = nb_rows[b];
+    const float s = scale[0];
+    float best = 0.0f;
+    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < n_b; row += gridDim.x * blockDim.x) {
+        const float4* f = slab + ((size_t)(rb_start[b] + (row >> 5)) * KG) * 64 + (row & 31);
+        float acc = 0.0f;
+        for (int g = 0; g < KG; ++g) {
+            const float4 e = f[(size_t)g * 64], o = f[(size_t)g * 64 + 32];
+            acc += e.x * e.x + e.y * e.y + e.z * e.z + e.w * e.w + o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
+        }
+        best = fmaxf(best, sqrtf(acc) * s * 1.0002f);  // 1.0002: covers the binary32 error of the sum
+    }
+    if (best > 0.0f) atomicMax(bnorm_bits + b, __float_as_uint(best));
+}
+
+// ---- per batch: query scale, norms, fp16 packing, per-slot bound ---------------------------------
+__global__ void query_norm_kernel(const float* __restrict__ q, int nq, int d, float* __restrict__ qnorm,
+                                  unsigned* __restrict__ maxbits) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float m = 0.0f;
+    if (i < nq) {
+        float acc = 0.0f;
+        for (int k = 0; k < d; ++k) { const float v = q[(size_t)i * d + k]; acc += v * v; m = fmaxf(m, fabsf(v)); }
+        qnorm[i] = sqrtf(acc) * 1.0002f;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(maxbits, __float_as_uint(m));
+}
+
+// colmap gather of row-major queries -> fp16 fragments (x qscale); one thread per (col, k16-group, half)
+__global__ void pack_queries16_kernel(const float* __restrict__ q, int d, const int* __restrict__ colmap,
+                                      long long ncols, int KG16, const float* __restrict__ qscale,
+                                      uint4* __restrict__ dst) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= ncols * KG16 * 2) return;
+    const int hh = (int)(idx & 1);
+    const int g = (int)((idx >> 1) % KG16);
+    const long long col = (idx >> 1) / KG16;
+    const int qi = colmap[col];
+    const float s = qscale[0];
+    half8 h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 16 * g + 8 * hh + j;
+        h[j] = (_Float16)((qi >= 0 && k < d) ? q[(size_t)qi * d + k] * s : 0.0f);
+    }
+    dst[((size_t)(col >> 5) * KG16 + g) * 64 + hh * 32 + (col & 31)] = *reinterpret_cast<uint4*>(&h);
+}
+
+// eps2[col] = 2*eps' of the slot occupying column `col` (header); -1 for idle columns
+__global__ void slot_bound_kernel(const int* __restrict__ bucket_order, const int* __restrict__ slot_col, int nslots,
+                                  int nb, int dpad, const float* __restrict__ qnorm, const float* __restrict__ qscale,
+                                  const unsigned* __restrict__ bnorm_bits, float* __restrict__ eps2) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nslots) return;
+    const int col = slot_col[p];
+    if (col < 0) return;
+    const float qn = qnorm[p / nb] * qscale[0];
+    const float xn = __uint_as_float(bnorm_bits[bucket_order[p]]);
+    const float u = 4.8828125e-4f, sub = 2.98023224e-8f;  // 2^-11, 2^-25
+    const float rel = 2.0f * u + u * u + 2.5f * (float)dpad * 5.96046448e-8f;
+    const float e = rel * qn * xn + 1.001f * sub * sqrtf((float)dpad) * (qn + xn) + (float)dpad * sub * sub;
+    eps2[col] = 2.0f * e * 1.001f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Prefilter kernels: fp16 operands, 256 x 128 block tile (wave = 64 vectors x 128 queries, 8
+// accumulator tiles), A straight to VGPRs, B through two 8-KiB LDS buffers, one barrier per
+// 32-wide k-stage.  Two passes over the same code (template SAMPLE):
+//   pass 1 (SAMPLE):  one item per (bucket, query tile) scans every PF_SAMPLE-th 256-row tile of the
+//                     whole bucket with per-lane VALUES-ONLY top-10 lists, merges the 8 lists of a
+//                     column and stores bound[col] = the sample's 10th-best shat (a lower bound of
+//                     the bucket's 10th best That; -inf if the sample holds < 10 rows);
+//   pass 2 (!SAMPLE): items (bucket, query tile, chunk) from the XCD-affine queues; no lists, no
+//                     inter-item traffic: every row with shat >= bound[col] - 2 eps' is appended to
+//                     the slot's candidate buffer.  About 10 * PF_SAMPLE rows per slot pass.
+// ------------------------------------------------------------------------------------------------
+constexpr int PF_SAMPLE = 16;
+
+struct PrefilterParams {
+    const uint4* slab16;
+    const uint4* qfrag16;
+    int KG16;  // k16-groups per row-block (multiple of PF_STAGE_G)
+    int L;
+    int chunk_rb;
+    const int* rb_start;
+    const int* nb_rows;
+    const int* nch;
+    const int* m;
+    const int* cb_start;
+    const int* qt_base;   // [L+1] prefix of the buckets' query-tile counts (pass-1 items)
+    const int* grp_bucket;
+    const int* grp_base;
+    const int* grp_n;
+    const int* grp_total;
+    unsigned* head;       // [NGRP] pass-2 queue heads; [NGRP] = pass-1 head
+    float* bound;         // [columns] pass 1 -> pass 2
+    const float* eps2;    // 2 eps' per column
+    unsigned* cand_cnt;   // [columns]
+    unsigned* cand_row;   // [columns][PF_CAP]
+    float* cand_s;        // [columns][PF_CAP]
+};
+
+__device__ __forceinline__ void vlist_insert(float (&v)[KPB], float s) {  // values-only sorted insert
+#pragma unroll
+    for (int t = KPB - 1; t > 0; --t) v[t] = (s > v[t - 1]) ? v[t - 1] : ((s > v[t]) ? s : v[t]);
+    v[0] = (s > v[0]) ? s : v[0];
+}
+
+template <int NCB, bool SAMPLE>
+struct PreItem {
+    static constexpr int NLIST = SAMPLE ? NCB : 1;
+    const PrefilterParams& P;
+    uint4* sB0;
+    uint4* sB1;  // two distinct __shared__ arrays [4 col-blocks][PF_STAGE_G][64] uint4 = 8 KiB each
+    int lane, w, h, c;
+    float lv[NLIST][KPB];   // pass 1 only
+    float thr[NCB];         // pass 2: bound - 2 eps' of this lane's column in col-block n
+    f32x16 acc[PF_RB][NCB];
+
+    template <int PAR>
+    __device__ __forceinline__ void compute(const uint4 (&a)[PF_RB][PF_STAGE_G]) {
+        const uint4* sB = (PAR ? sB1 : sB0) + lane;
+#pragma unroll
+        for (int g = 0; g < PF_STAGE_G; ++g) {
+            half8 bq[NCB];
+#pragma unroll
+            for (int n = 0; n < NCB; ++n) {
+                const uint4 t = sB[(n * PF_STAGE_G + g) * 64];
+                bq[n] = *reinterpret_cast<const half8*>(&t);
+            }
+#pragma unroll
+            for (int j = 0; j < PF_RB; ++j) {
+                const half8 av = *reinterpret_cast<const half8*>(&a[j][g]);
+#pragma unroll
+                for (int n = 0; n < NCB; ++n)
+                    acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bq[n], acc[j][n], 0, 0, 0);
+            }
+        }
+    }
+
+    __device__ __forceinline__ void epilogue(int rb_tile0, int n_b, size_t col0, int m_left) {
+#pragma unroll
+        for (int j = 0; j < PF_RB; ++j) {
+            const unsigned rowbase = (unsigned)((rb_tile0 + w * PF_RB + j) * 32);
+#pragma unroll
+            for (int n = 0; n < NCB; ++n) {
+                const float t = SAMPLE ? lv[SAMPLE ? n : 0][KPB - 1] : thr[n];
+                unsigned mask = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool pass = SAMPLE ? (acc[j][n][r] > t) : (acc[j][n][r] >= t);
+                    mask |= (unsigned)(pass && rowbase + acc_row(r, h) < (unsigned)n_b) << r;
+                }
+                while (mask) {
+                    const int r = __builtin_ctz(mask);
+                    mask &= mask - 1;
+                    float s = acc[j][n][0];
+#pragma unroll
+                    for (int i = 1; i < 16; ++i) s = (r == i) ? acc[j][n][i] : s;
+                    if (SAMPLE) {
+                        if (s > lv[SAMPLE ? n : 0][KPB - 1]) vlist_insert(lv[SAMPLE ? n : 0], s);
+                    } else if (n * 32 + c < m_left) {
+                        const size_t col = col0 + n * 32 + c;
+                        const unsigned pos = atomicAdd(P.cand_cnt + col, 1u);
+                        if (pos < (unsigned)PF_CAP) {
+                            P.cand_row[col * PF_CAP + pos] = rowbase + acc_row(r, h);
+                            P.cand_s[col * PF_CAP + pos] = s;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.0f;
+            }
+        }
+    }
+
+    // SAMPLE: ch is ignored, the item covers tiles 0, PF_SAMPLE, 2*PF_SAMPLE, ... of the whole bucket
+    __device__ __forceinline__ void run(int b, int qt, int ch) {
+        const int tid = threadIdx.x;
+        lane = tid & 63; w = tid >> 6; h = lane >> 5; c = lane & 31;
+        const int KG = P.KG16, NS = KG / PF_STAGE_G;
+        const int n_b = P.nb_rows[b];
+        const int nrb_b = (n_b + 31) >> 5;
+        const int rb_in_b0 = SAMPLE ? 0 : ch * P.chunk_rb;
+        const int nrb = SAMPLE ? nrb_b : min(P.chunk_rb, nrb_b - rb_in_b0);
+        const int nvt_all = (nrb + 4 * PF_RB - 1) / (4 * PF_RB);
+        const int TSTEP = SAMPLE ? PF_SAMPLE : 1;                 // tile stride
+        const int nvt = (nvt_all + TSTEP - 1) / TSTEP;            // tiles this item processes
+        const int cb0 = P.cb_start[b] + qt * 4;
+        const int m_left = P.m[b] - qt * TILE_COLS;
+        const size_t col0 = (size_t)cb0 * 32;
+        const uint4* aslab = P.slab16 + ((size_t)P.rb_start[b] * KG) * 64 + lane;
+        const uint4* bbase = P.qfrag16 + ((size_t)(cb0 + min(w, NCB - 1)) * KG) * 64 + lane;
+        const size_t rb_stride = (size_t)KG * 64;
+        const int rb_last = nrb_b - 1;
+#pragma unroll
+        for (int n = 0; n < NCB; ++n) {
+            if (SAMPLE) {
+#pragma unroll
+                for (int j = 0; j < KPB; ++j) lv[SAMPLE ? n : 0][j] = -INFINITY;
+            } else {
+                thr[n] = P.bound[col0 + n * 32 + c] - P.eps2[col0 + n * 32 + c];
+            }
+#pragma unroll
+            for (int j = 0; j < PF_RB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.0f;
+        }
+        // running pointers of the NEXT stage to load (cf. ScanItemR): A rows of this wave, B of wave w
+        int vt_n = 0, t_n = 0, vt_c = 0, t_c = 0;  // vt_* count processed tiles; tile index = vt * TSTEP
+        const uint4* ap0 = aslab + (size_t)min(rb_in_b0 + w * PF_RB + 0, rb_last) * rb_stride;
+        const uint4* ap1 = aslab + (size_t)min(rb_in_b0 + w * PF_RB + 1, rb_last) * rb_stride;
+        const uint4* qp = bbase;
+        uint4 x[PF_RB][PF_STAGE_G], y[PF_RB][PF_STAGE_G], z[PF_STAGE_G];
+#define PF_LOAD(A)                                                                                \
+    {                                                                                             \
+        _Pragma("unroll") for (int g = 0; g < PF_STAGE_G; ++g) {                                  \
+            A[0][g] = ap0[g * 64]; A[1][g] = ap1[g * 64]; z[g] = qp[g * 64];                      \
+        }                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        if (t_n + 1 < NS) { ++t_n; ap0 += PF_STAGE_G * 64; ap1 += PF_STAGE_G * 64; qp += PF_STAGE_G * 64; } \
+        else if (vt_n + 1 < nvt) {                                                                \
+            ++vt_n; t_n = 0; qp = bbase;                                                          \
+            ap0 = aslab + (size_t)min(rb_in_b0 + (vt_n * TSTEP * 4 + w) * PF_RB + 0, rb_last) * rb_stride; \
+            ap1 = aslab + (size_t)min(rb_in_b0 + (vt_n * TSTEP * 4 + w) * PF_RB + 1, rb_last) * rb_stride; \
+        }                                                                                         \
+    }
+#define PF_STORE_B(SB)                                                                            \
+    if (w < NCB) {                                                                                \
+        _Pragma("unroll") for (int g = 0; g < PF_STAGE_G; ++g) (SB)[(w * PF_STAGE_G + g) * 64 + lane] = z[g]; \
+    }
+#define PF_FINISH_STAGE                                                                           \
+    if (++t_c == NS) {                                                                            \
+        epilogue(rb_in_b0 + vt_c * TSTEP * 4 * PF_RB, n_b, col0, m_left);                         \
+        t_c = 0; ++vt_c;                                                                          \
+    }
+        const int total = nvt * NS;
+        PF_LOAD(x)
+        PF_STORE_B(sB0)
+        __syncthreads();
+        for (int u = 0; u < total; u += 2) {
+            PF_LOAD(y)
+            compute<0>(x);
+            PF_FINISH_STAGE
+            PF_STORE_B(sB1)
+            __syncthreads();
+            if (u + 1 >= total) break;
+            PF_LOAD(x)
+            compute<1>(y);
+            PF_FINISH_STAGE
+            PF_STORE_B(sB0)
+            __syncthreads();
+        }
+#undef PF_LOAD
+#undef PF_STORE_B
+#undef PF_FINISH_STAGE
+        if (!SAMPLE) return;
+        // ---- pass 1: bound[col] = 10th best of the sample; the 8 (wave, half) value lists of a
+        //      column are merged in two rounds of 4 lists (5 KiB in sB0) + a carried list (sB1) ----
+        float* buf = reinterpret_cast<float*>(sB0);    // [32 cols][4 lists][KPB]
+        float* carry = reinterpret_cast<float*>(sB1);  // [32 cols][KPB], touched by its own thread only
+#pragma unroll
+        for (int n = 0; n < NCB; ++n) {
+#pragma unroll
+            for (int round = 0; round < 2; ++round) {
+                __syncthreads();
+                if ((w >> 1) == round) {
+                    const int o = (c * 4 + ((w & 1) * 2 + h)) * KPB;
+#pragma unroll
+                    for (int j = 0; j < KPB; ++j) buf[o + j] = lv[SAMPLE ? n : 0][j];
+                }
+                __syncthreads();
+                if (tid < 32) {
+                    float best[KPB];
+                    unsigned heads = 0;
+                    int hc = (round == 0) ? KPB : 0;  // the carried list is empty in round 0
+                    const int o = tid * 4 * KPB;
+#pragma unroll
+                    for (int j = 0; j < KPB; ++j) {
+                        float bs = -INFINITY;
+                        int bsrc = -1;
+#pragma unroll
+                        for (int src = 0; src < 4; ++src) {
+                            const int hd = (heads >> (4 * src)) & 15;
+                            if (hd < KPB) {
+                                const float s = buf[o + src * KPB + hd];
+                                if (s > bs) { bs = s; bsrc = src; }
+                            }
+                        }
+                        if (hc < KPB) {
+                            const float s = carry[tid * KPB + hc];
+                            if (s > bs) { bs = s; bsrc = 4; }
+                        }
+                        if (bsrc == 4) ++hc;
+                        else if (bsrc >= 0) heads += 1u << (4 * bsrc);
+                        best[j] = bs;
+                    }
+#pragma unroll
+                    for (int j = 0; j < KPB; ++j) carry[tid * KPB + j] = best[j];
+                    // the sample holds 10 rows with shat >= best[9]: a lower bound of the bucket's That
+                    if (round == 1) P.bound[col0 + n * 32 + tid] = best[KPB - 1];
+                }
+            }
+        }
+        __syncthreads();
+    }
+};
+
+template <bool SAMPLE>
+__global__ __launch_bounds__(256, 2) void prefilter_kernel(PrefilterParams P) {
+    __shared__ __attribute__((aligned(16))) uint4 sB0[4 * PF_STAGE_G * 64];
+    __shared__ __attribute__((aligned(16))) uint4 sB1[4 * PF_STAGE_G * 64];
+    int* s_item = reinterpret_cast<int*>(sB1);
+    int grp = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & (NGRP - 1));
+    for (;;) {
+        if (threadIdx.x == 0) {
+            int b = -1, local = 0;
+            if (SAMPLE) {  // one plain queue of (bucket, query tile) items
+                const int tot = P.qt_base[P.L];
+                const int it = (int)atomicAdd(&P.head[NGRP], 1u);
+                if (it < tot) {
+                    int lo = 0, hi = P.L;
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (P.qt_base[mid] <= it) lo = mid; else hi = mid;
+                    }
+                    b = lo;
+                    local = it - P.qt_base[lo];
+                }
+            } else {
+                for (int tries = 0; tries < NGRP; ++tries) {
+                    const int tot = P.grp_total[grp];
+                    if (__hip_atomic_load(&P.head[grp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)tot) {
+                        const int it = (int)atomicAdd(&P.head[grp], 1u);
+                        if (it < tot) {
+                            const int* base = P.grp_base + grp * (P.L + 1);
+                            int lo = 0, hi = P.grp_n[grp];
+                            while (hi - lo > 1) {
+                                const int mid = (lo + hi) >> 1;
+                                if (base[mid] <= it) lo = mid; else hi = mid;
+                            }
+                            b = P.grp_bucket[grp * P.L + lo];
+                            local = it - base[lo];
+                            break;
+                        }
+                    }
+                    grp = (grp + 1) & (NGRP - 1);
+                }
+            }
+            s_item[0] = b;
+            s_item[1] = local;
+        }
+        __syncthreads();
+        const int b = s_item[0], local = s_item[1];
+        __syncthreads();
+        if (b < 0) return;
+        const int m_b = P.m[b];
+        const int nqt = (m_b + TILE_COLS - 1) / TILE_COLS;
+        const int qt = SAMPLE ? local : local % nqt, ch = SAMPLE ? 0 : local / nqt;
+        const int ncb = min(4, (m_b - qt * TILE_COLS + 31) >> 5);
+        switch (ncb) {
+            case 1: { PreItem<1, SAMPLE> it{P, sB0, sB1}; it.run(b, qt, ch); break; }
+            case 2: { PreItem<2, SAMPLE> it{P, sB0, sB1}; it.run(b, qt, ch); break; }
+            case 3: { PreItem<3, SAMPLE> it{P, sB0, sB1}; it.run(b, qt, ch); break; }
+            default: { PreItem<4, SAMPLE> it{P, sB0, sB1}; it.run(b, qt, ch); break; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Select + exact re-rank: one wave per (query, rank) slot.
+//   That = 10th largest shat of the slot's candidates (every row of the shat-top-10 was emitted);
+//   survivors = candidates with shat >= That - 2 eps' (a superset of the canonical top-10, header);
+//   each survivor is re-scored by one lane with the canonical chain acc = fmaf(q[k], x[k], acc)
+//   on the f32 slab; the 10 best by (score desc, row asc) become the slot's rank list, in the same
+//   form merge_kernel's phase A writes (dist = 1 - s, ids, faiss padding for short buckets).
+// Candidate overflow (> PF_CAP emitted or > PF_KEEP survivors) sets fallback[p] instead.
+// ------------------------------------------------------------------------------------------------
+struct RescoreParams {
+    const int* bucket_order;
+    const int* slot_col;
+    int nslots, nb, d, KG, raw;
+    const int* rb_start;
+    const int* nb_rows;
+    const unsigned* cand_cnt;
+    const unsigned* cand_row;
+    const float* cand_s;
+    const float* eps2;
+    const float4* slab;
+    const float* q;  // row-major [nq][d]
+    const unsigned* ids_slab;
+    float* rank_d;
+    unsigned* rank_id;
+    int* fallback;
+    long long* stats;  // [2] += survivors, [3] += fallback slots
+};
+
+// canonical similarity of in-bucket row `row` of the bucket starting at row-block rb0 with query qv[0..d)
+__device__ __forceinline__ float exact_score(const float4* __restrict__ slab, int KG, int rb0, unsigned row,
+                                             const float* __restrict__ qv, int d) {
+    const float4* f = slab + ((size_t)(rb0 + (int)(row >> 5)) * KG) * 64 + (row & 31);
+    float acc = 0.0f;
+    const int ng = d >> 3;
+    for (int g = 0; g < ng; ++g) {
+        const float4 e = f[(size_t)g * 64], o = f[(size_t)g * 64 + 32];
+        const float* qq = qv + 8 * g;
+        acc = __builtin_fmaf(qq[0], e.x, acc); acc = __builtin_fmaf(qq[1], o.x, acc);
+        acc = __builtin_fmaf(qq[2], e.y, acc); acc = __builtin_fmaf(qq[3], o.y, acc);
+        acc = __builtin_fmaf(qq[4], e.z, acc); acc = __builtin_fmaf(qq[5], o.z, acc);
+        acc = __builtin_fmaf(qq[6], e.w, acc); acc = __builtin_fmaf(qq[7], o.w, acc);
+    }
+    if (d & 7) {
+        const float4 e = f[(size_t)ng * 64], o = f[(size_t)ng * 64 + 32];
+        const float xv[8] = {e.x, o.x, e.y, o.y, e.z, o.z, e.w, o.w};
+        for (int j = 0; j < (d & 7); ++j) acc = __builtin_fmaf(qv[8 * ng + j], xv[j], acc);
+    }
+    return acc;
+}
+
+// lanes 0..9 hold the sorted (score, row) results; writes the slot's rank list (merge phase A form)
+__device__ __forceinline__ void write_rank_list(int lane, float my_s, unsigned my_r, int n_b, int rb0, int raw,
+                                                const unsigned* __restrict__ ids_slab, float* rd, unsigned* ri) {
+    const float FMAXV = 3.402823466e+38f;
+    if (lane < KPB) {
+        const bool real = my_r != NOROW && lane < n_b;
+        float dv;
+        unsigned iv;
+        if (raw) { dv = real ? my_s : -FMAXV; iv = real ? my_r : NOROW; }
+        else if (real) { dv = 1.0f - my_s; iv = ids_slab[(size_t)rb0 * 32 + my_r]; }
+        else { dv = 1.0f - (-FMAXV); iv = ids_slab[(size_t)rb0 * 32 + (n_b - 1)]; }  // faiss padding (Q4)
+        rd[lane] = dv;
+        ri[lane] = iv;
+    }
+}
+
+__global__ __launch_bounds__(64) void select_rescore_kernel(RescoreParams P) {
+    __shared__ unsigned keep_row[PF_KEEP];
+    __shared__ unsigned keep_n;
+    const int p = blockIdx.x, lane = threadIdx.x;
+    if (p >= P.nslots) return;
+    float* rd = P.rank_d + (size_t)p * KPB;
+    unsigned* ri = P.rank_id + (size_t)p * KPB;
+    const int col = P.slot_col[p];
+    const float FMAXV = 3.402823466e+38f;
+    if (lane == 0) P.fallback[p] = 0;
+    if (col < 0) {  // unvisited (LearnedIndex.py:340-341)
+        if (lane < KPB) { rd[lane] = P.raw ? -FMAXV : INFINITY; ri[lane] = P.raw ? NOROW : 0u; }
+        return;
+    }
+    const unsigned cnt = P.cand_cnt[col];
+    if (cnt > (unsigned)PF_CAP) {
+        if (lane == 0) { P.fallback[p] = 1; atomicAdd((unsigned long long*)&P.stats[3], 1ull); }
+        return;
+    }
+    const float* cs = P.cand_s + (size_t)col * PF_CAP;
+    const unsigned* cr = P.cand_row + (size_t)col * PF_CAP;
+    // That: 10 selection passes in (value desc, position asc) order
+    float pv = INFINITY;
+    int pi = -1;
+    for (int t = 0; t < KPB; ++t) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int e = lane; e < (int)cnt; e += 64) {
+            const float v = cs[e];
+            const bool after = (v < pv) || (v == pv && e > pi);
+            if (after && (v > bv || (v == bv && e < bi))) { bv = v; bi = e; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        pv = bv;  // -inf once the candidates are exhausted (fewer than 10): everything survives
+        pi = bi;
+    }
+    const float cut = pv - P.eps2[col];
+    if (lane == 0) keep_n = 0;
+    __syncthreads();
+    for (int e = lane; e < (int)cnt; e += 64) {
+        if (cs[e] >= cut) {
+            const unsigned k = atomicAdd(&keep_n, 1u);
+            if (k < (unsigned)PF_KEEP) keep_row[k] = cr[e];
+        }
+    }
+    __syncthreads();
+    const unsigned nk = keep_n;
+    if (nk > (unsigned)PF_KEEP) {
+        if (lane == 0) { P.fallback[p] = 1; atomicAdd((unsigned long long*)&P.stats[3], 1ull); }
+        return;
+    }
+    if (lane == 0) atomicAdd((unsigned long long*)&P.stats[2], (unsigned long long)nk);
+    const int b = P.bucket_order[p];
+    const int rb0 = P.rb_start[b], n_b = P.nb_rows[b];
+    float s = -INFINITY;
+    unsigned row = NOROW;
+    if (lane < (int)nk) {
+        row = keep_row[lane];
+        s = exact_score(P.slab, P.KG, rb0, row, P.q + (size_t)(p / P.nb) * P.d, P.d);
+    }
+    // 10 best by (score desc, row asc)
+    float my_s = -INFINITY;
+    unsigned my_r = NOROW;
+    for (int j = 0; j < KPB; ++j) {
+        float bs = s;
+        unsigned br = row;
+        int wl = lane;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float os = __shfl_xor(bs, o);
+            const unsigned orr = __shfl_xor(br, o);
+            const int ol = __shfl_xor(wl, o);
+            if (better(os, orr, bs, br) || (os == bs && orr == br && ol < wl)) { bs = os; br = orr; wl = ol; }
+        }
+        if (lane == j) { my_s = bs; my_r = br; }
+        if (lane == wl) { s = -INFINITY; row = NOROW; }
+    }
+    write_rank_list(lane, my_s, my_r, n_b, rb0, P.raw, P.ids_slab, rd, ri);
+}
+
+// Exact fallback for overflowed slots: one block per slot, brute force over the whole bucket with the
+// canonical chain on the VALU (slow, rare, always correct).
+__global__ __launch_bounds__(256) void fallback_kernel(RescoreParams P) {
+    __shared__ float fs[256 * KPB];
+    __shared__ unsigned fr[256 * KPB];
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    if (p >= P.nslots || !P.fallback[p]) return;
+    const int b = P.bucket_order[p];
+    const int rb0 = P.rb_start[b], n_b = P.nb_rows[b];
+    const float* qv = P.q + (size_t)(p / P.nb) * P.d;
+    float v[KPB];
+    unsigned id[KPB];
+#pragma unroll
+    for (int j = 0; j < KPB; ++j) { v[j] = -INFINITY; id[j] = NOROW; }
+    for (unsigned row = tid; row < (unsigned)n_b; row += 256) {
+        const float s = exact_score(P.slab, P.KG, rb0, row, qv, P.d);
+        if (s > v[KPB - 1]) list_insert(v, id, s, row);  // rows ascend per thread: strict > keeps the earlier
+    }
+#pragma unroll
+    for (int j = 0; j < KPB; ++j) { fs[tid * KPB + j] = v[j]; fr[tid * KPB + j] = id[j]; }
+    __syncthreads();
+    if (tid >= 64) return;
+    // wave 0: lane owns lists lane, lane+64, lane+128, lane+192 (heads 4 bits each)
+    unsigned heads = 0;
+    float my_s = -INFINITY;
+    unsigned my_r = NOROW;
+    for (int j = 0; j < KPB; ++j) {
+        float bs = -INFINITY;
+        unsigned br = NOROW;
+        int bl = -1;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int hd = (heads >> (4 * t)) & 15;
+            if (hd < KPB) {
+                const float s = fs[(lane + 64 * t) * KPB + hd];
+                const unsigned r = fr[(lane + 64 * t) * KPB + hd];
+                if (better(s, r, bs, br)) { bs = s; br = r; bl = t; }
+            }
+        }
+        int wl = lane;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float os = __shfl_xor(bs, o);
+            const unsigned orr = __shfl_xor(br, o);
+            const int ol = __shfl_xor(wl, o);
+            if (better(os, orr, bs, br) || (os == bs && orr == br && ol < wl)) { bs = os; br = orr; wl = ol; }
+        }
+        if (wl == lane && bl >= 0) heads += 1u << (4 * bl);
+        if (lane == j) { my_s = bs; my_r = br; }
+    }
+    write_rank_list(lane, my_s, my_r, n_b, rb0, P.raw, P.ids_slab, P.rank_d + (size_t)p * KPB,
+                    P.rank_id + (size_t)p * KPB);
+}
+
+}  // namespace lmi

@@ -1,0 +1,105 @@
+"""GPU (`-m gpu`): the fp16 prefilter + exact re-rank against the all-f32 scan and the oracle.
+
+The two modes must agree bit for bit on everything -- including inputs built to stress the
+candidate logic: clouds of near-duplicates inside the 2-eps window (forces the exact fallback),
+un-normalised vectors with norms spread over four orders of magnitude, tiny and empty buckets."""
+import numpy as np
+import pytest
+
+from helpers import inputs_for, layers_from, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def both_modes(capi, X, labels, L, Q, order, k=10, chunk_rows=256):
+    out = []
+    for pf in (True, False):
+        idx = capi.Index(0, chunk_rows=chunk_rows, prefilter=pf)
+        idx.set_buckets(X, labels, L)
+        d, i = idx.scan_topk(Q, order, k)
+        active, survivors, fallbacks = idx.prefilter_stats()
+        assert active == pf
+        out.append((d, i, survivors, fallbacks))
+        idx.close()
+    return out
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from learnedmetricindex_amd import _capi
+
+    _capi.lib()
+    return _capi
+
+
+@pytest.mark.parametrize("name", ["G3", "G4", "G5"])
+def test_modes_agree_on_fixtures(capi, oracle, name):
+    g = load_golden(name)
+    Xn, Qn, Xs, Qs = inputs_for(name, g)
+    layers = layers_from(g)
+    dp = g["data_prediction"]
+    L = layers[-1][0].shape[0]
+    nb = int(g["n_buckets"])
+    order = oracle.rank_classes(oracle.forward_logits(layers, Qn, nthreads=4), nb)
+    (d1, i1, sv, fb), (d0, i0, _, _) = both_modes(capi, Xs, dp[:, 0], L, Qs, order, chunk_rows=2048)
+    np.testing.assert_array_equal(i1, i0)
+    np.testing.assert_array_equal(d1, d0)
+    # other chunking: different items, same answers
+    (d2, i2, _, fb2), _ = both_modes(capi, Xs, dp[:, 0], L, Qs, order, chunk_rows=256)
+    np.testing.assert_array_equal(i2, i0)
+    np.testing.assert_array_equal(d2, d0)
+    do, io, _ = oracle.search(layers, Qn, Xs, Qs, dp, nb, 10, nthreads=4)
+    np.testing.assert_array_equal(i1, io)
+    np.testing.assert_array_equal(d1.astype(np.float64), do)
+    assert fb == 0 and sv >= 10  # ordinary data never needs the fallback
+    slots = order.size
+    assert sv / slots < 40, f"{sv / slots:.1f} survivors per slot: the bound is looser than expected"
+
+
+def test_near_duplicate_cloud_forces_exact_fallback(capi, oracle):
+    """300 vectors within 1e-5 of each other, all near the query: far more than PF_KEEP survivors
+    inside the 2-eps window -> the slot must fall back to the exact kernel and still be right."""
+    rs = np.random.RandomState(4)
+    d = 96
+    base = rs.randn(d).astype(np.float32)
+    base /= np.linalg.norm(base)
+    X = rs.randn(6000, d).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    cloud = base[None, :] + 1e-5 * rs.randn(300, d).astype(np.float32)
+    X[1000:1300] = cloud / np.linalg.norm(cloud, axis=1, keepdims=True)
+    labels = np.zeros(6000, dtype=np.int64)
+    labels[3000:] = 1
+    Q = np.stack([base, -base, X[4000]]).astype(np.float32)
+    order = np.array([[0, 1], [0, 1], [1, 0]], dtype=np.int32)
+    (d1, i1, sv, fb), (d0, i0, _, _) = both_modes(capi, X, labels, 2, Q, order)
+    assert fb >= 1
+    np.testing.assert_array_equal(i1, i0)
+    np.testing.assert_array_equal(d1, d0)
+    D, I = oracle.knn_ip(Q[:1], X[:3000], 10)
+    np.testing.assert_array_equal(i1[0], (I[0] + 1).astype(np.uint32))  # ids are 1-based rows
+
+
+def test_unnormalised_wide_dynamic_range(capi, oracle):
+    """Norms from 1e-2 to 1e2 (search.py:198-210: the scan vectors are not normalised when
+    kind != clip768v2): the fp16 copy uses one scale for the whole index, the bound stays valid."""
+    rs = np.random.RandomState(8)
+    N, d, L = 20000, 45, 6
+    X = rs.randn(N, d).astype(np.float32) * (10.0 ** rs.uniform(-2, 2, size=(N, 1))).astype(np.float32)
+    Q = rs.randn(64, d).astype(np.float32) * (10.0 ** rs.uniform(-1, 1, size=(64, 1))).astype(np.float32)
+    labels = rs.randint(0, L, size=N)
+    labels[labels == 2] = 3                       # an empty bucket
+    labels[np.flatnonzero(labels == 4)[7:]] = 5   # a 7-vector bucket
+    order = np.stack([rs.permutation(L)[:4] for _ in range(64)]).astype(np.int32)
+    (d1, i1, sv, fb), (d0, i0, _, _) = both_modes(capi, X, labels, L, Q, order)
+    np.testing.assert_array_equal(i1, i0)
+    np.testing.assert_array_equal(d1, d0)
+    # spot-check against the oracle's knn for one (query, bucket) with a populated bucket
+    order[0, 0] = 5
+    rows = np.flatnonzero(labels == order[0, 0])
+    D, I = oracle.knn_ip(Q[:1], X[rows], 10)
+    idx = capi.Index(0, chunk_rows=256)
+    idx.set_buckets(X, labels, L)
+    dd, ii = idx.scan_topk(Q[:1], order[:1, :1], 10)
+    np.testing.assert_array_equal(ii[0], (rows[I[0]] + 1).astype(np.uint32))
+    np.testing.assert_array_equal(dd[0], np.float32(1) - D[0])
+    idx.close()
