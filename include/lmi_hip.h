@@ -55,9 +55,12 @@ typedef struct lmi_index lmi_index;
 enum {
     LMI_T_INFERENCE = 0, /* MLP forward + class ranking   -> measured_time["inference"]            */
     LMI_T_ROUTE = 1,     /* routing (CSR of queries per bucket) + query packing                     */
-    LMI_T_SCAN = 2,      /* the bucket-scan kernel alone  -> measured_time["seq_search"]            */
+    LMI_T_SCAN = 2,      /* the bucket scan (exact: scan_kernel; prefilter: slots 5+6+7) -> ["seq_search"] */
     LMI_T_MERGE = 3,     /* chunk/rank merge kernel       -> measured_time["sort"]                  */
     LMI_T_TOTAL = 4,     /* first to last event           -> measured_time["search"]                */
+    LMI_T_PF_SAMPLE = 5, /* prefilter pass 1 (bounds from a sample); 0 in exact mode                */
+    LMI_T_PF_EMIT = 6,   /* prefilter pass 2 (fp16 scan + candidate emission) -- the dominant kernel */
+    LMI_T_RESCORE = 7,   /* select + exact re-rank + exact fallback                                  */
     LMI_T_COUNT = 8
 };
 

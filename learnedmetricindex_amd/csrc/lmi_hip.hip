@@ -100,14 +100,14 @@ struct lmi_index {
     bool have16 = false;     // slab16 built by lmi_buckets_end
     int KG16 = 0;
     DevBuf slab16, xscale, xmaxbits, bnorm;
-    DevBuf qnorm, qmaxbits, qscale, qfrag16, eps2, cand_cnt, cand_row, cand_s, fallback;
+    DevBuf qnorm, qmaxbits, qscale, qfrag16, eps2, cand_cnt, cand_row, cand_s, fallback, pf_bound;
 
     // ---- per-call workspaces ----
     DevBuf act[2], xfrag, logits, order, q_nav, q_srch;
     DevBuf m, cb_start, item_base, part_base, stats, head, slot_local, slot_col, colmap, qfrag, grp, col_thr;
     DevBuf part_score, part_row, rank_d, rank_id, out_d, out_id, out_key;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool ev_valid[6] = {false, false, false, false, false, false};
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid[8] = {false, false, false, false, false, false, false, false};
     long long h_stats[4] = {0, 0, 0, 0};
     bool stats_pending = false;
 };
@@ -136,7 +136,7 @@ extern "C" LMI_API int lmi_create(int device, lmi_index** out) {
     int occ = 0;
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_kernel, 256, SCAN_LDS));
     h->scan_blocks_per_cu = std::max(1, std::min(occ, RB == 1 ? 2 : 1));
-    for (int i = 0; i < 6; ++i) HIPCHK(hipEventCreate(&h->ev[i]));
+    for (int i = 0; i < 8; ++i) HIPCHK(hipEventCreate(&h->ev[i]));
     *out = h;
     return 0;
 }
@@ -150,10 +150,10 @@ extern "C" LMI_API int lmi_destroy(lmi_index* h) {
     DevBuf* bufs[] = {&h->slab, &h->ids_slab, &h->pos, &h->d_nb_rows, &h->d_rb_start, &h->d_nch, &h->stage,
                       &h->act[0], &h->act[1], &h->xfrag, &h->logits, &h->order, &h->q_nav, &h->q_srch, &h->m,
                       &h->cb_start, &h->item_base, &h->part_base, &h->stats, &h->head, &h->slot_local,
-                      &h->slot_col, &h->colmap, &h->qfrag, &h->grp, &h->col_thr, &h->slab16, &h->xscale, &h->xmaxbits, &h->bnorm, &h->qnorm, &h->qmaxbits, &h->qscale, &h->qfrag16, &h->eps2, &h->cand_cnt, &h->cand_row, &h->cand_s, &h->fallback, &h->part_score, &h->part_row, &h->rank_d,
+                      &h->slot_col, &h->colmap, &h->qfrag, &h->grp, &h->col_thr, &h->slab16, &h->xscale, &h->xmaxbits, &h->bnorm, &h->qnorm, &h->qmaxbits, &h->qscale, &h->qfrag16, &h->eps2, &h->cand_cnt, &h->cand_row, &h->cand_s, &h->fallback, &h->pf_bound, &h->part_score, &h->part_row, &h->rank_d,
                       &h->rank_id, &h->out_d, &h->out_id, &h->out_key};
     for (DevBuf* b : bufs) b->release();
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < 8; ++i)
         if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     delete h;
     return 0;
@@ -439,7 +439,7 @@ extern "C" LMI_API int lmi_mlp_topk(lmi_index* h, const float* queries_nav, int 
         d_order = h->order.as<int>();
         if (logits) { CHK(h->logits.reserve((size_t)nq * L * 4)); d_logits = h->logits.as<float>(); }
     }
-    for (int i = 0; i < 6; ++i) h->ev_valid[i] = false;
+    for (int i = 0; i < 8; ++i) h->ev_valid[i] = false;
     CHK(record(h, 0));
     CHK(mlp_enqueue(h, static_cast<const float*>(d_q), nq, nb, d_order, d_logits));
     CHK(record(h, 1));
@@ -469,7 +469,7 @@ extern "C" LMI_API int lmi_mlp_proba(lmi_index* h, const float* queries_nav, int
         d_order = h->order.as<int>();
         d_probs = h->out_d.as<float>();
     }
-    for (int i = 0; i < 6; ++i) h->ev_valid[i] = false;
+    for (int i = 0; i < 8; ++i) h->ev_valid[i] = false;
     CHK(record(h, 0));
     CHK(mlp_enqueue(h, static_cast<const float*>(d_q), nq, L, d_order, nullptr));
     softmax_ranked_kernel<<<cdiv(nq, 64), 64, 0, h->stream>>>(h->logits.as<float>(), d_order, nq, L, d_probs);
@@ -585,6 +585,9 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         CHK(h->cand_row.reserve(ncols * PF_CAP * 4));
         CHK(h->cand_s.reserve(ncols * PF_CAP * 4));
         CHK(h->fallback.reserve((size_t)nslots * 4));
+        CHK(h->pf_bound.reserve(ncols * PF_PARTS * KPB * 4));
+        HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->pf_bound.p), (int)0xFF800000u /* -inf */,
+                                 ncols * PF_PARTS * KPB, h->stream));
         HIPCHK(hipMemsetAsync(h->qmaxbits.p, 0, 16, h->stream));
         HIPCHK(hipMemsetAsync(h->cand_cnt.p, 0, ncols * 4, h->stream));
         HIPCHK(hipMemsetAsync(h->stats.as<long long>() + 2, 0, 16, h->stream));
@@ -620,15 +623,20 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         F.grp_total = R.grp_total;
         F.qt_base = R.qt_base;
         F.head = S.head;
-        F.bound = S.col_thr;
+        F.bound = h->pf_bound.as<float>();
+        F.bound1 = S.col_thr;
         F.eps2 = h->eps2.as<float>();
         F.cand_cnt = h->cand_cnt.as<unsigned>();
         F.cand_row = h->cand_row.as<unsigned>();
         F.cand_s = h->cand_s.as<float>();
         prefilter_kernel<true><<<h->num_cus * 2, 256, 0, h->stream>>>(F);   // pass 1: bounds from a sample
         HIPCHK(hipGetLastError());
+        bound_merge_kernel<<<cdiv((long long)ncols, 256), 256, 0, h->stream>>>(F.bound, (long long)ncols, F.bound1);
+        HIPCHK(hipGetLastError());
+        CHK(record(h, 5));
         prefilter_kernel<false><<<h->num_cus * 2, 256, 0, h->stream>>>(F);  // pass 2: candidates
         HIPCHK(hipGetLastError());
+        CHK(record(h, 6));
         RescoreParams Q;
         Q.bucket_order = d_order;
         Q.slot_col = h->slot_col.as<int>();
@@ -716,7 +724,7 @@ extern "C" LMI_API int lmi_scan_topk(lmi_index* h, const float* queries_search, 
         d_i = h->out_id.as<uint32_t>();
         if (keys) { CHK(h->out_key.reserve((size_t)nq * kout * 4)); d_k = h->out_key.as<uint32_t>(); }
     }
-    for (int i = 0; i < 6; ++i) h->ev_valid[i] = false;
+    for (int i = 0; i < 8; ++i) h->ev_valid[i] = false;
     CHK(record(h, 1));
     CHK(scan_enqueue(h, static_cast<const float*>(d_qs), nq, static_cast<const int*>(d_order), nb, kout, 0, d_d, d_i, d_k));
     if (!on_device) {
@@ -754,7 +762,7 @@ extern "C" LMI_API int lmi_search(lmi_index* h, const float* queries_nav, const 
         d_i = h->out_id.as<uint32_t>();
         if (keys) { CHK(h->out_key.reserve((size_t)nq * kout * 4)); d_k = h->out_key.as<uint32_t>(); }
     }
-    for (int i = 0; i < 6; ++i) h->ev_valid[i] = false;
+    for (int i = 0; i < 8; ++i) h->ev_valid[i] = false;
     CHK(record(h, 0));
     CHK(mlp_enqueue(h, static_cast<const float*>(d_qn), nq, nb, d_order, nullptr));
     CHK(record(h, 1));
@@ -859,6 +867,9 @@ extern "C" LMI_API int lmi_timings(lmi_index* h, float* ms) {
     CHK(span(1, 2, &ms[LMI_T_ROUTE]));
     CHK(span(2, 3, &ms[LMI_T_SCAN]));
     CHK(span(3, 4, &ms[LMI_T_MERGE]));
+    CHK(span(2, 5, &ms[LMI_T_PF_SAMPLE]));
+    CHK(span(5, 6, &ms[LMI_T_PF_EMIT]));
+    CHK(span(6, 3, &ms[LMI_T_RESCORE]));
     int first = h->ev_valid[0] ? 0 : 1;
     int last = h->ev_valid[4] ? 4 : 1;
     CHK(span(first, last, &ms[LMI_T_TOTAL]));

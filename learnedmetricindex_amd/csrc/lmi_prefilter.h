@@ -154,15 +154,17 @@ __global__ void slot_bound_kernel(const int* __restrict__ bucket_order, const in
 // Prefilter kernels: fp16 operands, 256 x 128 block tile (wave = 64 vectors x 128 queries, 8
 // accumulator tiles), A straight to VGPRs, B through two 8-KiB LDS buffers, one barrier per
 // 32-wide k-stage.  Two passes over the same code (template SAMPLE):
-//   pass 1 (SAMPLE):  one item per (bucket, query tile) scans every PF_SAMPLE-th 256-row tile of the
-//                     whole bucket with per-lane VALUES-ONLY top-10 lists, merges the 8 lists of a
-//                     column and stores bound[col] = the sample's 10th-best shat (a lower bound of
-//                     the bucket's 10th best That; -inf if the sample holds < 10 rows);
+//   pass 1 (SAMPLE):  PF_PARTS items per (bucket, query tile) scan every PF_SAMPLE-th 256-row tile of
+//                     the whole bucket (part p takes sampled tiles p, p+PF_PARTS, ..) with per-lane
+//                     VALUES-ONLY top-10 lists, merge the 8 lists of a column and store the part's 10
+//                     best; the consumer's 10th best of the union of the parts is a lower bound of the
+//                     bucket's 10th best That (-inf if the sample holds < 10 rows);
 //   pass 2 (!SAMPLE): items (bucket, query tile, chunk) from the XCD-affine queues; no lists, no
 //                     inter-item traffic: every row with shat >= bound[col] - 2 eps' is appended to
 //                     the slot's candidate buffer.  About 10 * PF_SAMPLE rows per slot pass.
 // ------------------------------------------------------------------------------------------------
-constexpr int PF_SAMPLE = 16;
+constexpr int PF_SAMPLE = 16;  // pass 1 looks at every 16th tile ...
+constexpr int PF_PARTS = 4;    // ... split over 4 items per (bucket, query tile), merged by the consumers
 
 struct PrefilterParams {
     const uint4* slab16;
@@ -181,7 +183,8 @@ struct PrefilterParams {
     const int* grp_n;
     const int* grp_total;
     unsigned* head;       // [NGRP] pass-2 queue heads; [NGRP] = pass-1 head
-    float* bound;         // [columns] pass 1 -> pass 2
+    float* bound;         // [columns][PF_PARTS][KPB] pass 1: each part's 10 best sampled shat
+    float* bound1;        // [columns] bound_merge_kernel: 10th best of the union of the parts -> pass 2
     const float* eps2;    // 2 eps' per column
     unsigned* cand_cnt;   // [columns]
     unsigned* cand_row;   // [columns][PF_CAP]
@@ -262,18 +265,20 @@ struct PreItem {
         }
     }
 
-    // SAMPLE: ch is ignored, the item covers tiles 0, PF_SAMPLE, 2*PF_SAMPLE, ... of the whole bucket
+    // SAMPLE: `ch` is the part p in [0, PF_PARTS): the item covers the tiles (p + PF_PARTS*i)*PF_SAMPLE, i = 0,1,..
+    // of the whole bucket and writes its 10 best values; !SAMPLE: chunk `ch`, every tile.
     __device__ __forceinline__ void run(int b, int qt, int ch) {
         const int tid = threadIdx.x;
         lane = tid & 63; w = tid >> 6; h = lane >> 5; c = lane & 31;
         const int KG = P.KG16, NS = KG / PF_STAGE_G;
         const int n_b = P.nb_rows[b];
         const int nrb_b = (n_b + 31) >> 5;
-        const int rb_in_b0 = SAMPLE ? 0 : ch * P.chunk_rb;
-        const int nrb = SAMPLE ? nrb_b : min(P.chunk_rb, nrb_b - rb_in_b0);
-        const int nvt_all = (nrb + 4 * PF_RB - 1) / (4 * PF_RB);
-        const int TSTEP = SAMPLE ? PF_SAMPLE : 1;                 // tile stride
-        const int nvt = (nvt_all + TSTEP - 1) / TSTEP;            // tiles this item processes
+        const int nrb_all = SAMPLE ? nrb_b : min(P.chunk_rb, nrb_b - ch * P.chunk_rb);
+        const int nvt_all = (nrb_all + 4 * PF_RB - 1) / (4 * PF_RB);
+        const int TSTEP = SAMPLE ? PF_SAMPLE * PF_PARTS : 1;      // tile stride
+        const int t0 = SAMPLE ? ch * PF_SAMPLE : 0;               // first tile
+        const int nvt = nvt_all > t0 ? (nvt_all - t0 + TSTEP - 1) / TSTEP : 0;  // tiles this item processes
+        const int rb_in_b0 = SAMPLE ? t0 * 4 * PF_RB : ch * P.chunk_rb;
         const int cb0 = P.cb_start[b] + qt * 4;
         const int m_left = P.m[b] - qt * TILE_COLS;
         const size_t col0 = (size_t)cb0 * 32;
@@ -287,7 +292,8 @@ struct PreItem {
 #pragma unroll
                 for (int j = 0; j < KPB; ++j) lv[SAMPLE ? n : 0][j] = -INFINITY;
             } else {
-                thr[n] = P.bound[col0 + n * 32 + c] - P.eps2[col0 + n * 32 + c];
+                const float v10 = P.bound1[col0 + n * 32 + c];
+                thr[n] = v10 - P.eps2[col0 + n * 32 + c];
             }
 #pragma unroll
             for (int j = 0; j < PF_RB; ++j)
@@ -323,9 +329,11 @@ struct PreItem {
         t_c = 0; ++vt_c;                                                                          \
     }
         const int total = nvt * NS;
+        if (total > 0) {
         PF_LOAD(x)
         PF_STORE_B(sB0)
         __syncthreads();
+        }
         for (int u = 0; u < total; u += 2) {
             PF_LOAD(y)
             compute<0>(x);
@@ -385,14 +393,41 @@ struct PreItem {
                     }
 #pragma unroll
                     for (int j = 0; j < KPB; ++j) carry[tid * KPB + j] = best[j];
-                    // the sample holds 10 rows with shat >= best[9]: a lower bound of the bucket's That
-                    if (round == 1) P.bound[col0 + n * 32 + tid] = best[KPB - 1];
+                    // this part's 10 best sampled values (descending; -inf where the sample ran out)
+                    if (round == 1) {
+                        float* bl = P.bound + (col0 + n * 32 + tid) * (PF_PARTS * KPB) + ch * KPB;
+#pragma unroll
+                        for (int j = 0; j < KPB; ++j) bl[j] = best[j];
+                    }
                 }
             }
         }
         __syncthreads();
     }
 };
+
+// 10th best of the union of the PF_PARTS sampled lists of every column (each sorted descending)
+__global__ void bound_merge_kernel(const float* __restrict__ parts, long long ncols, float* __restrict__ bound1) {
+    const long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= ncols) return;
+    float v[PF_PARTS * KPB];
+#pragma unroll
+    for (int i = 0; i < PF_PARTS * KPB; ++i) v[i] = parts[col * (PF_PARTS * KPB) + i];
+    float pv = INFINITY;
+    int pi = -1;
+    for (int j = 0; j < KPB; ++j) {  // selection in (value desc, position asc) order
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < PF_PARTS * KPB; ++i) {
+            const bool after = (v[i] < pv) || (v[i] == pv && i > pi);
+            if (after && (v[i] > bv || (v[i] == bv && i < bi))) { bv = v[i]; bi = i; }
+        }
+        pv = bv;
+        pi = bi;
+    }
+    bound1[col] = pv;
+}
 
 template <bool SAMPLE>
 __global__ __launch_bounds__(256, 2) void prefilter_kernel(PrefilterParams P) {
@@ -404,16 +439,17 @@ __global__ __launch_bounds__(256, 2) void prefilter_kernel(PrefilterParams P) {
         if (threadIdx.x == 0) {
             int b = -1, local = 0;
             if (SAMPLE) {  // one plain queue of (bucket, query tile) items
-                const int tot = P.qt_base[P.L];
+                const int tot = P.qt_base[P.L] * PF_PARTS;
                 const int it = (int)atomicAdd(&P.head[NGRP], 1u);
                 if (it < tot) {
+                    const int pair = it / PF_PARTS;  // (bucket, query tile) pair; parts adjacent in the queue
                     int lo = 0, hi = P.L;
                     while (hi - lo > 1) {
                         const int mid = (lo + hi) >> 1;
-                        if (P.qt_base[mid] <= it) lo = mid; else hi = mid;
+                        if (P.qt_base[mid] <= pair) lo = mid; else hi = mid;
                     }
                     b = lo;
-                    local = it - P.qt_base[lo];
+                    local = (pair - P.qt_base[lo]) * PF_PARTS + (it % PF_PARTS);
                 }
             } else {
                 for (int tries = 0; tries < NGRP; ++tries) {
@@ -444,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void prefilter_kernel(PrefilterParams P) {
         if (b < 0) return;
         const int m_b = P.m[b];
         const int nqt = (m_b + TILE_COLS - 1) / TILE_COLS;
-        const int qt = SAMPLE ? local : local % nqt, ch = SAMPLE ? 0 : local / nqt;
+        const int qt = SAMPLE ? local / PF_PARTS : local % nqt, ch = SAMPLE ? local % PF_PARTS : local / nqt;
         const int ncb = min(4, (m_b - qt * TILE_COLS + 31) >> 5);
         switch (ncb) {
             case 1: { PreItem<1, SAMPLE> it{P, sB0, sB1}; it.run(b, qt, ch); break; }
