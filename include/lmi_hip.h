@@ -137,8 +137,8 @@ LMI_API int lmi_timings(lmi_index *h, float *ms /* [LMI_T_COUNT] */);
 LMI_API int lmi_scan_stats(lmi_index *h, double *flops, int64_t *pairs, int64_t *items);
 /* Scan mode.  on (default): fp16-MFMA prefilter with a proven error bound + exact binary32
  * re-ranking of the survivors (lmi_prefilter.h); off: every similarity by f32 MFMA.  Both modes
- * return bit-identical results; call before lmi_buckets_end (the fp16 copy of the index is built
- * there).  lmi_prefilter_stats: whether the last scan used the prefilter, how many candidates were
+ * return bit-identical results; call before lmi_buckets_begin (the index is stored differently:
+ * row-major f32 + fp16 fragments vs f32 fragments).  lmi_prefilter_stats: whether the last scan used the prefilter, how many candidates were
  * re-scored exactly and how many (query, rank) slots fell back to the exact brute-force kernel. */
 LMI_API int lmi_set_prefilter(lmi_index *h, int on);
 LMI_API int lmi_prefilter_stats(lmi_index *h, int *active, int64_t *survivors, int64_t *fallbacks);

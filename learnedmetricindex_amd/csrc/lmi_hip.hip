@@ -99,8 +99,10 @@ struct lmi_index {
     bool prefilter = true;   // lmi_set_prefilter
     bool have16 = false;     // slab16 built by lmi_buckets_end
     int KG16 = 0;
-    DevBuf slab16, xscale, xmaxbits, bnorm;
-    DevBuf qnorm, qmaxbits, qscale, qfrag16, eps2, cand_cnt, cand_row, cand_s, fallback, pf_bound;
+    DevBuf slab16, rowmajor, xscale, xmaxbits, bnorm;
+    DevBuf qnorm, qmaxbits, qscale, qfrag16, eps2, cand_cnt, cand_row, cand_s, fallback, pf_bound, nkeep;
+    int last_nslots = 0;
+    bool last_fast = false;
 
     // ---- per-call workspaces ----
     DevBuf act[2], xfrag, logits, order, q_nav, q_srch;
@@ -150,7 +152,7 @@ extern "C" LMI_API int lmi_destroy(lmi_index* h) {
     DevBuf* bufs[] = {&h->slab, &h->ids_slab, &h->pos, &h->d_nb_rows, &h->d_rb_start, &h->d_nch, &h->stage,
                       &h->act[0], &h->act[1], &h->xfrag, &h->logits, &h->order, &h->q_nav, &h->q_srch, &h->m,
                       &h->cb_start, &h->item_base, &h->part_base, &h->stats, &h->head, &h->slot_local,
-                      &h->slot_col, &h->colmap, &h->qfrag, &h->grp, &h->col_thr, &h->slab16, &h->xscale, &h->xmaxbits, &h->bnorm, &h->qnorm, &h->qmaxbits, &h->qscale, &h->qfrag16, &h->eps2, &h->cand_cnt, &h->cand_row, &h->cand_s, &h->fallback, &h->pf_bound, &h->part_score, &h->part_row, &h->rank_d,
+                      &h->slot_col, &h->colmap, &h->qfrag, &h->grp, &h->col_thr, &h->slab16, &h->rowmajor, &h->xscale, &h->xmaxbits, &h->bnorm, &h->qnorm, &h->qmaxbits, &h->qscale, &h->qfrag16, &h->eps2, &h->cand_cnt, &h->cand_row, &h->cand_s, &h->fallback, &h->pf_bound, &h->nkeep, &h->part_score, &h->part_row, &h->rank_d,
                       &h->rank_id, &h->out_d, &h->out_id, &h->out_key};
     for (DevBuf* b : bufs) b->release();
     for (int i = 0; i < 8; ++i)
@@ -175,7 +177,8 @@ extern "C" LMI_API int lmi_set_chunk_rows(lmi_index* h, int rows) {
 
 extern "C" LMI_API int lmi_set_prefilter(lmi_index* h, int on) {
     if (!h) return fail("lmi_set_prefilter: NULL handle");
-    if (on && h->built && !h->have16) return fail("lmi_set_prefilter: the fp16 slab was not built (enable before lmi_buckets_end)");
+    if ((h->built || h->building) && (on != 0) != h->prefilter)
+        return fail("lmi_set_prefilter: the mode is fixed once lmi_buckets_begin has run (the index is stored differently)");
     h->prefilter = on != 0;
     return 0;
 }
@@ -261,8 +264,17 @@ extern "C" LMI_API int lmi_buckets_begin(lmi_index* h, int64_t N, int d, int L, 
         ids_slab[p] = ids ? ids[i] : (uint32_t)(i + 1);  // search.py:190-191: 1-based labels
     }
     const size_t slab_bytes = (size_t)std::max<int64_t>(h->n_rb_total, 1) * h->KGs * 1024;
-    CHK(h->slab.reserve(slab_bytes));
-    HIPCHK(hipMemsetAsync(h->slab.p, 0, slab_bytes, h->stream));
+    if (h->prefilter) {  // row-major f32 (exact re-rank / fallback / read-back); fp16 fragments at buckets_end
+        const size_t rm_bytes = (size_t)std::max<int64_t>(h->n_rb_total, 1) * 32 * d * 4;
+        h->slab.release();
+        CHK(h->rowmajor.reserve(rm_bytes));
+        HIPCHK(hipMemsetAsync(h->rowmajor.p, 0, rm_bytes, h->stream));
+    } else {             // f32 fragments for the all-f32 scan
+        h->rowmajor.release();
+        h->slab16.release();
+        CHK(h->slab.reserve(slab_bytes));
+        HIPCHK(hipMemsetAsync(h->slab.p, 0, slab_bytes, h->stream));
+    }
     CHK(h->ids_slab.reserve(ids_slab.size() * 4));
     HIPCHK(hipMemcpy(h->ids_slab.p, ids_slab.data(), ids_slab.size() * 4, hipMemcpyHostToDevice));
     CHK(h->pos.reserve(std::max<size_t>(pos.size(), 1) * 4));
@@ -292,9 +304,15 @@ extern "C" LMI_API int lmi_buckets_add_rows(lmi_index* h, const float* rows, int
             HIPCHK(hipMemcpyAsync(h->stage.p, src, (size_t)n * h->d * 4, hipMemcpyHostToDevice, h->stream));
             src = h->stage.as<float>();
         }
-        long long total = (long long)n * h->KGs;
-        pack_scatter_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(src, h->d, h->pos.as<int>(), row0 + off, n,
-                                                                    h->KGs, h->slab.as<float4>());
+        if (h->prefilter) {
+            long long total = (long long)n * h->d;
+            scatter_rows_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(src, h->d, h->pos.as<int>(), row0 + off, n,
+                                                                        h->rowmajor.as<float>());
+        } else {
+            long long total = (long long)n * h->KGs;
+            pack_scatter_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(src, h->d, h->pos.as<int>(), row0 + off, n,
+                                                                        h->KGs, h->slab.as<float4>());
+        }
         HIPCHK(hipGetLastError());
         if (!on_device) HIPCHK(hipStreamSynchronize(h->stream));
     }
@@ -312,25 +330,24 @@ extern "C" LMI_API int lmi_buckets_end(lmi_index* h) {
     if (h->prefilter && h->n_rb_total > 0) {
         // fp16 copy of the slab for the prefilter: one power-of-two scale for the whole index
         h->KG16 = (int)rup(cdiv(h->d, 16), PF_STAGE_G);
-        const long long n4 = (long long)h->n_rb_total * h->KGs * 64;
+        const long long n_rows = (long long)h->n_rb_total * 32;
         CHK(h->xmaxbits.reserve(16));
         CHK(h->xscale.reserve(16));
         CHK(h->bnorm.reserve((size_t)h->L * 4));
         CHK(h->slab16.reserve((size_t)h->n_rb_total * h->KG16 * 1024));
         HIPCHK(hipMemsetAsync(h->xmaxbits.p, 0, 16, h->stream));
         HIPCHK(hipMemsetAsync(h->bnorm.p, 0, (size_t)h->L * 4, h->stream));
-        absmax_kernel<<<h->num_cus * 8, 256, 0, h->stream>>>(h->slab.as<float4>(), n4, h->xmaxbits.as<unsigned>());
+        absmax_kernel<<<h->num_cus * 8, 256, 0, h->stream>>>(h->rowmajor.as<float>(), n_rows * h->d, h->xmaxbits.as<unsigned>());
         HIPCHK(hipGetLastError());
         make_scale_kernel<<<1, 1, 0, h->stream>>>(h->xmaxbits.as<unsigned>(), h->xscale.as<float>());
         HIPCHK(hipGetLastError());
-        const long long total = (long long)h->n_rb_total * h->KG16 * 64;
-        convert16_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(h->slab.as<float4>(), h->KGs, h->n_rb_total, h->KG16,
+        const long long total = n_rows * h->KG16 * 2;
+        convert16_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(h->rowmajor.as<float>(), h->d, n_rows, h->KG16,
                                                                  h->xscale.as<float>(), h->slab16.as<uint4>());
         HIPCHK(hipGetLastError());
         dim3 g(64, h->L);
-        bucket_norm_kernel<<<g, 256, 0, h->stream>>>(h->slab.as<float4>(), h->KGs, h->d_rb_start.as<int>(),
-                                                    h->d_nb_rows.as<int>(), h->L, h->xscale.as<float>(),
-                                                    h->bnorm.as<unsigned>());
+        bucket_norm_kernel<<<g, 256, 0, h->stream>>>(h->rowmajor.as<float>(), h->d, h->d_rb_start.as<int>(),
+                                                    h->d_nb_rows.as<int>(), h->xscale.as<float>(), h->bnorm.as<unsigned>());
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(h->stream));
         h->have16 = true;
@@ -353,7 +370,9 @@ extern "C" LMI_API int lmi_bucket_read(lmi_index* h, int bucket, float* rows, ui
     if (n == 0) return 0;
     CHK(set_dev(h));
     const int64_t p0 = (int64_t)h->h_rb_start[bucket] * 32;
-    if (rows) {
+    if (rows && h->prefilter) {
+        HIPCHK(hipMemcpyAsync(rows, h->rowmajor.as<float>() + (size_t)p0 * h->d, (size_t)n * h->d * 4, hipMemcpyDeviceToHost, h->stream));
+    } else if (rows) {
         CHK(h->stage.reserve((size_t)n * h->d * 4));
         long long total = n * cdiv(h->d, 8);
         unpack_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(h->slab.as<float4>(), h->KGs, p0, n, h->d, h->stage.as<float>());
@@ -585,6 +604,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         CHK(h->cand_row.reserve(ncols * PF_CAP * 4));
         CHK(h->cand_s.reserve(ncols * PF_CAP * 4));
         CHK(h->fallback.reserve((size_t)nslots * 4));
+        CHK(h->nkeep.reserve((size_t)nslots * 4));
         CHK(h->pf_bound.reserve(ncols * PF_PARTS * KPB * 4));
         HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->pf_bound.p), (int)0xFF800000u /* -inf */,
                                  ncols * PF_PARTS * KPB, h->stream));
@@ -643,7 +663,6 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         Q.nslots = nslots;
         Q.nb = nb;
         Q.d = h->d;
-        Q.KG = h->KGs;
         Q.raw = raw;
         Q.rb_start = S.rb_start;
         Q.nb_rows = R.nb_rows;
@@ -651,13 +670,13 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         Q.cand_row = F.cand_row;
         Q.cand_s = F.cand_s;
         Q.eps2 = F.eps2;
-        Q.slab = S.slab;
+        Q.rows = h->rowmajor.as<float>();
         Q.q = d_qs;
         Q.ids_slab = h->ids_slab.as<unsigned>();
         Q.rank_d = h->rank_d.as<float>();
         Q.rank_id = h->rank_id.as<unsigned>();
         Q.fallback = h->fallback.as<int>();
-        Q.stats = R.stats;
+        Q.nkeep = h->nkeep.as<int>();
         select_rescore_kernel<<<nslots, 64, 0, h->stream>>>(Q);
         HIPCHK(hipGetLastError());
         fallback_kernel<<<nslots, 256, 0, h->stream>>>(Q);
@@ -690,6 +709,8 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     HIPCHK(hipGetLastError());
     CHK(record(h, 4));
     h->stats_pending = true;
+    h->last_nslots = nslots;
+    h->last_fast = fast;
     return 0;
 }
 
@@ -879,14 +900,18 @@ extern "C" LMI_API int lmi_timings(lmi_index* h, float* ms) {
 extern "C" LMI_API int lmi_prefilter_stats(lmi_index* h, int* active, int64_t* survivors, int64_t* fallbacks) {
     if (!h) return fail("lmi_prefilter_stats: NULL handle");
     CHK(set_dev(h));
-    if (h->stats_pending) {
+    unsigned long long acc[2] = {0, 0};
+    if (h->last_fast && h->last_nslots > 0) {
+        unsigned long long* d_acc = reinterpret_cast<unsigned long long*>(h->stats.as<long long>() + 2);
+        HIPCHK(hipMemsetAsync(d_acc, 0, 16, h->stream));
+        prefilter_stats_kernel<<<64, 256, 0, h->stream>>>(h->nkeep.as<int>(), h->fallback.as<int>(), h->last_nslots, d_acc);
+        HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(h->stream));
-        HIPCHK(hipMemcpy(h->h_stats, h->stats.p, 32, hipMemcpyDeviceToHost));
-        h->stats_pending = false;
+        HIPCHK(hipMemcpy(acc, d_acc, 16, hipMemcpyDeviceToHost));
     }
     if (active) *active = (h->prefilter && h->have16) ? 1 : 0;
-    if (survivors) *survivors = h->h_stats[2];
-    if (fallbacks) *fallbacks = h->h_stats[3];
+    if (survivors) *survivors = (int64_t)acc[0];
+    if (fallbacks) *fallbacks = (int64_t)acc[1];
     return 0;
 }
 

@@ -29,17 +29,31 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 constexpr int PF_RB = 2;            // row-blocks per wave: block tile = 4 waves x 2 x 32 = 256 vectors
 constexpr int PF_TILE_ROWS = 256;
-constexpr int PF_STAGE_G = 2;       // k16-groups per stage -> BK = 32
+#ifndef LMI_PF_STAGE_G
+#define LMI_PF_STAGE_G 2
+#endif
+constexpr int PF_STAGE_G = LMI_PF_STAGE_G;  // k16-groups per stage -> BK = 16 * PF_STAGE_G
 constexpr int PF_CAP = 1024;        // candidate slots per (query, rank); overflow -> exact fallback
 constexpr int PF_KEEP = 64;         // survivors re-scored per slot; more -> exact fallback
 
-// ---- ingest: global max |x| of the f32 slab (bits of a non-negative float order like ints) -------
-__global__ void absmax_kernel(const float4* __restrict__ slab, long long n4, unsigned* __restrict__ out) {
+// ---- ingest (prefilter mode): the index keeps a bucket-contiguous ROW-MAJOR f32 copy (exact
+//      re-ranking reads whole rows: 3 KiB contiguous instead of 192 scattered 16-B pieces of the
+//      fragment-major layout, which cost 4x the bytes in 64-B sectors) and the fp16 fragments ----
+__global__ void scatter_rows_kernel(const float* __restrict__ src, int d, const int* __restrict__ pos,
+                                    long long row0, long long nrows, float* __restrict__ dst) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nrows * d) return;
+    const long long i = idx / d;
+    const int k = (int)(idx - i * d);
+    const long long p = pos[row0 + i];
+    if (p >= 0) dst[p * d + k] = src[idx];
+}
+
+// global max |x| (bits of a non-negative float order like unsigned ints)
+__global__ void absmax_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ out) {
     float m = 0.0f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-        const float4 v = slab[i];
-        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-    }
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(x[i]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
@@ -55,45 +69,38 @@ __global__ void make_scale_kernel(const unsigned* __restrict__ maxbits, float* _
     scale[1] = 1.0f / s;
 }
 
-// f32 fragment-major -> fp16 fragment-major (x scale).  One thread per (row, k16-group, half).
-//   f32: F[rb][k/8][(k&1)*32 + r].comp((k&7)>>1);  f16: H[rb][k/16][((k>>3)&1)*32 + r][k&7]
-__global__ void convert16_kernel(const float4* __restrict__ src, int KG, long long n_rb, int KG16,
+// row-major f32 -> fp16 fragment-major (x scale): H[rb][k/16][((k>>3)&1)*32 + r][k&7].
+// One thread per (slab row p, k16-group, half).
+__global__ void convert16_kernel(const float* __restrict__ rows, int d, long long n_rows, int KG16,
                                  const float* __restrict__ scale, uint4* __restrict__ dst) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long total = n_rb * KG16 * 64;
-    if (idx >= total) return;
-    const int lane = (int)(idx & 63), r = lane & 31, hh = lane >> 5;
-    const int g = (int)((idx >> 6) % KG16);
-    const long long rb = (idx >> 6) / KG16;
-    const int g8 = 2 * g + hh;  // f32 k-group holding k = 16g + 8hh .. +7
-    float4 e = make_float4(0.f, 0.f, 0.f, 0.f), o = e;
-    if (g8 < KG) {
-        const float4* f = src + ((size_t)rb * KG + g8) * 64 + r;
-        e = f[0];   // k even: +0,+2,+4,+6
-        o = f[32];  // k odd : +1,+3,+5,+7
-    }
+    if (idx >= n_rows * KG16 * 2) return;
+    const int hh = (int)(idx & 1);
+    const int g = (int)((idx >> 1) % KG16);
+    const long long p = (idx >> 1) / KG16;
     const float s = scale[0];
+    const float* x = rows + p * d;
     half8 h;
-    h[0] = (_Float16)(e.x * s); h[1] = (_Float16)(o.x * s); h[2] = (_Float16)(e.y * s); h[3] = (_Float16)(o.y * s);
-    h[4] = (_Float16)(e.z * s); h[5] = (_Float16)(o.z * s); h[6] = (_Float16)(e.w * s); h[7] = (_Float16)(o.w * s);
-    dst[idx] = *reinterpret_cast<uint4*>(&h);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 16 * g + 8 * hh + j;
+        h[j] = (_Float16)(k < d ? x[k] * s : 0.0f);
+    }
+    dst[((size_t)(p >> 5) * KG16 + g) * 64 + hh * 32 + (p & 31)] = *reinterpret_cast<uint4*>(&h);
 }
 
 // per-bucket max of the scaled row norm, rounded up (bits of non-negative floats order like ints)
-__global__ void bucket_norm_kernel(const float4* __restrict__ slab, int KG, const int* __restrict__ rb_start,
-                                   const int* __restrict__ nb_rows, int L, const float* __restrict__ scale,
+__global__ void bucket_norm_kernel(const float* __restrict__ rows, int d, const int* __restrict__ rb_start,
+                                   const int* __restrict__ nb_rows, const float* __restrict__ scale,
                                    unsigned* __restrict__ bnorm_bits) {
     const int b = blockIdx.y;
     const int n_b = nb_rows[b];
     const float s = scale[0];
     float best = 0.0f;
     for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < n_b; row += gridDim.x * blockDim.x) {
-        const float4* f = slab + ((size_t)(rb_start[b] + (row >> 5)) * KG) * 64 + (row & 31);
+        const float* x = rows + ((size_t)rb_start[b] * 32 + row) * d;
         float acc = 0.0f;
-        for (int g = 0; g < KG; ++g) {
-            const float4 e = f[(size_t)g * 64], o = f[(size_t)g * 64 + 32];
-            acc += e.x * e.x + e.y * e.y + e.z * e.z + e.w * e.w + o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
-        }
+        for (int k = 0; k < d; ++k) acc += x[k] * x[k];
         best = fmaxf(best, sqrtf(acc) * s * 1.0002f);  // 1.0002: covers the binary32 error of the sum
     }
     if (best > 0.0f) atomicMax(bnorm_bits + b, __float_as_uint(best));
@@ -503,40 +510,36 @@ __global__ __launch_bounds__(256, 2) void prefilter_kernel(PrefilterParams P) {
 struct RescoreParams {
     const int* bucket_order;
     const int* slot_col;
-    int nslots, nb, d, KG, raw;
+    int nslots, nb, d, raw;
     const int* rb_start;
     const int* nb_rows;
     const unsigned* cand_cnt;
     const unsigned* cand_row;
     const float* cand_s;
     const float* eps2;
-    const float4* slab;
-    const float* q;  // row-major [nq][d]
+    const float* rows;  // bucket-contiguous row-major f32 [slab rows][d]
+    const float* q;     // row-major [nq][d]
     const unsigned* ids_slab;
     float* rank_d;
     unsigned* rank_id;
     int* fallback;
-    long long* stats;  // [2] += survivors, [3] += fallback slots
+    int* nkeep;  // [nslots] survivors re-scored (statistics; summed on request)
 };
 
-// canonical similarity of in-bucket row `row` of the bucket starting at row-block rb0 with query qv[0..d)
-__device__ __forceinline__ float exact_score(const float4* __restrict__ slab, int KG, int rb0, unsigned row,
-                                             const float* __restrict__ qv, int d) {
-    const float4* f = slab + ((size_t)(rb0 + (int)(row >> 5)) * KG) * 64 + (row & 31);
+// canonical similarity of slab row p with query qv[0..d): acc = fmaf(q[k], x[k], acc), k ascending
+__device__ __forceinline__ float exact_score(const float* __restrict__ rows, size_t p, const float* __restrict__ qv, int d) {
+    const float* x = rows + p * d;
     float acc = 0.0f;
-    const int ng = d >> 3;
-    for (int g = 0; g < ng; ++g) {
-        const float4 e = f[(size_t)g * 64], o = f[(size_t)g * 64 + 32];
-        const float* qq = qv + 8 * g;
-        acc = __builtin_fmaf(qq[0], e.x, acc); acc = __builtin_fmaf(qq[1], o.x, acc);
-        acc = __builtin_fmaf(qq[2], e.y, acc); acc = __builtin_fmaf(qq[3], o.y, acc);
-        acc = __builtin_fmaf(qq[4], e.z, acc); acc = __builtin_fmaf(qq[5], o.z, acc);
-        acc = __builtin_fmaf(qq[6], e.w, acc); acc = __builtin_fmaf(qq[7], o.w, acc);
-    }
-    if (d & 7) {
-        const float4 e = f[(size_t)ng * 64], o = f[(size_t)ng * 64 + 32];
-        const float xv[8] = {e.x, o.x, e.y, o.y, e.z, o.z, e.w, o.w};
-        for (int j = 0; j < (d & 7); ++j) acc = __builtin_fmaf(qv[8 * ng + j], xv[j], acc);
+    int k = 0;
+    if ((d & 3) == 0) {  // rows are 16-byte aligned: vector loads, same k order
+        for (; k < d; k += 4) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + k);
+            const float4 qq = *reinterpret_cast<const float4*>(qv + k);
+            acc = __builtin_fmaf(qq.x, xv.x, acc); acc = __builtin_fmaf(qq.y, xv.y, acc);
+            acc = __builtin_fmaf(qq.z, xv.z, acc); acc = __builtin_fmaf(qq.w, xv.w, acc);
+        }
+    } else {
+        for (; k < d; ++k) acc = __builtin_fmaf(qv[k], x[k], acc);
     }
     return acc;
 }
@@ -566,14 +569,14 @@ __global__ __launch_bounds__(64) void select_rescore_kernel(RescoreParams P) {
     unsigned* ri = P.rank_id + (size_t)p * KPB;
     const int col = P.slot_col[p];
     const float FMAXV = 3.402823466e+38f;
-    if (lane == 0) P.fallback[p] = 0;
+    if (lane == 0) { P.fallback[p] = 0; P.nkeep[p] = 0; }
     if (col < 0) {  // unvisited (LearnedIndex.py:340-341)
         if (lane < KPB) { rd[lane] = P.raw ? -FMAXV : INFINITY; ri[lane] = P.raw ? NOROW : 0u; }
         return;
     }
     const unsigned cnt = P.cand_cnt[col];
     if (cnt > (unsigned)PF_CAP) {
-        if (lane == 0) { P.fallback[p] = 1; atomicAdd((unsigned long long*)&P.stats[3], 1ull); }
+        if (lane == 0) { P.fallback[p] = 1; P.nkeep[p] = 0; }
         return;
     }
     const float* cs = P.cand_s + (size_t)col * PF_CAP;
@@ -610,17 +613,17 @@ __global__ __launch_bounds__(64) void select_rescore_kernel(RescoreParams P) {
     __syncthreads();
     const unsigned nk = keep_n;
     if (nk > (unsigned)PF_KEEP) {
-        if (lane == 0) { P.fallback[p] = 1; atomicAdd((unsigned long long*)&P.stats[3], 1ull); }
+        if (lane == 0) { P.fallback[p] = 1; P.nkeep[p] = 0; }
         return;
     }
-    if (lane == 0) atomicAdd((unsigned long long*)&P.stats[2], (unsigned long long)nk);
+    if (lane == 0) P.nkeep[p] = (int)nk;
     const int b = P.bucket_order[p];
     const int rb0 = P.rb_start[b], n_b = P.nb_rows[b];
     float s = -INFINITY;
     unsigned row = NOROW;
     if (lane < (int)nk) {
         row = keep_row[lane];
-        s = exact_score(P.slab, P.KG, rb0, row, P.q + (size_t)(p / P.nb) * P.d, P.d);
+        s = exact_score(P.rows, (size_t)rb0 * 32 + row, P.q + (size_t)(p / P.nb) * P.d, P.d);
     }
     // 10 best by (score desc, row asc)
     float my_s = -INFINITY;
@@ -642,6 +645,16 @@ __global__ __launch_bounds__(64) void select_rescore_kernel(RescoreParams P) {
     write_rank_list(lane, my_s, my_r, n_b, rb0, P.raw, P.ids_slab, rd, ri);
 }
 
+// statistics on request: out[0] += survivors, out[1] += fallback slots
+__global__ void prefilter_stats_kernel(const int* __restrict__ nkeep, const int* __restrict__ fallback, int nslots,
+                                       unsigned long long* __restrict__ out) {
+    unsigned long long a = 0, b = 0;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < nslots; p += gridDim.x * blockDim.x) { a += nkeep[p]; b += fallback[p]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(out, a); atomicAdd(out + 1, b); }
+}
+
 // Exact fallback for overflowed slots: one block per slot, brute force over the whole bucket with the
 // canonical chain on the VALU (slow, rare, always correct).
 __global__ __launch_bounds__(256) void fallback_kernel(RescoreParams P) {
@@ -657,7 +670,7 @@ __global__ __launch_bounds__(256) void fallback_kernel(RescoreParams P) {
 #pragma unroll
     for (int j = 0; j < KPB; ++j) { v[j] = -INFINITY; id[j] = NOROW; }
     for (unsigned row = tid; row < (unsigned)n_b; row += 256) {
-        const float s = exact_score(P.slab, P.KG, rb0, row, qv, P.d);
+        const float s = exact_score(P.rows, (size_t)rb0 * 32 + row, qv, P.d);
         if (s > v[KPB - 1]) list_insert(v, id, s, row);  // rows ascend per thread: strict > keeps the earlier
     }
 #pragma unroll

@@ -87,7 +87,8 @@ def main():
         fl, pairs, items = idx.scan_stats()
         med, mn = float(np.median(times)), float(np.min(times))
         print(f"{os.path.basename(path):28s} scan median {med:8.3f} ms  min {mn:8.3f} ms  "
-              f"{fl / med / 1e9:7.2f} TFLOP/s (median)  items {items}", flush=True)
+              f"{fl / med / 1e9:7.2f} TFLOP/s (median)  items {items}  prefilter {idx.prefilter_stats()}  "
+              f"rounds {[round(t, 1) for t in times]}  last phases {[round(float(v), 2) for v in idx.timings()]}", flush=True)
 
 
 if __name__ == "__main__":
