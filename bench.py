@@ -289,7 +289,7 @@ def main():
             "phases_ms": {"inference": round(float(phases[0]), 4), "route_pack": round(float(phases[1]), 4),
                           "scan": round(float(phases[2]), 4), "merge": round(float(phases[3]), 4),
                           "pf_sample": round(float(phases[5]), 4), "pf_emit": round(float(phases[6]), 4),
-                          "rescore": round(float(phases[7]), 4)},
+                          "rescore": round(float(phases[7]), 4), "fallback": round(float(phases[8]), 4)},
         }
         print(json.dumps(result), flush=True)
     if world > 1:

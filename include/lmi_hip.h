@@ -60,8 +60,9 @@ enum {
     LMI_T_TOTAL = 4,     /* first to last event           -> measured_time["search"]                */
     LMI_T_PF_SAMPLE = 5, /* prefilter pass 1 (bounds from a sample); 0 in exact mode                */
     LMI_T_PF_EMIT = 6,   /* prefilter pass 2 (fp16 scan + candidate emission) -- the dominant kernel */
-    LMI_T_RESCORE = 7,   /* select + exact re-rank + exact fallback                                  */
-    LMI_T_COUNT = 8
+    LMI_T_RESCORE = 7,   /* select + exact re-rank of the survivors                                  */
+    LMI_T_FALLBACK = 8,  /* exact brute-force fallback for overflowed slots (normally empty)         */
+    LMI_T_COUNT = 12
 };
 
 LMI_API int lmi_abi_version(void);

@@ -108,8 +108,8 @@ struct lmi_index {
     DevBuf act[2], xfrag, logits, order, q_nav, q_srch;
     DevBuf m, cb_start, item_base, part_base, stats, head, slot_local, slot_col, colmap, qfrag, grp, col_thr;
     DevBuf part_score, part_row, rank_d, rank_id, out_d, out_id, out_key;
-    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool ev_valid[8] = {false, false, false, false, false, false, false, false};
+    hipEvent_t ev[10] = {};
+    bool ev_valid[10] = {};
     long long h_stats[4] = {0, 0, 0, 0};
     bool stats_pending = false;
 };
@@ -138,7 +138,7 @@ extern "C" LMI_API int lmi_create(int device, lmi_index** out) {
     int occ = 0;
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_kernel, 256, SCAN_LDS));
     h->scan_blocks_per_cu = std::max(1, std::min(occ, RB == 1 ? 2 : 1));
-    for (int i = 0; i < 8; ++i) HIPCHK(hipEventCreate(&h->ev[i]));
+    for (int i = 0; i < 10; ++i) HIPCHK(hipEventCreate(&h->ev[i]));
     *out = h;
     return 0;
 }
@@ -155,7 +155,7 @@ extern "C" LMI_API int lmi_destroy(lmi_index* h) {
                       &h->slot_col, &h->colmap, &h->qfrag, &h->grp, &h->col_thr, &h->slab16, &h->rowmajor, &h->xscale, &h->xmaxbits, &h->bnorm, &h->qnorm, &h->qmaxbits, &h->qscale, &h->qfrag16, &h->eps2, &h->cand_cnt, &h->cand_row, &h->cand_s, &h->fallback, &h->pf_bound, &h->nkeep, &h->part_score, &h->part_row, &h->rank_d,
                       &h->rank_id, &h->out_d, &h->out_id, &h->out_key};
     for (DevBuf* b : bufs) b->release();
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 10; ++i)
         if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     delete h;
     return 0;
@@ -458,7 +458,7 @@ extern "C" LMI_API int lmi_mlp_topk(lmi_index* h, const float* queries_nav, int 
         d_order = h->order.as<int>();
         if (logits) { CHK(h->logits.reserve((size_t)nq * L * 4)); d_logits = h->logits.as<float>(); }
     }
-    for (int i = 0; i < 8; ++i) h->ev_valid[i] = false;
+    for (int i = 0; i < 10; ++i) h->ev_valid[i] = false;
     CHK(record(h, 0));
     CHK(mlp_enqueue(h, static_cast<const float*>(d_q), nq, nb, d_order, d_logits));
     CHK(record(h, 1));
@@ -488,7 +488,7 @@ extern "C" LMI_API int lmi_mlp_proba(lmi_index* h, const float* queries_nav, int
         d_order = h->order.as<int>();
         d_probs = h->out_d.as<float>();
     }
-    for (int i = 0; i < 8; ++i) h->ev_valid[i] = false;
+    for (int i = 0; i < 10; ++i) h->ev_valid[i] = false;
     CHK(record(h, 0));
     CHK(mlp_enqueue(h, static_cast<const float*>(d_q), nq, L, d_order, nullptr));
     softmax_ranked_kernel<<<cdiv(nq, 64), 64, 0, h->stream>>>(h->logits.as<float>(), d_order, nq, L, d_probs);
@@ -679,6 +679,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         Q.nkeep = h->nkeep.as<int>();
         select_rescore_kernel<<<nslots, 64, 0, h->stream>>>(Q);
         HIPCHK(hipGetLastError());
+        CHK(record(h, 7));
         fallback_kernel<<<nslots, 256, 0, h->stream>>>(Q);
         HIPCHK(hipGetLastError());
         CHK(record(h, 3));
@@ -745,7 +746,7 @@ extern "C" LMI_API int lmi_scan_topk(lmi_index* h, const float* queries_search, 
         d_i = h->out_id.as<uint32_t>();
         if (keys) { CHK(h->out_key.reserve((size_t)nq * kout * 4)); d_k = h->out_key.as<uint32_t>(); }
     }
-    for (int i = 0; i < 8; ++i) h->ev_valid[i] = false;
+    for (int i = 0; i < 10; ++i) h->ev_valid[i] = false;
     CHK(record(h, 1));
     CHK(scan_enqueue(h, static_cast<const float*>(d_qs), nq, static_cast<const int*>(d_order), nb, kout, 0, d_d, d_i, d_k));
     if (!on_device) {
@@ -783,7 +784,7 @@ extern "C" LMI_API int lmi_search(lmi_index* h, const float* queries_nav, const 
         d_i = h->out_id.as<uint32_t>();
         if (keys) { CHK(h->out_key.reserve((size_t)nq * kout * 4)); d_k = h->out_key.as<uint32_t>(); }
     }
-    for (int i = 0; i < 8; ++i) h->ev_valid[i] = false;
+    for (int i = 0; i < 10; ++i) h->ev_valid[i] = false;
     CHK(record(h, 0));
     CHK(mlp_enqueue(h, static_cast<const float*>(d_qn), nq, nb, d_order, nullptr));
     CHK(record(h, 1));
@@ -890,7 +891,8 @@ extern "C" LMI_API int lmi_timings(lmi_index* h, float* ms) {
     CHK(span(3, 4, &ms[LMI_T_MERGE]));
     CHK(span(2, 5, &ms[LMI_T_PF_SAMPLE]));
     CHK(span(5, 6, &ms[LMI_T_PF_EMIT]));
-    CHK(span(6, 3, &ms[LMI_T_RESCORE]));
+    CHK(span(6, 7, &ms[LMI_T_RESCORE]));
+    CHK(span(7, 3, &ms[LMI_T_FALLBACK]));
     int first = h->ev_valid[0] ? 0 : 1;
     int last = h->ev_valid[4] ? 4 : 1;
     CHK(span(first, last, &ms[LMI_T_TOTAL]));
