@@ -23,6 +23,10 @@
 #pragma once
 #include "lmi_kernels.h"
 
+#ifndef LMI_PF_REGSTAGE
+#define LMI_PF_DMA 1  // default: LDS-DMA ring of 3 stages; -DLMI_PF_REGSTAGE selects the one-stage register pipeline
+#endif
+
 namespace lmi {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -159,8 +163,11 @@ __global__ void slot_bound_kernel(const int* __restrict__ bucket_order, const in
 
 // ------------------------------------------------------------------------------------------------
 // Prefilter kernels: fp16 operands, 256 x 128 block tile (wave = 64 vectors x 128 queries, 8
-// accumulator tiles), A straight to VGPRs, B through two 8-KiB LDS buffers, one barrier per
-// 32-wide k-stage.  Two passes over the same code (template SAMPLE):
+// accumulator tiles), both operands by LDS-DMA into a ring of three 24-KiB stages (32 k each), one
+// barrier per stage, stage u+2 in flight while stage u computes.  (A/B on MI355X, 10M x 768: the
+// one-stage register pipeline kept for -DLMI_PF_REGSTAGE spent 71 % of its wave time parked on
+// waits -- an fp16 stage is 8x shorter than an f32 one, shorter than the memory latency; the ring
+// is 25 % faster.)  Two passes over the same code (template SAMPLE):
 //   pass 1 (SAMPLE):  PF_PARTS items per (bucket, query tile) scan every PF_SAMPLE-th 256-row tile of
 //                     the whole bucket (part p takes sampled tiles p, p+PF_PARTS, ..) with per-lane
 //                     VALUES-ONLY top-10 lists, merge the 8 lists of a column and store the part's 10
@@ -210,6 +217,10 @@ struct PreItem {
     const PrefilterParams& P;
     uint4* sB0;
     uint4* sB1;  // two distinct __shared__ arrays [4 col-blocks][PF_STAGE_G][64] uint4 = 8 KiB each
+#ifdef LMI_PF_DMA
+    uint4* sB2;  // third B buffer and three A buffers [4 waves][PF_RB][PF_STAGE_G][64]: LDS-DMA ring of 3 stages
+    uint4 *sA0, *sA1, *sA2;
+#endif
     int lane, w, h, c;
     float lv[NLIST][KPB];   // pass 1 only
     float thr[NCB];         // pass 2: bound - 2 eps' of this lane's column in col-block n
@@ -235,6 +246,43 @@ struct PreItem {
             }
         }
     }
+
+#ifdef LMI_PF_DMA
+    template <int SLOT>
+    __device__ __forceinline__ void issue_dma(const uint4* ap0, const uint4* ap1, const uint4* qp) {
+        uint4* sA = SLOT == 0 ? sA0 : SLOT == 1 ? sA1 : sA2;
+        uint4* sB = SLOT == 0 ? sB0 : SLOT == 1 ? sB1 : sB2;
+#pragma unroll
+        for (int g = 0; g < PF_STAGE_G; ++g) {
+            glds16(reinterpret_cast<const float4*>(ap0 + g * 64), reinterpret_cast<float4*>(sA + ((w * PF_RB + 0) * PF_STAGE_G + g) * 64));
+            glds16(reinterpret_cast<const float4*>(ap1 + g * 64), reinterpret_cast<float4*>(sA + ((w * PF_RB + 1) * PF_STAGE_G + g) * 64));
+            glds16(reinterpret_cast<const float4*>(qp + g * 64), reinterpret_cast<float4*>(sB + (w * PF_STAGE_G + g) * 64));
+        }
+    }
+
+    template <int SLOT>
+    __device__ __forceinline__ void compute_dma() {
+        const uint4* sA = (SLOT == 0 ? sA0 : SLOT == 1 ? sA1 : sA2) + (w * PF_RB) * PF_STAGE_G * 64 + lane;
+        const uint4* sB = (SLOT == 0 ? sB0 : SLOT == 1 ? sB1 : sB2) + lane;
+#pragma unroll
+        for (int g = 0; g < PF_STAGE_G; ++g) {
+            half8 bq[NCB];
+#pragma unroll
+            for (int n = 0; n < NCB; ++n) {
+                const uint4 t = sB[(n * PF_STAGE_G + g) * 64];
+                bq[n] = *reinterpret_cast<const half8*>(&t);
+            }
+#pragma unroll
+            for (int j = 0; j < PF_RB; ++j) {
+                const uint4 ta = sA[(j * PF_STAGE_G + g) * 64];
+                const half8 av = *reinterpret_cast<const half8*>(&ta);
+#pragma unroll
+                for (int n = 0; n < NCB; ++n)
+                    acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bq[n], acc[j][n], 0, 0, 0);
+            }
+        }
+    }
+#endif
 
     __device__ __forceinline__ void epilogue(int rb_tile0, int n_b, size_t col0, int m_left) {
 #pragma unroll
@@ -312,6 +360,48 @@ struct PreItem {
         const uint4* ap0 = aslab + (size_t)min(rb_in_b0 + w * PF_RB + 0, rb_last) * rb_stride;
         const uint4* ap1 = aslab + (size_t)min(rb_in_b0 + w * PF_RB + 1, rb_last) * rb_stride;
         const uint4* qp = bbase;
+#ifdef LMI_PF_DMA
+        // LDS-DMA ring, 3 stages: stage u+2 is issued while stage u computes, so a load has two stage
+        // times to land (the one-stage register pipeline left 71 % of the wave time parked on waits).
+        // Every wave issues exactly 6 DMAs per stage (waves w >= NCB stage a duplicate col-block into
+        // an unused slot) and the stream never stops (past the end the last stage is re-loaded), so
+        // "stage u has landed" is the constant `s_waitcnt vmcnt(6)`: only stage u+1's may be pending.
+#define PF_ADVANCE                                                                                \
+        if (t_n + 1 < NS) { ++t_n; ap0 += PF_STAGE_G * 64; ap1 += PF_STAGE_G * 64; qp += PF_STAGE_G * 64; } \
+        else if (vt_n + 1 < nvt) {                                                                \
+            ++vt_n; t_n = 0; qp = bbase;                                                          \
+            ap0 = aslab + (size_t)min(rb_in_b0 + (vt_n * TSTEP * 4 + w) * PF_RB + 0, rb_last) * rb_stride; \
+            ap1 = aslab + (size_t)min(rb_in_b0 + (vt_n * TSTEP * 4 + w) * PF_RB + 1, rb_last) * rb_stride; \
+        }
+#define PF_STEP(SLOT)                                                                             \
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                          \
+        __builtin_amdgcn_s_barrier();                                                             \
+        issue_dma<(SLOT + 2) % 3>(ap0, ap1, qp);                                                  \
+        PF_ADVANCE                                                                                \
+        compute_dma<SLOT>();                                                                      \
+        if (++t_c == NS) {                                                                        \
+            epilogue(rb_in_b0 + vt_c * TSTEP * 4 * PF_RB, n_b, col0, m_left);                     \
+            t_c = 0; ++vt_c;                                                                      \
+        }
+        const int total = nvt * NS;
+        if (total > 0) {
+            issue_dma<0>(ap0, ap1, qp);
+            PF_ADVANCE
+            issue_dma<1>(ap0, ap1, qp);
+            PF_ADVANCE
+        }
+        for (int u = 0; u < total; u += 3) {
+            PF_STEP(0)
+            if (u + 1 >= total) break;
+            PF_STEP(1)
+            if (u + 2 >= total) break;
+            PF_STEP(2)
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the look-ahead before the LDS is reused
+        __syncthreads();
+#undef PF_STEP
+#undef PF_ADVANCE
+#else
         uint4 x[PF_RB][PF_STAGE_G], y[PF_RB][PF_STAGE_G], z[PF_STAGE_G];
 #define PF_LOAD(A)                                                                                \
     {                                                                                             \
@@ -357,6 +447,7 @@ struct PreItem {
 #undef PF_LOAD
 #undef PF_STORE_B
 #undef PF_FINISH_STAGE
+#endif
         if (!SAMPLE) return;
         // ---- pass 1: bound[col] = 10th best of the sample; the 8 (wave, half) value lists of a
         //      column are merged in two rounds of 4 lists (5 KiB in sB0) + a carried list (sB1) ----
@@ -440,6 +531,15 @@ template <bool SAMPLE>
 __global__ __launch_bounds__(256, 2) void prefilter_kernel(PrefilterParams P) {
     __shared__ __attribute__((aligned(16))) uint4 sB0[4 * PF_STAGE_G * 64];
     __shared__ __attribute__((aligned(16))) uint4 sB1[4 * PF_STAGE_G * 64];
+#ifdef LMI_PF_DMA
+    __shared__ __attribute__((aligned(16))) uint4 sB2[4 * PF_STAGE_G * 64];
+    __shared__ __attribute__((aligned(16))) uint4 sA0[4 * PF_RB * PF_STAGE_G * 64];
+    __shared__ __attribute__((aligned(16))) uint4 sA1[4 * PF_RB * PF_STAGE_G * 64];
+    __shared__ __attribute__((aligned(16))) uint4 sA2[4 * PF_RB * PF_STAGE_G * 64];
+#define PF_ITEM_ARGS P, sB0, sB1, sB2, sA0, sA1, sA2
+#else
+#define PF_ITEM_ARGS P, sB0, sB1
+#endif
     int* s_item = reinterpret_cast<int*>(sB1);
     int grp = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & (NGRP - 1));
     for (;;) {
@@ -490,10 +590,10 @@ __global__ __launch_bounds__(256, 2) void prefilter_kernel(PrefilterParams P) {
         const int qt = SAMPLE ? local / PF_PARTS : local % nqt, ch = SAMPLE ? local % PF_PARTS : local / nqt;
         const int ncb = min(4, (m_b - qt * TILE_COLS + 31) >> 5);
         switch (ncb) {
-            case 1: { PreItem<1, SAMPLE> it{P, sB0, sB1}; it.run(b, qt, ch); break; }
-            case 2: { PreItem<2, SAMPLE> it{P, sB0, sB1}; it.run(b, qt, ch); break; }
-            case 3: { PreItem<3, SAMPLE> it{P, sB0, sB1}; it.run(b, qt, ch); break; }
-            default: { PreItem<4, SAMPLE> it{P, sB0, sB1}; it.run(b, qt, ch); break; }
+            case 1: { PreItem<1, SAMPLE> it{PF_ITEM_ARGS}; it.run(b, qt, ch); break; }
+            case 2: { PreItem<2, SAMPLE> it{PF_ITEM_ARGS}; it.run(b, qt, ch); break; }
+            case 3: { PreItem<3, SAMPLE> it{PF_ITEM_ARGS}; it.run(b, qt, ch); break; }
+            default: { PreItem<4, SAMPLE> it{PF_ITEM_ARGS}; it.run(b, qt, ch); break; }
         }
     }
 }
