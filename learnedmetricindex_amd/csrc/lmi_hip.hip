@@ -677,7 +677,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         Q.rank_id = h->rank_id.as<unsigned>();
         Q.fallback = h->fallback.as<int>();
         Q.nkeep = h->nkeep.as<int>();
-        select_rescore_kernel<<<nslots, 64, 0, h->stream>>>(Q);
+        select_rescore_kernel<<<cdiv(nslots, RS_WAVES), 64 * RS_WAVES, 0, h->stream>>>(Q);
         HIPCHK(hipGetLastError());
         CHK(record(h, 7));
         fallback_kernel<<<nslots, 256, 0, h->stream>>>(Q);

@@ -660,10 +660,17 @@ __device__ __forceinline__ void write_rank_list(int lane, float my_s, unsigned m
     }
 }
 
-__global__ __launch_bounds__(64) void select_rescore_kernel(RescoreParams P) {
-    __shared__ unsigned keep_row[PF_KEEP];
-    __shared__ unsigned keep_n;
-    const int p = blockIdx.x, lane = threadIdx.x;
+// 4 slots per block (one wave each).  The candidates live in registers (<= 16 per lane) for the ten
+// selection passes; the query is staged in LDS once per wave; every survivor's row is streamed in
+// 128-byte pieces (8 independent 16-byte loads in flight per lane) through the k-ordered fmaf chain.
+constexpr int RS_WAVES = 4;
+constexpr int RS_MAXD = 1024;  // queries up to this many dims are staged in LDS (else read from L2)
+
+__global__ __launch_bounds__(64 * RS_WAVES) void select_rescore_kernel(RescoreParams P) {
+    __shared__ unsigned keep_row[RS_WAVES][PF_KEEP];
+    __shared__ __attribute__((aligned(16))) float qs[RS_WAVES][RS_MAXD];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int p = blockIdx.x * RS_WAVES + wv;
     if (p >= P.nslots) return;
     float* rd = P.rank_d + (size_t)p * KPB;
     unsigned* ri = P.rank_id + (size_t)p * KPB;
@@ -676,21 +683,37 @@ __global__ __launch_bounds__(64) void select_rescore_kernel(RescoreParams P) {
     }
     const unsigned cnt = P.cand_cnt[col];
     if (cnt > (unsigned)PF_CAP) {
-        if (lane == 0) { P.fallback[p] = 1; P.nkeep[p] = 0; }
+        if (lane == 0) P.fallback[p] = 1;
         return;
     }
+    // stage the query (coalesced) while the candidates load
+    const float* qg = P.q + (size_t)(p / P.nb) * P.d;
+    const bool q_lds = P.d <= RS_MAXD;
+    if (q_lds)
+        for (int k = lane; k < P.d; k += 64) qs[wv][k] = qg[k];
     const float* cs = P.cand_s + (size_t)col * PF_CAP;
     const unsigned* cr = P.cand_row + (size_t)col * PF_CAP;
-    // That: 10 selection passes in (value desc, position asc) order
+    constexpr int PER = PF_CAP / 64;
+    float cv[PER];
+    unsigned cw[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int e = lane + 64 * i;
+        cv[i] = e < (int)cnt ? cs[e] : -INFINITY;
+        cw[i] = e < (int)cnt ? cr[e] : NOROW;
+    }
+    // That: 10 selection passes in (value desc, position asc) order, all in registers
     float pv = INFINITY;
     int pi = -1;
     for (int t = 0; t < KPB; ++t) {
         float bv = -INFINITY;
         int bi = 0x7fffffff;
-        for (int e = lane; e < (int)cnt; e += 64) {
-            const float v = cs[e];
-            const bool after = (v < pv) || (v == pv && e > pi);
-            if (after && (v > bv || (v == bv && e < bi))) { bv = v; bi = e; }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = lane + 64 * i;
+            const bool live = e < (int)cnt;
+            const bool after = (cv[i] < pv) || (cv[i] == pv && e > pi);
+            if (live && after && (cv[i] > bv || (cv[i] == bv && e < bi))) { bv = cv[i]; bi = e; }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -702,28 +725,52 @@ __global__ __launch_bounds__(64) void select_rescore_kernel(RescoreParams P) {
         pi = bi;
     }
     const float cut = pv - P.eps2[col];
-    if (lane == 0) keep_n = 0;
-    __syncthreads();
-    for (int e = lane; e < (int)cnt; e += 64) {
-        if (cs[e] >= cut) {
-            const unsigned k = atomicAdd(&keep_n, 1u);
-            if (k < (unsigned)PF_KEEP) keep_row[k] = cr[e];
+    // survivors -> keep_row[] (order is irrelevant: the final sort is by (score, row))
+    unsigned nk = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const bool keep = (lane + 64 * i) < (int)cnt && cv[i] >= cut;
+        const unsigned long long bal = __ballot(keep);
+        if (keep) {
+            const unsigned k = nk + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+            if (k < (unsigned)PF_KEEP) keep_row[wv][k] = cw[i];
         }
+        nk += (unsigned)__popcll(bal);
     }
-    __syncthreads();
-    const unsigned nk = keep_n;
     if (nk > (unsigned)PF_KEEP) {
-        if (lane == 0) { P.fallback[p] = 1; P.nkeep[p] = 0; }
+        if (lane == 0) P.fallback[p] = 1;
         return;
     }
     if (lane == 0) P.nkeep[p] = (int)nk;
+    // qs[wv] / keep_row[wv] are private to this wave (other waves of the block may have returned):
+    // LDS is in-order per wave, a wave-level fence is all that is needed
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     const int b = P.bucket_order[p];
     const int rb0 = P.rb_start[b], n_b = P.nb_rows[b];
     float s = -INFINITY;
     unsigned row = NOROW;
     if (lane < (int)nk) {
-        row = keep_row[lane];
-        s = exact_score(P.rows, (size_t)rb0 * 32 + row, P.q + (size_t)(p / P.nb) * P.d, P.d);
+        row = keep_row[wv][lane];
+        const float* x = P.rows + ((size_t)rb0 * 32 + row) * P.d;
+        const float* qv = q_lds ? qs[wv] : qg;
+        float acc = 0.0f;
+        int k = 0;
+        if ((P.d & 3) == 0) {
+            for (; k + 32 <= P.d; k += 32) {  // 8 independent 16-byte loads in flight, then 32 chained fmas
+                float4 xv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) xv[i] = *reinterpret_cast<const float4*>(x + k + 4 * i);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float4 qq = *reinterpret_cast<const float4*>(qv + k + 4 * i);
+                    acc = __builtin_fmaf(qq.x, xv[i].x, acc); acc = __builtin_fmaf(qq.y, xv[i].y, acc);
+                    acc = __builtin_fmaf(qq.z, xv[i].z, acc); acc = __builtin_fmaf(qq.w, xv[i].w, acc);
+                }
+            }
+        }
+        for (; k < P.d; ++k) acc = __builtin_fmaf(qv[k], x[k], acc);
+        s = acc;
     }
     // 10 best by (score desc, row asc)
     float my_s = -INFINITY;
