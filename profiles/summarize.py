@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condenses rocprofv3 output (gpurun_out/prof_rNN/) into the small files committed under profiles/.
 
-  python profiles/summarize.py gpurun_out/prof_r01 r01
+  python profiles/summarize.py gpurun_out/prof_r01 r01 [dominant-kernel-substring]
 
 Writes profiles/<tag>_kernel_stats.csv (top kernels by total time, names shortened),
 profiles/<tag>_scan_pmc.json (per-launch FETCH_SIZE / WRITE_SIZE of lmi::scan_kernel and the HBM
@@ -21,7 +21,17 @@ def one(pattern):
     return files[0] if files else None
 
 
-def main(src, tag):
+DOMINANT = "lmi::scan_kernel("
+
+
+def is_dom(name):
+    return DOMINANT in name
+
+
+def main(src, tag, dominant=None):
+    global DOMINANT
+    if dominant:
+        DOMINANT = dominant
     out_dir = os.path.dirname(os.path.abspath(__file__))
     stats = one(os.path.join(src, "trace", "**", "*_kernel_stats.csv"))
     if stats:
@@ -39,7 +49,7 @@ def main(src, tag):
             continue
         vals, durs, meta = [], [], None
         for r in csv.DictReader(open(f)):
-            if r["Kernel_Name"].startswith("lmi::scan_kernel(") and r["Counter_Name"] == name:
+            if is_dom(r["Kernel_Name"]) and r["Counter_Name"] == name:
                 vals.append(float(r["Counter_Value"]))
                 durs.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
                 meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count",
@@ -55,7 +65,7 @@ def main(src, tag):
             continue
         acc = {}
         for r in csv.DictReader(open(f)):
-            if r["Kernel_Name"].startswith("lmi::scan_kernel("):
+            if is_dom(r["Kernel_Name"]):
                 acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
         for k, v in acc.items():
             extra[k] = sum(v) / len(v)
@@ -72,10 +82,11 @@ def main(src, tag):
         pmc["hbm_bytes_per_launch"] = fetch + write
         pmc["note"] = ("(2 * FETCH_SIZE + WRITE_SIZE) KiB -> bytes; FETCH_SIZE counts L2 misses, Infinity-Cache "
                        "hits included, so this is an upper bound on true HBM reads")
+    pmc["kernel"] = DOMINANT
     with open(os.path.join(out_dir, f"{tag}_scan_pmc.json"), "w") as fh:
         json.dump(pmc, fh, indent=1)
     print(json.dumps(pmc, indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
