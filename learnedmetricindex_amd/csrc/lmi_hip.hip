@@ -424,14 +424,24 @@ static int mlp_enqueue(lmi_index* h, const float* d_q, int nq, int nb, int* d_or
     const float4* in = h->xfrag.as<float4>();
     for (int i = 0; i < h->n_layers; ++i) {
         const bool last = i + 1 == h->n_layers;
-        dim3 grid(cdiv(ncb, 4), cdiv(h->n_rb[i], 4));
+        // few feature blocks (e.g. the 120-class output layer: 4) -> one col-block per wave, 4x the blocks
+        const bool narrow = cdiv(h->n_rb[i], 4) * cdiv(ncb, 4) < h->num_cus;
+        dim3 grid(narrow ? ncb : cdiv(ncb, 4), cdiv(h->n_rb[i], 4));
         if (last) {
-            mlp_layer_kernel<true><<<grid, 256, 0, h->stream>>>(h->Wf[i].as<float4>(), h->bias[i].as<float>(), in,
-                                                               h->KG[i], h->n_rb[i], ncb, d_logits, 0, nq, L);
+            if (narrow)
+                mlp_layer_kernel<true, 1><<<grid, 256, 0, h->stream>>>(h->Wf[i].as<float4>(), h->bias[i].as<float>(), in,
+                                                                      h->KG[i], h->n_rb[i], ncb, d_logits, 0, nq, L);
+            else
+                mlp_layer_kernel<true, 4><<<grid, 256, 0, h->stream>>>(h->Wf[i].as<float4>(), h->bias[i].as<float>(), in,
+                                                                      h->KG[i], h->n_rb[i], ncb, d_logits, 0, nq, L);
         } else {
             float* o = h->act[i & 1].as<float>();
-            mlp_layer_kernel<false><<<grid, 256, 0, h->stream>>>(h->Wf[i].as<float4>(), h->bias[i].as<float>(), in,
-                                                                h->KG[i], h->n_rb[i], ncb, o, h->n_rb[i] * 4, nq, L);
+            if (narrow)
+                mlp_layer_kernel<false, 1><<<grid, 256, 0, h->stream>>>(h->Wf[i].as<float4>(), h->bias[i].as<float>(), in,
+                                                                       h->KG[i], h->n_rb[i], ncb, o, h->n_rb[i] * 4, nq, L);
+            else
+                mlp_layer_kernel<false, 4><<<grid, 256, 0, h->stream>>>(h->Wf[i].as<float4>(), h->bias[i].as<float>(), in,
+                                                                       h->KG[i], h->n_rb[i], ncb, o, h->n_rb[i] * 4, nq, L);
             in = reinterpret_cast<const float4*>(o);
         }
         HIPCHK(hipGetLastError());
@@ -557,7 +567,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     HIPCHK(hipGetLastError());
     route_scan_kernel<<<1, 256, 0, h->stream>>>(L, R);
     HIPCHK(hipGetLastError());
-    route_group_kernel<<<1, 1024, 0, h->stream>>>(L, R);
+    route_group_kernel<<<1, 1024, (size_t)L * 20, h->stream>>>(L, R);
     HIPCHK(hipGetLastError());
     route_fill_kernel<<<cdiv(nslots, 256), 256, 0, h->stream>>>(d_order, h->slot_local.as<int>(), nslots, nb,
                                                                R.cb_start, h->colmap.as<int>(), h->slot_col.as<int>());
@@ -611,7 +621,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         HIPCHK(hipMemsetAsync(h->qmaxbits.p, 0, 16, h->stream));
         HIPCHK(hipMemsetAsync(h->cand_cnt.p, 0, ncols * 4, h->stream));
         HIPCHK(hipMemsetAsync(h->stats.as<long long>() + 2, 0, 16, h->stream));
-        query_norm_kernel<<<cdiv(nq, 64), 64, 0, h->stream>>>(d_qs, nq, h->d, h->qnorm.as<float>(), h->qmaxbits.as<unsigned>());
+        query_norm_kernel<<<cdiv(nq, 4), 256, 0, h->stream>>>(d_qs, nq, h->d, h->qnorm.as<float>(), h->qmaxbits.as<unsigned>());
         HIPCHK(hipGetLastError());
         make_scale_kernel<<<1, 1, 0, h->stream>>>(h->qmaxbits.as<unsigned>(), h->qscale.as<float>());
         HIPCHK(hipGetLastError());

@@ -100,12 +100,13 @@ __global__ void unpack_kernel(const float4* __restrict__ src, int KG, long long 
 // MLP layer:  Y^T = W . X^T + b  (ReLU unless last).   model.py:45-49, 97-99, 232
 //   Wf   [n_rb][KG][64]  weights, rows = output features (padded with zero rows)
 //   Xf   [ncb][KG][64]   activations, "rows" = queries
-//   grid (ceil(ncb/4), ceil(n_rb/4)), block 256: wave w -> feature block blockIdx.y*4+w, 4 col-blocks.
+//   grid (ceil(ncb/CBW), ceil(n_rb/4)), block 256: wave w -> feature block blockIdx.y*4+w, CBW col-blocks
+//   (CBW = 4, or 1 when the layer has few feature blocks and would otherwise fill a third of the CUs).
 //   Accumulators start at the bias (torch addmm starts from the bias): chain = b + sum_k.
 //   !LAST: output written as the next layer's fragment-major activations (KGn = n_rb_pad*4 groups).
 //    LAST: logits row-major [nq][L].
 // ------------------------------------------------------------------------------------------------
-template <bool LAST>
+template <bool LAST, int CBW = 4>
 __global__ __launch_bounds__(256) void mlp_layer_kernel(const float4* __restrict__ Wf,
                                                         const float* __restrict__ bias,
                                                         const float4* __restrict__ Xf, int KG, int n_rb,
@@ -113,39 +114,39 @@ __global__ __launch_bounds__(256) void mlp_layer_kernel(const float4* __restrict
                                                         int nq, int L) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = lane >> 5, c = lane & 31;
     const int rb = blockIdx.y * 4 + w;
-    const int cb0 = blockIdx.x * 4;
+    const int cb0 = blockIdx.x * CBW;
     if (rb >= n_rb) return;
-    f32x16 acc[4];
+    f32x16 acc[CBW];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         float bv = bias[rb * 32 + acc_row(r, h)];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[n][r] = bv;
+        for (int n = 0; n < CBW; ++n) acc[n][r] = bv;
     }
     const float4* ap = Wf + (size_t)rb * KG * 64 + lane;
-    const float4* bp[4];
+    const float4* bp[CBW];
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
+    for (int n = 0; n < CBW; ++n) {
         int cb = cb0 + n < ncb ? cb0 + n : ncb - 1;  // clamp: duplicates are computed and discarded
         bp[n] = Xf + (size_t)cb * KG * 64 + lane;
     }
     for (int g = 0; g < KG; ++g) {
         float4 a = ap[(size_t)g * 64];
-        float4 b[4];
+        float4 b[CBW];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) b[n] = bp[n][(size_t)g * 64];
+        for (int n = 0; n < CBW; ++n) b[n] = bp[n][(size_t)g * 64];
         const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
+            for (int n = 0; n < CBW; ++n) {
                 const float bv = s == 0 ? b[n].x : s == 1 ? b[n].y : s == 2 ? b[n].z : b[n].w;
                 acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv, acc[n], 0, 0, 0);
             }
         }
     }
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
+    for (int n = 0; n < CBW; ++n) {
         const int cb = cb0 + n;
         if (cb >= ncb) continue;
         const int q = cb * 32 + c;
@@ -262,14 +263,32 @@ struct RouteArrays {
     int* qt_base;         // [L+1] prefix of the buckets' query-tile counts (prefilter pass-1 items)
 };
 
-__global__ void route_count_kernel(const int* __restrict__ bucket_order, int nslots, int L, RouteArrays R,
-                                   int* __restrict__ slot_local) {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= nslots) return;
-    int b = bucket_order[p];
-    int loc = -1;
-    if (b >= 0 && b < L && R.nb_rows[b] > 0) loc = atomicAdd(&R.m[b], 1);
-    slot_local[p] = loc;
+// Positions are handed out per block through an LDS histogram (one global atomic per bucket and
+// block instead of one per slot: 40 000 returning atomics on 120 hot words took 66 us).
+constexpr int ROUTE_LDS_BUCKETS = 4096;
+__global__ __launch_bounds__(256) void route_count_kernel(const int* __restrict__ bucket_order, int nslots, int L,
+                                                          RouteArrays R, int* __restrict__ slot_local) {
+    __shared__ int cnt_s[ROUTE_LDS_BUCKETS];
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    int b = -1;
+    if (p < nslots) {
+        b = bucket_order[p];
+        if (!(b >= 0 && b < L && R.nb_rows[b] > 0)) b = -1;
+    }
+    if (L > ROUTE_LDS_BUCKETS) {  // huge fan-out: plain global atomics
+        if (p < nslots) slot_local[p] = b >= 0 ? atomicAdd(&R.m[b], 1) : -1;
+        return;
+    }
+    for (int i = threadIdx.x; i < L; i += blockDim.x) cnt_s[i] = 0;
+    __syncthreads();
+    const int loc = b >= 0 ? atomicAdd(&cnt_s[b], 1) : 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < L; i += blockDim.x) {
+        const int c = cnt_s[i];
+        cnt_s[i] = c > 0 ? atomicAdd(&R.m[i], c) : 0;  // block's base position in bucket i
+    }
+    __syncthreads();
+    if (p < nslots) slot_local[p] = b >= 0 ? cnt_s[b] + loc : -1;
 }
 
 __global__ __launch_bounds__(256) void route_scan_kernel(int L, RouteArrays R) {
@@ -321,20 +340,34 @@ __global__ __launch_bounds__(256) void route_scan_kernel(int L, RouteArrays R) {
 // vectors are fetched once for all of its query tiles.  Heaviest buckets first (LPT) balances the
 // queues; blocks of a drained queue steal from the others, so placement only affects speed.
 __global__ __launch_bounds__(1024) void route_group_kernel(int L, RouteArrays R) {
+    // dynamic LDS: m[L], items[L], order[L] ints + work[L] long long (the serial LPT below then
+    // never waits on global memory: 100 us -> a few us at L = 120)
+    extern __shared__ __attribute__((aligned(16))) char grp_smem[];
+    long long* work_s = reinterpret_cast<long long*>(grp_smem);
+    int* m_s = reinterpret_cast<int*>(work_s + L);
+    int* items_s = m_s + L;
+    int* order_s = items_s + L;
     const int t = threadIdx.x;
-    // rank of every bucket by (work desc, id asc); work = item count x rows is a fine proxy
     for (int b = t; b < L; b += 1024) {
-        const long long wb = (long long)R.m[b] * R.nb_rows[b];
+        const int m = R.m[b];
+        m_s[b] = m;
+        work_s[b] = (long long)m * R.nb_rows[b];
+        items_s[b] = ((m + TILE_COLS - 1) / TILE_COLS) * R.nch[b];
+    }
+    __syncthreads();
+    // rank of every bucket by (work desc, id asc); work = queries x rows is a fine proxy
+    for (int b = t; b < L; b += 1024) {
+        const long long wb = work_s[b];
         int rank = 0;
         for (int o = 0; o < L; ++o) {
-            const long long wo = (long long)R.m[o] * R.nb_rows[o];
+            const long long wo = work_s[o];
             rank += (wo > wb) || (wo == wb && o < b);
         }
-        R.order_tmp[rank] = b;
+        order_s[rank] = b;
     }
-    if (t == 1) {  // query-tile prefix in bucket order (one thread; L is small)
+    if (t == 1) {  // query-tile prefix in bucket order (prefilter pass-1 items)
         int q = 0;
-        for (int b = 0; b < L; ++b) { R.qt_base[b] = q; q += (R.m[b] + TILE_COLS - 1) / TILE_COLS; }
+        for (int b = 0; b < L; ++b) { R.qt_base[b] = q; q += (m_s[b] + TILE_COLS - 1) / TILE_COLS; }
         R.qt_base[L] = q;
     }
     __syncthreads();
@@ -343,18 +376,16 @@ __global__ __launch_bounds__(1024) void route_group_kernel(int L, RouteArrays R)
         int cnt[NGRP], items[NGRP];
         for (int g = 0; g < NGRP; ++g) { load[g] = 0; cnt[g] = 0; items[g] = 0; R.grp_base[g * (L + 1)] = 0; }
         for (int i = 0; i < L; ++i) {
-            const int b = R.order_tmp[i];
-            const int m = R.m[b];
-            if (m == 0) break;  // sorted by work: nothing but idle buckets from here on
+            const int b = order_s[i];
+            if (m_s[b] == 0) break;  // sorted by work: nothing but idle buckets from here on
             int g = 0;
             for (int o = 1; o < NGRP; ++o)
                 if (load[o] < load[g]) g = o;
-            const int it = ((m + TILE_COLS - 1) / TILE_COLS) * R.nch[b];
             R.grp_bucket[g * L + cnt[g]] = b;
-            items[g] += it;
+            items[g] += items_s[b];
             cnt[g] += 1;
             R.grp_base[g * (L + 1) + cnt[g]] = items[g];
-            load[g] += (long long)m * R.nb_rows[b];
+            load[g] += work_s[b];
         }
         for (int g = 0; g < NGRP; ++g) { R.grp_n[g] = cnt[g]; R.grp_total[g] = items[g]; }
     }
