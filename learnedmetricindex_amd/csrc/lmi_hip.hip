@@ -97,6 +97,7 @@ struct lmi_index {
     DevBuf stage;  // H2D staging for add_rows / host query uploads
     // ---- fp16 prefilter (lmi_prefilter.h) ----
     bool prefilter = true;   // lmi_set_prefilter
+    bool pf_hw_ok = false;   // fp16 subnormal self-test passed on this device
     bool have16 = false;     // slab16 built by lmi_buckets_end
     int KG16 = 0;
     DevBuf slab16, rowmajor, xscale, xmaxbits, bnorm;
@@ -139,6 +140,21 @@ extern "C" LMI_API int lmi_create(int device, lmi_index** out) {
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_kernel, 256, SCAN_LDS));
     h->scan_blocks_per_cu = std::max(1, std::min(occ, RB == 1 ? 2 : 1));
     for (int i = 0; i < 10; ++i) HIPCHK(hipEventCreate(&h->ev[i]));
+    {   // fp16 subnormal self-test (lmi_prefilter.h): the error bound of the prefilter relies on it
+        static int cached = -1;  // per process; every MI355X behaves the same
+        if (cached < 0) {
+            int* d_ok = nullptr;
+            int ok = 0;
+            HIPCHK(hipMalloc(&d_ok, sizeof(int)));
+            pf_selftest_kernel<<<1, 64>>>(d_ok);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpy(&ok, d_ok, sizeof(int), hipMemcpyDeviceToHost));
+            HIPCHK(hipFree(d_ok));
+            cached = ok;
+        }
+        h->pf_hw_ok = cached == 1;
+        if (!h->pf_hw_ok) h->prefilter = false;
+    }
     *out = h;
     return 0;
 }
@@ -179,6 +195,7 @@ extern "C" LMI_API int lmi_set_prefilter(lmi_index* h, int on) {
     if (!h) return fail("lmi_set_prefilter: NULL handle");
     if ((h->built || h->building) && (on != 0) != h->prefilter)
         return fail("lmi_set_prefilter: the mode is fixed once lmi_buckets_begin has run (the index is stored differently)");
+    if (on && !h->pf_hw_ok) return fail("lmi_set_prefilter: fp16 subnormal self-test failed on this device; the prefilter's error bound does not hold");
     h->prefilter = on != 0;
     return 0;
 }

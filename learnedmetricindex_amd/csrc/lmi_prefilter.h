@@ -110,6 +110,32 @@ __global__ void bucket_norm_kernel(const float* __restrict__ rows, int d, const 
     if (best > 0.0f) atomicMax(bnorm_bits + b, __float_as_uint(best));
 }
 
+// ---- hardware self-test: the bound assumes that fp16 SUBNORMAL operands enter the MFMA and the
+//      f32 -> f16 conversion un-flushed (|q^ - q'| <= u|q'| + 2^-25).  One wave multiplies subnormal
+//      A values (j+1)*2^-24 by B = 1024 over k = 0..15 and compares with the exact sum; lmi_create
+//      runs it once and the prefilter is only enabled when it passes. ----
+__global__ void pf_selftest_kernel(int* __restrict__ ok) {
+    const int lane = threadIdx.x;
+    half8 a, b;
+    float expect = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float tiny = (float)(8 * (lane >> 5) + j + 1) * 5.9604644775390625e-8f;  // (k+1) * 2^-24
+        a[j] = (_Float16)tiny;       // conversion must keep the subnormal
+        b[j] = (_Float16)1024.0f;
+    }
+    for (int k = 0; k < 16; ++k) expect += (float)(k + 1) * 5.9604644775390625e-8f * 1024.0f;  // exact in binary32
+    f32x16 c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = 0.0f;
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    bool good = true;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) good = good && (c[r] == expect);
+    const unsigned long long all = __ballot(good);
+    if (lane == 0) *ok = (all == ~0ull) ? 1 : 0;
+}
+
 // ---- per batch: query scale, norms, fp16 packing, per-slot bound ---------------------------------
 __global__ __launch_bounds__(256) void query_norm_kernel(const float* __restrict__ q, int nq, int d,
                                                          float* __restrict__ qnorm, unsigned* __restrict__ maxbits) {
@@ -175,7 +201,10 @@ __global__ void slot_bound_kernel(const int* __restrict__ bucket_order, const in
 //                     inter-item traffic: every row with shat >= bound[col] - 2 eps' is appended to
 //                     the slot's candidate buffer.  About 10 * PF_SAMPLE rows per slot pass.
 // ------------------------------------------------------------------------------------------------
-constexpr int PF_SAMPLE = 16;  // pass 1 looks at every 16th tile ...
+#ifndef LMI_PF_SAMPLE
+#define LMI_PF_SAMPLE 16
+#endif
+constexpr int PF_SAMPLE = LMI_PF_SAMPLE;  // pass 1 looks at every 16th tile ...
 constexpr int PF_PARTS = 4;    // ... split over 4 items per (bucket, query tile), merged by the consumers
 
 struct PrefilterParams {
