@@ -136,6 +136,9 @@ extern "C" LMI_API int lmi_create(int device, lmi_index** out) {
     lmi_index* h = new lmi_index();
     h->device = device;
     h->num_cus = prop.multiProcessorCount;
+    // route_group_kernel stages 20 bytes per bucket in dynamic LDS (fan-outs up to 8 000 buckets)
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&route_group_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     int occ = 0;
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_kernel, 256, SCAN_LDS));
     h->scan_blocks_per_cu = std::max(1, std::min(occ, RB == 1 ? 2 : 1));
@@ -246,6 +249,7 @@ extern "C" LMI_API int lmi_buckets_begin(lmi_index* h, int64_t N, int d, int L, 
     if (!h) return fail("lmi_buckets_begin: NULL handle");
     if (N < 0 || d < 1 || L < 1 || (N > 0 && !labels)) return fail("lmi_buckets_begin: bad arguments");
     if (N >= (1ll << 31) - 64ll * L) return fail("lmi_buckets_begin: N too large for 32-bit positions");
+    if (L > 8000) return fail("lmi_buckets_begin: %d buckets exceed the 8000 the routing kernels stage in LDS", L);
     CHK(set_dev(h));
     h->N = N;
     h->d = d;

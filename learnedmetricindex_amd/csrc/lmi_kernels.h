@@ -525,26 +525,8 @@ struct ScanItem {
 #endif
     }
 
-    // the same DMA, one k-group at a time, so that it can be interleaved with the MFMAs of the
-    // running stage instead of being issued as one burst (each LDS-DMA costs ~64 issue cycles)
     template <int PAR>
-    __device__ __forceinline__ void issue_part(int u, int g) {
-#ifdef LMI_ABL_NOLOAD
-        return;
-#endif
-        float4* sA = PAR ? S.A1 : S.A0;
-        float4* sB = PAR ? S.B1 : S.B0;
-        const int vt = u / NS, t = u - vt * NS;
-#pragma unroll
-        for (int j = 0; j < RB; ++j) {
-            const int rb = min(rb_in_b0 + (vt * 4 + w) * RB + j, nrb_b - 1);
-            glds16(aslab + ((size_t)rb * KG + t * STAGE_G + g) * 64, sA + ((w * RB + j) * STAGE_G + g) * 64);
-        }
-        if (w < NCB) glds16(bbase + (size_t)(t * STAGE_G + g) * 64, sB + (w * STAGE_G + g) * 64);
-    }
-
-    template <int PAR, bool INTERLEAVE = false>
-    __device__ __forceinline__ void compute(int u, bool more = false) {  // MFMAs of stage u (parity-PAR buffers)
+    __device__ __forceinline__ void compute(int u) {  // MFMAs of stage u (parity-PAR buffers)
         const float4* sA = (PAR ? S.A1 : S.A0) + (w * RB) * STAGE_G * 64 + lane;
         const float4* sB = (PAR ? S.B1 : S.B0) + lane;
         const int vt = u / NS, t = u - vt * NS;
@@ -562,7 +544,6 @@ struct ScanItem {
 #pragma unroll
                 for (int n = 0; n < NCB; ++n) fb[nxt][n] = sB[(n * STAGE_G + g + 1) * 64];
             }
-            if (INTERLEAVE && more) issue_part<1 - PAR>(u + 1, g);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -614,12 +595,8 @@ struct ScanItem {
 
     template <int PAR>
     __device__ __forceinline__ void step(int u) {
-#ifdef LMI_DMA_INTERLEAVE
-        compute<PAR, true>(u, u + 1 < total);
-#else
         if (u + 1 < total) issue<1 - PAR>(u + 1);
         compute<PAR>(u);
-#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -709,251 +686,13 @@ struct ScanItem {
     }
 };
 
-// ------------------------------------------------------------------------------------------------
-// Register-staged scan item (alternative, -DLMI_SCAN_REGSTAGE; the LDS-DMA form above is the
-// default).  Round-1 A/B on MI355X (tools/scan_ab.py, 10M x 768, one process, interleaved rounds):
-// LDS-DMA 119.4 TFLOP/s, this form 114.2, the DMA loop with operand loads removed 141 -- every
-// 1-KiB operand load costs ~100 SIMD cycles of MFMA issue whichever way it is loaded (the cost is
-// linear in the number of loads and unchanged when every load hits L2), so neither staging
-// mechanism removes it; fewer loads per MFMA (larger wave tiles) is what would.  Here:
-//   A (this wave's 32 vectors)  global_load_dwordx4 -> VGPRs -> MFMA operand; no LDS round trip
-//                               (A is private to the wave), next stage prefetched in registers;
-//   B (the 128 queries)         global_load_dwordx4 early, ds_write_b128 late (after the stage's
-//                               MFMAs), one barrier per stage, two 16-KiB LDS buffers;
-//   top-k lists                 ONE list per (wave, column) instead of one per (lane, column): lane
-//                               half h owns col-blocks n with (n & 1) == h, the other half's
-//                               candidates cross with one __shfl_xor(.,32) -- 40 fewer VGPRs.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void list_insert_cmp(float (&v)[KPB], unsigned (&id)[KPB], float s, unsigned row) {
-    // (score desc, row asc) order; candidates may arrive in any row order
-#pragma unroll
-    for (int t = KPB - 1; t > 0; --t) {
-        const bool shift = better(s, row, v[t - 1], id[t - 1]);
-        const bool here = better(s, row, v[t], id[t]);
-        id[t] = shift ? id[t - 1] : (here ? row : id[t]);
-        v[t] = shift ? v[t - 1] : (here ? s : v[t]);
-    }
-    const bool top = better(s, row, v[0], id[0]);
-    id[0] = top ? row : id[0];
-    v[0] = top ? s : v[0];
-}
+// Alternatives measured and removed (round 1, tools/scan_ab.py, 10M x 768, interleaved in one process):
+// a register-staged item (A by global_load_dwordx4 straight to VGPRs, B via VGPR -> ds_write, one
+// list per (wave, column)) ran 114 TFLOP/s against this LDS-DMA form's 119; issuing the DMA one
+// k-group at a time between the MFMAs -3 %; RB = 2 (256 x 128 tile, one block per CU) -16 %.  With the
+// operand loads removed the loop runs 141 TFLOP/s: every 1-KiB operand load costs ~100 SIMD cycles
+// of MFMA issue whichever way it is loaded, even when it hits L2.
 
-static_assert(STAGE_G == 4, "scan_item stages four k-groups at a time");
-
-template <int NCB>
-struct ScanItemR {
-    static constexpr int NL = (NCB + 1) / 2;  // lists per lane
-    const ScanParams& P;
-    float4* sB0;
-    float4* sB1;  // two DISTINCT __shared__ arrays [4 col-blocks][STAGE_G][64]
-    int lane, w, h, c;
-    int KG, NS, n_b, nrb_b, rb_in_b0, total;
-    const float4* aslab;
-    const float4* bbase;
-    float lv[NL][KPB];
-    unsigned li[NL][KPB];
-    float gthr[NL];       // shared lower bound of the column's final 10th-best (see col_thr)
-    const float* cthr;    // &col_thr[first column of this item] + c
-    f32x16 acc[NCB];
-
-    template <int G>
-    __device__ __forceinline__ void mfma_group(const float4* sB, const float4& a) {
-        float4 bq[NCB];
-#pragma unroll
-        for (int n = 0; n < NCB; ++n) bq[n] = sB[(n * STAGE_G + G) * 64];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const float av = s == 0 ? a.x : s == 1 ? a.y : s == 2 ? a.z : a.w;
-#pragma unroll
-            for (int n = 0; n < NCB; ++n) {
-                const float bv = s == 0 ? bq[n].x : s == 1 ? bq[n].y : s == 2 ? bq[n].z : bq[n].w;
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[n], 0, 0, 0);
-            }
-        }
-    }
-
-    template <int PAR>
-    __device__ __forceinline__ void compute(int vt, int t, const float4& a0, const float4& a1,
-                                            const float4& a2, const float4& a3) {
-        const float4* sB = (PAR ? sB1 : sB0) + lane;
-        mfma_group<0>(sB, a0);
-        mfma_group<1>(sB, a1);
-        mfma_group<2>(sB, a2);
-        mfma_group<3>(sB, a3);
-        if (t == NS - 1) epilogue(vt);
-    }
-
-    // Pruning rule (exact): a score strictly below `gthr` cannot be among the bucket's 10 best for
-    // this query, because some already finished chunk of the same bucket holds 10 rows scoring
-    // >= gthr.  Equal scores are kept (the row tie-break may still favour them).
-    __device__ __forceinline__ void epilogue(int vt) {
-        const unsigned rowbase = (unsigned)((rb_in_b0 + vt * 4 + w) * 32);
-#pragma unroll
-        for (int l = 0; l < NL; ++l)
-            if (2 * l + h < NCB)
-                gthr[l] = fmaxf(gthr[l], __hip_atomic_load(cthr + (2 * l + h) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-#pragma unroll
-        for (int n = 0; n < NCB; ++n) {
-            const bool own = h == (n & 1);
-            // the column's list and bound live in the owner half; fetch them for the other half
-            const float t_own = lv[n >> 1][KPB - 1], g_own = gthr[n >> 1];
-            const float t_other = __shfl_xor(t_own, 32), g_other = __shfl_xor(g_own, 32);
-            const float thr = own ? t_own : t_other, gl = own ? g_own : g_other;
-            unsigned mask = 0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                mask |= (unsigned)(acc[n][r] > thr && acc[n][r] >= gl && rowbase + acc_row(r, h) < (unsigned)n_b) << r;
-            while (__any(mask != 0)) {  // wave-uniform; rare once a bound is known
-                const bool valid = mask != 0;
-                const int r = valid ? __builtin_ctz(mask) : 0;
-                mask &= mask - 1;
-                float s = acc[n][0];
-#pragma unroll
-                for (int i = 1; i < 16; ++i) s = (r == i) ? acc[n][i] : s;
-                s = valid ? s : -INFINITY;
-                const unsigned row = valid ? rowbase + acc_row(r, h) : NOROW;
-                const float ps = __shfl_xor(s, 32);
-                const unsigned prow = __shfl_xor(row, 32);
-                if (own) {
-                    if (better(s, row, lv[n >> 1][KPB - 1], li[n >> 1][KPB - 1])) list_insert_cmp(lv[n >> 1], li[n >> 1], s, row);
-                    if (better(ps, prow, lv[n >> 1][KPB - 1], li[n >> 1][KPB - 1])) list_insert_cmp(lv[n >> 1], li[n >> 1], ps, prow);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
-        }
-    }
-
-    __device__ __forceinline__ void run(int b, int qt, int ch) {
-        const int tid = threadIdx.x;
-        lane = tid & 63; w = tid >> 6; h = lane >> 5; c = lane & 31;
-        KG = P.KG; NS = KG / STAGE_G;
-        n_b = P.nb_rows[b];
-        nrb_b = (n_b + 31) >> 5;
-        rb_in_b0 = ch * P.chunk_rb;
-        const int nrb = min(P.chunk_rb, nrb_b - rb_in_b0);
-        const int nvt = (nrb + 3) >> 2;
-        const int cb0 = P.cb_start[b] + qt * 4;
-        aslab = P.slab + ((size_t)P.rb_start[b] * KG) * 64 + lane;
-        bbase = P.qfrag + ((size_t)(cb0 + min(w, NCB - 1)) * KG) * 64 + lane;
-        total = nvt * NS;
-        cthr = P.col_thr + (size_t)cb0 * 32 + c;
-#pragma unroll
-        for (int l = 0; l < NL; ++l) {
-            gthr[l] = -INFINITY;
-#pragma unroll
-            for (int j = 0; j < KPB; ++j) { lv[l][j] = -INFINITY; li[l][j] = NOROW; }
-        }
-#pragma unroll
-        for (int n = 0; n < NCB; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
-
-        // fragments live in plain float4 variables (aggregates passed by reference ended up in
-        // scratch): x* = A of the even stage, y* = A of the odd stage, z* = B being staged.
-        // (vt, t) of the running stage and the operand pointers of the NEXT stage are tracked
-        // incrementally: an integer division per stage cost ~100 VALU instructions per wave.
-        float4 x0, x1, x2, x3, y0, y1, y2, y3, z0, z1, z2, z3;
-        const size_t tile_stride = (size_t)KG * 64;          // float4 per row-block
-        const int rb_last = nrb_b - 1;
-        const float4* ap = aslab + (size_t)min(rb_in_b0 + w, rb_last) * tile_stride;  // stage to load next
-        const float4* qp = bbase;
-        int vt_n = 0, t_n = 0;                                // (tile, k-stage) `ap`/`qp` point at
-        int vt_c = 0, t_c = 0;                                // running stage
-#define LMI_LOAD_STAGE(A0, A1, A2, A3)                                                            \
-    {                                                                                             \
-        A0 = ap[0]; A1 = ap[64]; A2 = ap[128]; A3 = ap[192];                                      \
-        z0 = qp[0]; z1 = qp[64]; z2 = qp[128]; z3 = qp[192];                                      \
-        /* keep the 8 loads HERE: without the fence hipcc sinks them below the stage's MFMAs */   \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        /* advance to the following stage; past the end the last stage is simply re-loaded */     \
-        if (t_n + 1 < NS) { ++t_n; ap += STAGE_G * 64; qp += STAGE_G * 64; }                      \
-        else if (vt_n + 1 < nvt) {                                                                \
-            ++vt_n; t_n = 0; qp = bbase;                                                          \
-            ap = aslab + (size_t)min(rb_in_b0 + vt_n * 4 + w, rb_last) * tile_stride;             \
-        }                                                                                         \
-    }
-#define LMI_STORE_B(SB)                                                                           \
-    if (w < NCB) {                                                                                \
-        float4* sb_ = (SB) + (w * STAGE_G) * 64 + lane;                                           \
-        sb_[0] = z0; sb_[64] = z1; sb_[128] = z2; sb_[192] = z3;                                  \
-    }
-#define LMI_ADVANCE_CUR                                                                           \
-    if (++t_c == NS) { t_c = 0; ++vt_c; }
-        LMI_LOAD_STAGE(x0, x1, x2, x3)
-        LMI_STORE_B(sB0)
-        __syncthreads();
-        for (int u = 0; u < total; u += 2) {
-            LMI_LOAD_STAGE(y0, y1, y2, y3)
-            compute<0>(vt_c, t_c, x0, x1, x2, x3);
-            LMI_ADVANCE_CUR
-            LMI_STORE_B(sB1)
-            __syncthreads();
-            if (u + 1 >= total) break;
-            LMI_LOAD_STAGE(x0, x1, x2, x3)
-            compute<1>(vt_c, t_c, y0, y1, y2, y3);
-            LMI_ADVANCE_CUR
-            LMI_STORE_B(sB0)
-            __syncthreads();
-        }
-#undef LMI_LOAD_STAGE
-#undef LMI_STORE_B
-#undef LMI_ADVANCE_CUR
-
-        // ---- merge the 4 per-wave lists of every column through LDS: pass p handles col-blocks
-        //      2p (owner half 0) and 2p+1 (owner half 1); scores in sB0, rows in sB1 ----
-        float* ms = reinterpret_cast<float*>(sB0);
-        unsigned* mr = reinterpret_cast<unsigned*>(sB1);
-        const int m_b = P.m[b];
-        const int nch_b = P.nch[b];
-        const long long pbase = P.part_base[b];
-#pragma unroll
-        for (int pass = 0; pass < NL; ++pass) {
-            if (pass * 2 + h < NCB) {
-                const int o = ((h * 32 + c) * 4 + w) * KPB;
-#pragma unroll
-                for (int j = 0; j < KPB; ++j) { ms[o + j] = lv[pass][j]; mr[o + j] = li[pass][j]; }
-            }
-            __syncthreads();
-            if (tid < 64) {
-                const int n = pass * 2 + h;  // tid < 64: h = tid >> 5, c = tid & 31
-                const int col_in_b = qt * TILE_COLS + n * 32 + c;
-                if (n < NCB && col_in_b < m_b) {
-                    const int o = (h * 32 + c) * 4 * KPB;
-                    unsigned heads = 0;
-                    const long long dst = (pbase + (long long)col_in_b * nch_b + ch) * KPB;
-                    for (int j = 0; j < KPB; ++j) {
-                        float bs_ = -INFINITY;
-                        unsigned br = NOROW;
-                        int bsrc = 0;
-#pragma unroll
-                        for (int src = 0; src < 4; ++src) {
-                            const int hd = (heads >> (4 * src)) & 15;
-                            if (hd < KPB) {
-                                const float s = ms[o + src * KPB + hd];
-                                const unsigned r = mr[o + src * KPB + hd];
-                                if (better(s, r, bs_, br)) { bs_ = s; br = r; bsrc = src; }
-                            }
-                        }
-                        heads += 1u << (4 * bsrc);
-                        P.part_score[dst + j] = bs_;
-                        P.part_row[dst + j] = br;
-                        // this chunk alone has 10 rows >= bs_: publish the bound for the other chunks
-                        if (j == KPB - 1 && br != NOROW) atomic_max_float(P.col_thr + (size_t)(cb0 + n) * 32 + c, bs_);
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
-};
-
-#ifdef LMI_SCAN_REGSTAGE
-__global__ __launch_bounds__(256, 2) void scan_kernel(ScanParams P) {
-    __shared__ __attribute__((aligned(16))) float4 sB0[4 * STAGE_G * 64];
-    __shared__ __attribute__((aligned(16))) float4 sB1[4 * STAGE_G * 64];
-    int* s_item = reinterpret_cast<int*>(sB1);
-#else
 __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void scan_kernel(ScanParams P) {
     __shared__ __attribute__((aligned(16))) float4 sA0[4 * RB * STAGE_G * 64];
     __shared__ __attribute__((aligned(16))) float4 sA1[4 * RB * STAGE_G * 64];
@@ -961,7 +700,6 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void scan_kernel(ScanParams P
     __shared__ __attribute__((aligned(16))) float4 sB1[4 * STAGE_G * 64];
     const ScanLds S{sA0, sA1, sB0, sB1};
     int* s_item = reinterpret_cast<int*>(sB1);  // item broadcast: no DMA is in flight between items
-#endif
     // home queue = this block's XCD (HW_REG_XCC_ID, id 20, bits [3:0]); any value works: speed only
     int grp = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & (NGRP - 1));
     for (;;) {
@@ -996,21 +734,12 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void scan_kernel(ScanParams P
         const int nqt = (m_b + TILE_COLS - 1) / TILE_COLS;
         const int qt = local % nqt, ch = local / nqt;
         const int ncb = min(4, (m_b - qt * TILE_COLS + 31) >> 5);
-#ifdef LMI_SCAN_REGSTAGE
-        switch (ncb) {
-            case 1: { ScanItemR<1> it{P, sB0, sB1}; it.run(b, qt, ch); break; }
-            case 2: { ScanItemR<2> it{P, sB0, sB1}; it.run(b, qt, ch); break; }
-            case 3: { ScanItemR<3> it{P, sB0, sB1}; it.run(b, qt, ch); break; }
-            default: { ScanItemR<4> it{P, sB0, sB1}; it.run(b, qt, ch); break; }
-        }
-#else
         switch (ncb) {
             case 1: { ScanItem<1> it{P, S}; it.run(b, qt, ch); break; }
             case 2: { ScanItem<2> it{P, S}; it.run(b, qt, ch); break; }
             case 3: { ScanItem<3> it{P, S}; it.run(b, qt, ch); break; }
             default: { ScanItem<4> it{P, S}; it.run(b, qt, ch); break; }
         }
-#endif
     }
 }
 

@@ -23,9 +23,6 @@
 #pragma once
 #include "lmi_kernels.h"
 
-#ifndef LMI_PF_REGSTAGE
-#define LMI_PF_DMA 1  // default: LDS-DMA ring of 3 stages; -DLMI_PF_REGSTAGE selects the one-stage register pipeline
-#endif
 
 namespace lmi {
 
@@ -188,9 +185,9 @@ __global__ void slot_bound_kernel(const int* __restrict__ bucket_order, const in
 // ------------------------------------------------------------------------------------------------
 // Prefilter kernels: fp16 operands, 256 x 128 block tile (wave = 64 vectors x 128 queries, 8
 // accumulator tiles), both operands by LDS-DMA into a ring of three 24-KiB stages (32 k each), one
-// barrier per stage, stage u+2 in flight while stage u computes.  (A/B on MI355X, 10M x 768: the
-// one-stage register pipeline kept for -DLMI_PF_REGSTAGE spent 71 % of its wave time parked on
-// waits -- an fp16 stage is 8x shorter than an f32 one, shorter than the memory latency; the ring
+// barrier per stage, stage u+2 in flight while stage u computes.  (A/B on MI355X, 10M x 768: a
+// one-stage register pipeline (A to VGPRs, B via VGPR -> ds_write) spent 71 % of its wave time parked
+// on waits -- an fp16 stage is 8x shorter than an f32 one, shorter than the memory latency; the ring
 // is 25 % faster.)  Two passes over the same code (template SAMPLE):
 //   pass 1 (SAMPLE):  PF_PARTS items per (bucket, query tile) scan every PF_SAMPLE-th 256-row tile of
 //                     the whole bucket (part p takes sampled tiles p, p+PF_PARTS, ..) with per-lane
@@ -243,38 +240,14 @@ struct PreItem {
     static constexpr int NLIST = SAMPLE ? NCB : 1;
     const PrefilterParams& P;
     uint4* sB0;
-    uint4* sB1;  // two distinct __shared__ arrays [4 col-blocks][PF_STAGE_G][64] uint4 = 8 KiB each
-#ifdef LMI_PF_DMA
-    uint4* sB2;  // third B buffer and three A buffers [4 waves][PF_RB][PF_STAGE_G][64]: LDS-DMA ring of 3 stages
+    uint4* sB1;  // three DISTINCT __shared__ B arrays [4 col-blocks][PF_STAGE_G][64] uint4 = 8 KiB each ...
+    uint4* sB2;  // ... and three A arrays [4 waves][PF_RB][PF_STAGE_G][64] (16 KiB each): the LDS-DMA ring
     uint4 *sA0, *sA1, *sA2;
-#endif
     int lane, w, h, c;
     float lv[NLIST][KPB];   // pass 1 only
     float thr[NCB];         // pass 2: bound - 2 eps' of this lane's column in col-block n
     f32x16 acc[PF_RB][NCB];
 
-    template <int PAR>
-    __device__ __forceinline__ void compute(const uint4 (&a)[PF_RB][PF_STAGE_G]) {
-        const uint4* sB = (PAR ? sB1 : sB0) + lane;
-#pragma unroll
-        for (int g = 0; g < PF_STAGE_G; ++g) {
-            half8 bq[NCB];
-#pragma unroll
-            for (int n = 0; n < NCB; ++n) {
-                const uint4 t = sB[(n * PF_STAGE_G + g) * 64];
-                bq[n] = *reinterpret_cast<const half8*>(&t);
-            }
-#pragma unroll
-            for (int j = 0; j < PF_RB; ++j) {
-                const half8 av = *reinterpret_cast<const half8*>(&a[j][g]);
-#pragma unroll
-                for (int n = 0; n < NCB; ++n)
-                    acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bq[n], acc[j][n], 0, 0, 0);
-            }
-        }
-    }
-
-#ifdef LMI_PF_DMA
     template <int SLOT>
     __device__ __forceinline__ void issue_dma(const uint4* ap0, const uint4* ap1, const uint4* qp) {
         uint4* sA = SLOT == 0 ? sA0 : SLOT == 1 ? sA1 : sA2;
@@ -309,7 +282,6 @@ struct PreItem {
             }
         }
     }
-#endif
 
     __device__ __forceinline__ void epilogue(int rb_tile0, int n_b, size_t col0, int m_left) {
 #pragma unroll
@@ -382,12 +354,11 @@ struct PreItem {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.0f;
         }
-        // running pointers of the NEXT stage to load (cf. ScanItemR): A rows of this wave, B of wave w
+        // running pointers of the NEXT stage to load: A rows of this wave, B of wave w
         int vt_n = 0, t_n = 0, vt_c = 0, t_c = 0;  // vt_* count processed tiles; tile index = vt * TSTEP
         const uint4* ap0 = aslab + (size_t)min(rb_in_b0 + w * PF_RB + 0, rb_last) * rb_stride;
         const uint4* ap1 = aslab + (size_t)min(rb_in_b0 + w * PF_RB + 1, rb_last) * rb_stride;
         const uint4* qp = bbase;
-#ifdef LMI_PF_DMA
         // LDS-DMA ring, 3 stages: stage u+2 is issued while stage u computes, so a load has two stage
         // times to land (the one-stage register pipeline left 71 % of the wave time parked on waits).
         // Every wave issues exactly 6 DMAs per stage (waves w >= NCB stage a duplicate col-block into
@@ -428,53 +399,6 @@ struct PreItem {
         __syncthreads();
 #undef PF_STEP
 #undef PF_ADVANCE
-#else
-        uint4 x[PF_RB][PF_STAGE_G], y[PF_RB][PF_STAGE_G], z[PF_STAGE_G];
-#define PF_LOAD(A)                                                                                \
-    {                                                                                             \
-        _Pragma("unroll") for (int g = 0; g < PF_STAGE_G; ++g) {                                  \
-            A[0][g] = ap0[g * 64]; A[1][g] = ap1[g * 64]; z[g] = qp[g * 64];                      \
-        }                                                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        if (t_n + 1 < NS) { ++t_n; ap0 += PF_STAGE_G * 64; ap1 += PF_STAGE_G * 64; qp += PF_STAGE_G * 64; } \
-        else if (vt_n + 1 < nvt) {                                                                \
-            ++vt_n; t_n = 0; qp = bbase;                                                          \
-            ap0 = aslab + (size_t)min(rb_in_b0 + (vt_n * TSTEP * 4 + w) * PF_RB + 0, rb_last) * rb_stride; \
-            ap1 = aslab + (size_t)min(rb_in_b0 + (vt_n * TSTEP * 4 + w) * PF_RB + 1, rb_last) * rb_stride; \
-        }                                                                                         \
-    }
-#define PF_STORE_B(SB)                                                                            \
-    if (w < NCB) {                                                                                \
-        _Pragma("unroll") for (int g = 0; g < PF_STAGE_G; ++g) (SB)[(w * PF_STAGE_G + g) * 64 + lane] = z[g]; \
-    }
-#define PF_FINISH_STAGE                                                                           \
-    if (++t_c == NS) {                                                                            \
-        epilogue(rb_in_b0 + vt_c * TSTEP * 4 * PF_RB, n_b, col0, m_left);                         \
-        t_c = 0; ++vt_c;                                                                          \
-    }
-        const int total = nvt * NS;
-        if (total > 0) {
-        PF_LOAD(x)
-        PF_STORE_B(sB0)
-        __syncthreads();
-        }
-        for (int u = 0; u < total; u += 2) {
-            PF_LOAD(y)
-            compute<0>(x);
-            PF_FINISH_STAGE
-            PF_STORE_B(sB1)
-            __syncthreads();
-            if (u + 1 >= total) break;
-            PF_LOAD(x)
-            compute<1>(y);
-            PF_FINISH_STAGE
-            PF_STORE_B(sB0)
-            __syncthreads();
-        }
-#undef PF_LOAD
-#undef PF_STORE_B
-#undef PF_FINISH_STAGE
-#endif
         if (!SAMPLE) return;
         // ---- pass 1: bound[col] = 10th best of the sample; the 8 (wave, half) value lists of a
         //      column are merged in two rounds of 4 lists (5 KiB in sB0) + a carried list (sB1) ----
@@ -558,15 +482,11 @@ template <bool SAMPLE>
 __global__ __launch_bounds__(256, 2) void prefilter_kernel(PrefilterParams P) {
     __shared__ __attribute__((aligned(16))) uint4 sB0[4 * PF_STAGE_G * 64];
     __shared__ __attribute__((aligned(16))) uint4 sB1[4 * PF_STAGE_G * 64];
-#ifdef LMI_PF_DMA
     __shared__ __attribute__((aligned(16))) uint4 sB2[4 * PF_STAGE_G * 64];
     __shared__ __attribute__((aligned(16))) uint4 sA0[4 * PF_RB * PF_STAGE_G * 64];
     __shared__ __attribute__((aligned(16))) uint4 sA1[4 * PF_RB * PF_STAGE_G * 64];
     __shared__ __attribute__((aligned(16))) uint4 sA2[4 * PF_RB * PF_STAGE_G * 64];
 #define PF_ITEM_ARGS P, sB0, sB1, sB2, sA0, sA1, sA2
-#else
-#define PF_ITEM_ARGS P, sB0, sB1
-#endif
     int* s_item = reinterpret_cast<int*>(sB1);
     int grp = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & (NGRP - 1));
     for (;;) {

@@ -102,3 +102,34 @@ def test_all_buckets_equals_bruteforce(world):
     assert np.array_equal(i[strict], i1[strict]) and strict.mean() > 0.99
     idx.close()
     one.close()
+
+
+def test_many_buckets_c4_shape(oracle):
+    """BASELINE config 4 shape, scaled: 1 024 leaves, top-8 buckets (many small buckets, several
+    per XCD queue, buckets below one tile).  Both scan modes against the oracle on sampled queries."""
+    from learnedmetricindex_amd import _capi
+
+    rs = np.random.RandomState(21)
+    N_, D_, L_, NQ_, NB_ = 300_000, 64, 1024, 1500, 8
+    centres = rs.randn(L_, D_).astype(np.float32)
+    lab = rs.randint(0, L_, size=N_)
+    X = centres[lab] + 0.7 * rs.randn(N_, D_).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    Q = centres[rs.randint(0, L_, size=NQ_)] + 0.7 * rs.randn(NQ_, D_).astype(np.float32)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    order = np.argsort(-(Q @ centres.T), axis=1)[:, :NB_].astype(np.int32)
+    res = []
+    for pf in (True, False):
+        idx = _capi.Index(0, chunk_rows=2048, prefilter=pf)
+        idx.set_buckets(X, lab, L_)
+        res.append(idx.scan_topk(Q, order, 10))
+        if pf:
+            assert idx.prefilter_stats()[2] == 0
+        idx.close()
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    dp = lab.astype(np.int64)[:, None]
+    sel = rs.choice(NQ_, 40, replace=False)
+    do, io, _ = oracle.search(None, None, X, Q[sel], dp, NB_, 10, nthreads=4, bucket_order=order[sel][:, :, None])
+    np.testing.assert_array_equal(res[0][1][sel], io)
+    np.testing.assert_array_equal(res[0][0][sel].astype(np.float64), do)
