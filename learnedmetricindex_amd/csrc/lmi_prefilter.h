@@ -250,6 +250,13 @@ struct PreItem {
 
     template <int SLOT>
     __device__ __forceinline__ void issue_dma(const uint4* ap0, const uint4* ap1, const uint4* qp) {
+#ifdef LMI_ABL_NOLOAD  // timing-only ablation builds (tools/scan_ab.py --no-check)
+        return;
+#endif
+#ifdef LMI_ABL_HOTA    // every block streams the same 64 KiB of A: all L2 hits
+        ap0 = P.slab16 + (((size_t)(ap0 - P.slab16)) & 2047) + lane;
+        ap1 = P.slab16 + (((size_t)(ap1 - P.slab16)) & 2047) + 2048 + lane;
+#endif
         uint4* sA = SLOT == 0 ? sA0 : SLOT == 1 ? sA1 : sA2;
         uint4* sB = SLOT == 0 ? sB0 : SLOT == 1 ? sB1 : sB2;
 #pragma unroll

@@ -41,8 +41,8 @@
 #include <omp.h>
 #endif
 
-#define VB 32 /* vectors per transposed block */
-#define QB 4  /* queries per register block   */
+#define VB 8 /* vectors per transposed block */
+#define QB 8  /* queries per register block   */
 
 int lmi_oracle_abi_version(void) { return 1; }
 
@@ -163,34 +163,21 @@ static inline void topk_insert(float *D, int64_t *I, int k, float s, int64_t idx
     I[p] = idx;
 }
 
-void lmi_oracle_knn_ip(const float *xq, int64_t nq, const float *xb, int64_t nb, int d, int k,
-                       float *D, int64_t *I, int nthreads)
+/* (score desc, row asc): the order every list is kept in */
+static inline int better_sr(float s, int64_t r, float s2, int64_t r2) { return s > s2 || (s == s2 && r < r2); }
+
+/* one contiguous range of row-blocks against all queries; rows ascend, so strict > keeps the earlier */
+static void knn_range(const float *xq, int64_t nq, const float *xt, int64_t blk0, int64_t blk1, int64_t nb,
+                      int d, int k, float *D, int64_t *I)
 {
-    for (int64_t i = 0; i < nq * (int64_t)k; ++i) {
-        D[i] = -FLT_MAX;
-        I[i] = -1;
-    }
-    /* -FLT_MAX sentinels sit below every finite score; a real score of exactly -FLT_MAX is not
-       representable by unit-norm inputs.  Rows enter in ascending order, so strict > == "earlier
-       row wins". */
-    if (nq == 0 || nb == 0) return;
-    if (nthreads < 1) nthreads = 1;
-    const int64_t nblk = (nb + VB - 1) / VB;
-    /* transposed copy of xb in blocks of VB rows: xt[blk][k][v] */
-    float *xt = (float *)calloc((size_t)nblk * d * VB, sizeof(float));
-    for (int64_t r = 0; r < nb; ++r) {
-        float *dst = xt + (size_t)(r / VB) * d * VB + (r % VB);
-        const float *src = xb + (size_t)r * d;
-        for (int kk = 0; kk < d; ++kk) dst[(size_t)kk * VB] = src[kk];
-    }
+    for (int64_t i = 0; i < nq * (int64_t)k; ++i) { D[i] = -FLT_MAX; I[i] = -1; }
     const int64_t nqb = (nq + QB - 1) / QB;
-#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
     for (int64_t qb = 0; qb < nqb; ++qb) {
         const int64_t q0 = qb * QB;
         const int nqq = (int)((nq - q0) < QB ? (nq - q0) : QB);
         const float *qp[QB];
         for (int t = 0; t < QB; ++t) qp[t] = xq + (size_t)(q0 + (t < nqq ? t : 0)) * d;
-        for (int64_t blk = 0; blk < nblk; ++blk) {
+        for (int64_t blk = blk0; blk < blk1; ++blk) {
             float acc[QB][VB];
             memset(acc, 0, sizeof(acc));
             const float *xp = xt + (size_t)blk * d * VB;
@@ -205,9 +192,66 @@ void lmi_oracle_knn_ip(const float *xq, int64_t nq, const float *xb, int64_t nb,
             const int nv = (int)((nb - r0) < VB ? (nb - r0) : VB);
             for (int t = 0; t < nqq; ++t)
                 for (int v = 0; v < nv; ++v)
-                    topk_insert(D + (size_t)(q0 + t) * k, I + (size_t)(q0 + t) * k, k, acc[t][v],
-                                r0 + v);
+                    topk_insert(D + (size_t)(q0 + t) * k, I + (size_t)(q0 + t) * k, k, acc[t][v], r0 + v);
         }
+    }
+}
+
+void lmi_oracle_knn_ip(const float *xq, int64_t nq, const float *xb, int64_t nb, int d, int k,
+                       float *D, int64_t *I, int nthreads)
+{
+    for (int64_t i = 0; i < nq * (int64_t)k; ++i) {
+        D[i] = -FLT_MAX;
+        I[i] = -1;
+    }
+    /* -FLT_MAX sentinels sit below every finite score; a real score of exactly -FLT_MAX is not
+       representable by unit-norm inputs. */
+    if (nq == 0 || nb == 0) return;
+    if (nthreads < 1) nthreads = 1;
+    const int64_t nblk = (nb + VB - 1) / VB;
+    if (nthreads > nblk) nthreads = (int)nblk;
+    /* transposed copy of xb in blocks of VB rows: xt[blk][k][v] */
+    float *xt = (float *)calloc((size_t)nblk * d * VB, sizeof(float));
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+    for (int64_t r = 0; r < nb; ++r) {
+        float *dst = xt + (size_t)(r / VB) * d * VB + (r % VB);
+        const float *src = xb + (size_t)r * d;
+        for (int kk = 0; kk < d; ++kk) dst[(size_t)kk * VB] = src[kk];
+    }
+    if (nthreads == 1) {
+        knn_range(xq, nq, xt, 0, nblk, nb, d, k, D, I);
+    } else {
+        /* threads split the ROWS (a bucket is visited by few queries); per-thread lists are merged
+           in (score desc, row asc) order, so the result does not depend on the thread count */
+        float *Dt = (float *)malloc((size_t)nthreads * nq * k * sizeof(float));
+        int64_t *It = (int64_t *)malloc((size_t)nthreads * nq * k * sizeof(int64_t));
+#pragma omp parallel for num_threads(nthreads) schedule(static, 1)
+        for (int t = 0; t < nthreads; ++t) {
+            const int64_t b0 = nblk * t / nthreads, b1 = nblk * (t + 1) / nthreads;
+            knn_range(xq, nq, xt, b0, b1, nb, d, k, Dt + (size_t)t * nq * k, It + (size_t)t * nq * k);
+        }
+        for (int64_t q = 0; q < nq; ++q) {
+            int head[256];
+            for (int t = 0; t < nthreads && t < 256; ++t) head[t] = 0;
+            for (int j = 0; j < k; ++j) {
+                int bt = -1;
+                float bs = -FLT_MAX;
+                int64_t br = -1;
+                for (int t = 0; t < nthreads && t < 256; ++t) {
+                    if (head[t] >= k) continue;
+                    const float s = Dt[((size_t)t * nq + q) * k + head[t]];
+                    const int64_t r = It[((size_t)t * nq + q) * k + head[t]];
+                    if (r < 0) continue; /* that thread's list is exhausted */
+                    if (bt < 0 || better_sr(s, r, bs, br)) { bt = t; bs = s; br = r; }
+                }
+                if (bt < 0) break;
+                D[(size_t)q * k + j] = bs;
+                I[(size_t)q * k + j] = br;
+                head[bt]++;
+            }
+        }
+        free(Dt);
+        free(It);
     }
     free(xt);
 }
