@@ -103,3 +103,23 @@ def test_unnormalised_wide_dynamic_range(capi, oracle):
     np.testing.assert_array_equal(ii[0], (rows[I[0]] + 1).astype(np.uint32))
     np.testing.assert_array_equal(dd[0], np.float32(1) - D[0])
     idx.close()
+
+
+def test_wide_vectors_beyond_lds_query_staging(capi, oracle):
+    """d = 1100 > the 1 024 floats the re-rank kernel stages in LDS: the query is read from L2."""
+    rs = np.random.RandomState(15)
+    X = rs.randn(3000, 1100).astype(np.float32)
+    Q = rs.randn(5, 1100).astype(np.float32)
+    labels = rs.randint(0, 3, size=3000)
+    order = np.array([[0, 1], [1, 2], [2, 0], [0, 2], [1, 0]], dtype=np.int32)
+    (d1, i1, sv, fb), (d0, i0, _, _) = both_modes(capi, X, labels, 3, Q, order, chunk_rows=2048)
+    np.testing.assert_array_equal(i1, i0)
+    np.testing.assert_array_equal(d1, d0)
+    rows = np.flatnonzero(labels == 0)
+    D, I = oracle.knn_ip(Q[:1], X[rows], 10)
+    idx = capi.Index(0)
+    idx.set_buckets(X, labels, 3)
+    dd, ii = idx.scan_topk(Q[:1], order[:1, :1], 10)
+    np.testing.assert_array_equal(ii[0], (rows[I[0]] + 1).astype(np.uint32))
+    np.testing.assert_array_equal(dd[0], np.float32(1) - D[0])
+    idx.close()
