@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--chunk-rows", type=int, default=None)
     ap.add_argument("--exact", action="store_true",
                     help="all-f32 scan (lmi_set_prefilter(0)) instead of fp16 prefilter + exact re-rank; same results")
+    ap.add_argument("--emulate-shard", default=None, metavar="R/W",
+                    help="diagnostic, single GPU: own only the buckets rank R of a W-way sharded run would own "
+                         "(no collective); shows the per-rank step time of the N>1 bench on one card")
     ap.add_argument("--traffic-json", default=None,
                     help="PMC-derived HBM bytes per scan launch (default: profiles/scan_pmc_<config>.json, "
                          "written by profiles/summarize.py from separate rocprofv3 --pmc passes of this bench)")
@@ -137,6 +140,13 @@ def main():
     sizes = np.bincount(labels_h, minlength=L)
     owner = assign_buckets(sizes, world, weights=sizes.astype(np.float64) ** 2)
     owned = (owner == rank).astype(np.uint8) if world > 1 else None
+    if args.emulate_shard:
+        assert world == 1, "--emulate-shard is a single-GPU diagnostic"
+        er, ew = (int(v) for v in args.emulate_shard.split("/"))
+        owner = assign_buckets(sizes, ew, weights=sizes.astype(np.float64) ** 2)
+        owned = (owner == er).astype(np.uint8)
+        owner = np.where(owner == er, 0, -1)
+        args.no_cpu_baseline = args.no_recall = True
     eng.buckets_begin(labels_h, d, L, owned=owned)
     for p, n in pieces:
         eng.add_rows(gen_rows(1, p, n), p * CHUNK)
@@ -163,24 +173,22 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_all()
-    scan_ms, dom_ms, flops = [], [], 0.0
     dom_slot = _capi.T_SCAN if args.exact else _capi.T_PF_EMIT
+    eng.timings_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out_d, out_i, bo = step()
-        tms = eng.timings()  # hipEvents on the kernels' own stream
-        scan_ms.append(float(tms[_capi.T_SCAN]))
-        dom_ms.append(float(tms[dom_slot]))
     sync_all()
     elapsed = time.perf_counter() - t0
+    # hipEvents recorded on the kernels' own stream around every phase of every step; read once, after the
+    # timed region (the handle keeps the newest 128 sets), so the loop itself has no host synchronisation
+    phases, n_timed = eng.timings_mean()
     tm = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
     elapsed = float(tm.item())
     flops, pairs, items = eng.scan_stats()
     pf_active, pf_survivors, pf_fallbacks = eng.prefilter_stats()
-    phases = eng.timings()
-
     # ------------------------------------------------------------------ recall@10 vs exact brute force
     recall = None
     if not args.no_recall:
@@ -234,8 +242,8 @@ def main():
                          f"ids and distances identical to the GPU's"}
 
     if rank == 0:
-        scan_s = float(np.mean(scan_ms)) * 1e-3
-        dom_s = float(np.mean(dom_ms)) * 1e-3
+        scan_s = float(phases[_capi.T_SCAN]) * 1e-3
+        dom_s = float(phases[dom_slot]) * 1e-3
         visited = np.unique(bo.cpu().numpy())
         visited = visited[(visited >= 0) & (owner[np.clip(visited, 0, L - 1)] == rank)]
         rows_visited = float(sizes[visited].sum())
@@ -256,11 +264,11 @@ def main():
                     "frac": round(alg_bytes / dom_s / 1e9 / PEAK_HBM_GBS, 4)}
         traffic = None
         tj = args.traffic_json or os.path.join(ROOT, "profiles", f"scan_pmc_{args.config}{'_exact' if args.exact else ''}.json")
-        overridden = any(getattr(args, key) is not None for key in ("n", "nq", "nb", "leaves"))
+        overridden = any(getattr(args, key) is not None for key in ("n", "nq", "nb", "leaves", "emulate_shard"))
         if world == 1 and not overridden and os.path.exists(tj):
             traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
         roof.update({"traffic": traffic, "kernel": kernel, "flops_per_launch": flops, "bytes_per_launch": alg_bytes,
-                     "avg_launch_ms": round(dom_s * 1e3, 4),
+                     "avg_launch_ms": round(dom_s * 1e3, 4), "launches_timed": int(n_timed),
                      "floors_ms": {"mfma": round(t_mfma * 1e3, 3), "hbm": round(t_hbm * 1e3, 3)},
                      # the whole scan phase (all its kernels) priced as SURVEY 8d does: algorithmic f32 flops
                      # against the f32 MFMA peak, whatever precision the prefilter used
@@ -290,6 +298,7 @@ def main():
             "prefilter": None if args.exact else {"survivors_per_slot": round(pf_survivors / max(1, nq * nb), 2),
                                                    "fallback_slots": int(pf_fallbacks)},
             "cpu_baseline": cpu,
+            **({"diagnostic": f"emulated shard {args.emulate_shard}: NOT a bench line"} if args.emulate_shard else {}),
             "phases_ms": {"inference": round(float(phases[0]), 4), "route_pack": round(float(phases[1]), 4),
                           "scan": round(float(phases[2]), 4), "merge": round(float(phases[3]), 4),
                           "pf_sample": round(float(phases[5]), 4), "pf_emit": round(float(phases[6]), 4),

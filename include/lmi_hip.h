@@ -133,6 +133,10 @@ LMI_API int lmi_knn_ip(int device, const float *xq, int64_t nq, const float *xb,
 
 /* Timings of the last lmi_mlp_topk / lmi_scan_topk / lmi_search call (synchronises the stream). */
 LMI_API int lmi_timings(lmi_index *h, float *ms /* [LMI_T_COUNT] */);
+/* Mean of the timing slots over the calls made since lmi_timings_reset (the newest 128 at most), read
+ * with ONE stream synchronisation, so a timed loop needs no per-call sync; *n_calls = calls averaged. */
+LMI_API int lmi_timings_reset(lmi_index *h);
+LMI_API int lmi_timings_mean(lmi_index *h, float *ms /* [LMI_T_COUNT] */, int *n_calls /* nullable */);
 /* Work done by the last scan: flops = 2 * d * sum over (query, rank) of the bucket size;
  * items = work items executed by the persistent scan kernel. */
 LMI_API int lmi_scan_stats(lmi_index *h, double *flops, int64_t *pairs, int64_t *items);

@@ -51,6 +51,8 @@ SIGNATURES = {
     "lmi_knn_ip": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int64, _vp, ctypes.c_int64, ctypes.c_int,
                                   ctypes.c_int, _vp, _vp]),
     "lmi_timings": (ctypes.c_int, [_vp, _vp]),
+    "lmi_timings_reset": (ctypes.c_int, [_vp]),
+    "lmi_timings_mean": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(ctypes.c_int)]),
     "lmi_scan_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double), _i64p, _i64p]),
     "lmi_set_chunk_rows": (ctypes.c_int, [_vp, ctypes.c_int]),
     "lmi_set_prefilter": (ctypes.c_int, [_vp, ctypes.c_int]),
@@ -270,6 +272,16 @@ class Index:
         ms = np.zeros(T_COUNT, dtype=np.float32)
         _check(lib().lmi_timings(self._h, _ptr(ms)))
         return ms
+
+    def timings_reset(self) -> None:
+        _check(lib().lmi_timings_reset(self._h))
+
+    def timings_mean(self):
+        """(mean ms per slot, calls averaged) since timings_reset -- one stream sync for the whole loop."""
+        ms = np.zeros(T_COUNT, dtype=np.float32)
+        n = ctypes.c_int(0)
+        _check(lib().lmi_timings_mean(self._h, _ptr(ms), ctypes.byref(n)))
+        return ms, n.value
 
     def scan_stats(self):
         fl = ctypes.c_double(0)

@@ -109,8 +109,15 @@ struct lmi_index {
     DevBuf act[2], xfrag, logits, order, q_nav, q_srch;
     DevBuf m, cb_start, item_base, part_base, stats, head, slot_local, slot_col, colmap, qfrag, grp, col_thr;
     DevBuf part_score, part_row, rank_d, rank_id, out_d, out_id, out_key;
-    hipEvent_t ev[10] = {};
-    bool ev_valid[10] = {};
+    // hipEvents of the last EV_RING calls: lmi_timings reads the newest set, lmi_timings_mean averages all
+    // sets since lmi_timings_reset with ONE stream synchronisation (no per-call sync in a timed loop)
+    static constexpr int EV_RING = 128;
+    hipEvent_t ev_ring[EV_RING][10] = {};
+    bool valid_ring[EV_RING][10] = {};
+    int ev_cur = 0;
+    long long ev_calls = 0;  // calls since lmi_timings_reset
+    hipEvent_t* ev = ev_ring[0];
+    bool* ev_valid = valid_ring[0];
     long long h_stats[4] = {0, 0, 0, 0};
     bool stats_pending = false;
 };
@@ -142,7 +149,8 @@ extern "C" LMI_API int lmi_create(int device, lmi_index** out) {
     int occ = 0;
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_kernel, 256, SCAN_LDS));
     h->scan_blocks_per_cu = std::max(1, std::min(occ, RB == 1 ? 2 : 1));
-    for (int i = 0; i < 10; ++i) HIPCHK(hipEventCreate(&h->ev[i]));
+    for (int r = 0; r < lmi_index::EV_RING; ++r)
+        for (int i = 0; i < 10; ++i) HIPCHK(hipEventCreate(&h->ev_ring[r][i]));
     {   // fp16 subnormal self-test (lmi_prefilter.h): the error bound of the prefilter relies on it
         static int cached = -1;  // per process; every MI355X behaves the same
         if (cached < 0) {
@@ -174,8 +182,9 @@ extern "C" LMI_API int lmi_destroy(lmi_index* h) {
                       &h->slot_col, &h->colmap, &h->qfrag, &h->grp, &h->col_thr, &h->slab16, &h->rowmajor, &h->xscale, &h->xmaxbits, &h->bnorm, &h->qnorm, &h->qmaxbits, &h->qscale, &h->qfrag16, &h->eps2, &h->cand_cnt, &h->cand_row, &h->cand_s, &h->fallback, &h->pf_bound, &h->nkeep, &h->part_score, &h->part_row, &h->rank_d,
                       &h->rank_id, &h->out_d, &h->out_id, &h->out_key};
     for (DevBuf* b : bufs) b->release();
-    for (int i = 0; i < 10; ++i)
-        if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    for (int r = 0; r < lmi_index::EV_RING; ++r)
+        for (int i = 0; i < 10; ++i)
+            if (h->ev_ring[r][i]) (void)hipEventDestroy(h->ev_ring[r][i]);
     delete h;
     return 0;
 }
@@ -406,6 +415,14 @@ extern "C" LMI_API int lmi_bucket_read(lmi_index* h, int bucket, float* rows, ui
 }
 
 // ------------------------------------------------------------------------------------------------
+static void begin_call(lmi_index* h) {
+    h->ev_cur = (h->ev_cur + 1) % lmi_index::EV_RING;
+    h->ev = h->ev_ring[h->ev_cur];
+    h->ev_valid = h->valid_ring[h->ev_cur];
+    for (int i = 0; i < 10; ++i) h->ev_valid[i] = false;
+    ++h->ev_calls;
+}
+
 static int record(lmi_index* h, int i) {
     HIPCHK(hipEventRecord(h->ev[i], h->stream));
     h->ev_valid[i] = true;
@@ -445,26 +462,24 @@ static int mlp_enqueue(lmi_index* h, const float* d_q, int nq, int nb, int* d_or
     const float4* in = h->xfrag.as<float4>();
     for (int i = 0; i < h->n_layers; ++i) {
         const bool last = i + 1 == h->n_layers;
-        // few feature blocks (e.g. the 120-class output layer: 4) -> one col-block per wave, 4x the blocks
-        const bool narrow = cdiv(h->n_rb[i], 4) * cdiv(ncb, 4) < h->num_cus;
-        dim3 grid(narrow ? ncb : cdiv(ncb, 4), cdiv(h->n_rb[i], 4));
+        // col-blocks per wave: 4 when that already gives every CU two blocks, else 2, else 1 (e.g. the
+        // 120-class output layer has 4 feature blocks = one block row; 768->512 on 10 000 queries had 316
+        // blocks of CBW 4 on 256 CUs)
+        const int rows = cdiv(h->n_rb[i], 4);
+        const int cbw = rows * cdiv(ncb, 4) >= 2 * h->num_cus ? 4 : rows * cdiv(ncb, 2) >= 2 * h->num_cus ? 2 : 1;
+        dim3 grid(cdiv(ncb, cbw), rows);
+        float* o = last ? d_logits : h->act[i & 1].as<float>();
+        const int KGn = last ? 0 : h->n_rb[i] * 4;
+#define LMI_MLP_LAUNCH(LASTV, CBWV)                                                                        \
+        mlp_layer_kernel<LASTV, CBWV><<<grid, 256, 0, h->stream>>>(h->Wf[i].as<float4>(), h->bias[i].as<float>(), in, \
+                                                                  h->KG[i], h->n_rb[i], ncb, o, KGn, nq, L)
         if (last) {
-            if (narrow)
-                mlp_layer_kernel<true, 1><<<grid, 256, 0, h->stream>>>(h->Wf[i].as<float4>(), h->bias[i].as<float>(), in,
-                                                                      h->KG[i], h->n_rb[i], ncb, d_logits, 0, nq, L);
-            else
-                mlp_layer_kernel<true, 4><<<grid, 256, 0, h->stream>>>(h->Wf[i].as<float4>(), h->bias[i].as<float>(), in,
-                                                                      h->KG[i], h->n_rb[i], ncb, d_logits, 0, nq, L);
+            if (cbw == 4) LMI_MLP_LAUNCH(true, 4); else if (cbw == 2) LMI_MLP_LAUNCH(true, 2); else LMI_MLP_LAUNCH(true, 1);
         } else {
-            float* o = h->act[i & 1].as<float>();
-            if (narrow)
-                mlp_layer_kernel<false, 1><<<grid, 256, 0, h->stream>>>(h->Wf[i].as<float4>(), h->bias[i].as<float>(), in,
-                                                                       h->KG[i], h->n_rb[i], ncb, o, h->n_rb[i] * 4, nq, L);
-            else
-                mlp_layer_kernel<false, 4><<<grid, 256, 0, h->stream>>>(h->Wf[i].as<float4>(), h->bias[i].as<float>(), in,
-                                                                       h->KG[i], h->n_rb[i], ncb, o, h->n_rb[i] * 4, nq, L);
+            if (cbw == 4) LMI_MLP_LAUNCH(false, 4); else if (cbw == 2) LMI_MLP_LAUNCH(false, 2); else LMI_MLP_LAUNCH(false, 1);
             in = reinterpret_cast<const float4*>(o);
         }
+#undef LMI_MLP_LAUNCH
         HIPCHK(hipGetLastError());
     }
     rank_classes_kernel<<<nq, 64, 0, h->stream>>>(d_logits, nq, L, nb, d_order);
@@ -489,7 +504,7 @@ extern "C" LMI_API int lmi_mlp_topk(lmi_index* h, const float* queries_nav, int 
         d_order = h->order.as<int>();
         if (logits) { CHK(h->logits.reserve((size_t)nq * L * 4)); d_logits = h->logits.as<float>(); }
     }
-    for (int i = 0; i < 10; ++i) h->ev_valid[i] = false;
+    begin_call(h);
     CHK(record(h, 0));
     CHK(mlp_enqueue(h, static_cast<const float*>(d_q), nq, nb, d_order, d_logits));
     CHK(record(h, 1));
@@ -519,7 +534,7 @@ extern "C" LMI_API int lmi_mlp_proba(lmi_index* h, const float* queries_nav, int
         d_order = h->order.as<int>();
         d_probs = h->out_d.as<float>();
     }
-    for (int i = 0; i < 10; ++i) h->ev_valid[i] = false;
+    begin_call(h);
     CHK(record(h, 0));
     CHK(mlp_enqueue(h, static_cast<const float*>(d_q), nq, L, d_order, nullptr));
     softmax_ranked_kernel<<<cdiv(nq, 64), 64, 0, h->stream>>>(h->logits.as<float>(), d_order, nq, L, d_probs);
@@ -673,6 +688,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         F.grp_n = R.grp_n;
         F.grp_total = R.grp_total;
         F.qt_base = R.qt_base;
+        F.by_work = R.order_tmp;
         F.head = S.head;
         F.bound = h->pf_bound.as<float>();
         F.bound1 = S.col_thr;
@@ -777,7 +793,7 @@ extern "C" LMI_API int lmi_scan_topk(lmi_index* h, const float* queries_search, 
         d_i = h->out_id.as<uint32_t>();
         if (keys) { CHK(h->out_key.reserve((size_t)nq * kout * 4)); d_k = h->out_key.as<uint32_t>(); }
     }
-    for (int i = 0; i < 10; ++i) h->ev_valid[i] = false;
+    begin_call(h);
     CHK(record(h, 1));
     CHK(scan_enqueue(h, static_cast<const float*>(d_qs), nq, static_cast<const int*>(d_order), nb, kout, 0, d_d, d_i, d_k));
     if (!on_device) {
@@ -815,7 +831,7 @@ extern "C" LMI_API int lmi_search(lmi_index* h, const float* queries_nav, const 
         d_i = h->out_id.as<uint32_t>();
         if (keys) { CHK(h->out_key.reserve((size_t)nq * kout * 4)); d_k = h->out_key.as<uint32_t>(); }
     }
-    for (int i = 0; i < 10; ++i) h->ev_valid[i] = false;
+    begin_call(h);
     CHK(record(h, 0));
     CHK(mlp_enqueue(h, static_cast<const float*>(d_qn), nq, nb, d_order, nullptr));
     CHK(record(h, 1));
@@ -907,13 +923,10 @@ extern "C" LMI_API int lmi_knn_ip(int device, const float* xq, int64_t nq, const
     return rc;
 }
 
-extern "C" LMI_API int lmi_timings(lmi_index* h, float* ms) {
-    if (!h || !ms) return fail("lmi_timings: NULL argument");
-    CHK(set_dev(h));
-    HIPCHK(hipStreamSynchronize(h->stream));
+static int read_event_set(const hipEvent_t* ev, const bool* ev_valid, float* ms) {
     for (int i = 0; i < LMI_T_COUNT; ++i) ms[i] = 0.0f;
     auto span = [&](int a, int b, float* out) -> int {
-        if (h->ev_valid[a] && h->ev_valid[b]) HIPCHK(hipEventElapsedTime(out, h->ev[a], h->ev[b]));
+        if (ev_valid[a] && ev_valid[b]) HIPCHK(hipEventElapsedTime(out, ev[a], ev[b]));
         return 0;
     };
     CHK(span(0, 1, &ms[LMI_T_INFERENCE]));
@@ -924,9 +937,39 @@ extern "C" LMI_API int lmi_timings(lmi_index* h, float* ms) {
     CHK(span(5, 6, &ms[LMI_T_PF_EMIT]));
     CHK(span(6, 7, &ms[LMI_T_RESCORE]));
     CHK(span(7, 3, &ms[LMI_T_FALLBACK]));
-    int first = h->ev_valid[0] ? 0 : 1;
-    int last = h->ev_valid[4] ? 4 : 1;
+    int first = ev_valid[0] ? 0 : 1;
+    int last = ev_valid[4] ? 4 : 1;
     CHK(span(first, last, &ms[LMI_T_TOTAL]));
+    return 0;
+}
+
+extern "C" LMI_API int lmi_timings(lmi_index* h, float* ms) {
+    if (!h || !ms) return fail("lmi_timings: NULL argument");
+    CHK(set_dev(h));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return read_event_set(h->ev, h->ev_valid, ms);
+}
+
+extern "C" LMI_API int lmi_timings_reset(lmi_index* h) {
+    if (!h) return fail("lmi_timings_reset: NULL handle");
+    h->ev_calls = 0;
+    return 0;
+}
+
+extern "C" LMI_API int lmi_timings_mean(lmi_index* h, float* ms, int* n_calls) {
+    if (!h || !ms) return fail("lmi_timings_mean: NULL argument");
+    CHK(set_dev(h));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int n = (int)std::min<long long>(h->ev_calls, lmi_index::EV_RING);
+    double sum[LMI_T_COUNT] = {};
+    for (int j = 0; j < n; ++j) {
+        const int r = ((h->ev_cur - j) % lmi_index::EV_RING + lmi_index::EV_RING) % lmi_index::EV_RING;
+        float one[LMI_T_COUNT];
+        CHK(read_event_set(h->ev_ring[r], h->valid_ring[r], one));
+        for (int i = 0; i < LMI_T_COUNT; ++i) sum[i] += one[i];
+    }
+    for (int i = 0; i < LMI_T_COUNT; ++i) ms[i] = n ? (float)(sum[i] / n) : 0.0f;
+    if (n_calls) *n_calls = n;
     return 0;
 }
 

@@ -259,8 +259,8 @@ struct RouteArrays {
     int* grp_base;        // [NGRP][L+1] prefix of the buckets' item counts inside the group
     int* grp_n;           // [NGRP]      buckets in the group
     int* grp_total;       // [NGRP]      items in the group
-    int* order_tmp;       // [L] scratch: buckets sorted by work
-    int* qt_base;         // [L+1] prefix of the buckets' query-tile counts (prefilter pass-1 items)
+    int* order_tmp;       // [L] buckets sorted by work, heaviest first
+    int* qt_base;         // [L+1] prefix of the query-tile counts of order_tmp[0..] (prefilter pass-1 items)
 };
 
 // Positions are handed out per block through an LDS histogram (one global atomic per bucket and
@@ -365,29 +365,44 @@ __global__ __launch_bounds__(1024) void route_group_kernel(int L, RouteArrays R)
         }
         order_s[rank] = b;
     }
-    if (t == 1) {  // query-tile prefix in bucket order (prefilter pass-1 items)
+    __syncthreads();
+    if (t == 64) {  // query-tile prefix over the buckets heaviest first (prefilter pass-1 queue: LPT)
         int q = 0;
-        for (int b = 0; b < L; ++b) { R.qt_base[b] = q; q += (m_s[b] + TILE_COLS - 1) / TILE_COLS; }
+        for (int i = 0; i < L; ++i) {
+            const int b = order_s[i];
+            R.order_tmp[i] = b;
+            R.qt_base[i] = q;
+            q += (m_s[b] + TILE_COLS - 1) / TILE_COLS;
+        }
         R.qt_base[L] = q;
     }
-    __syncthreads();
-    if (t == 0) {
-        long long load[NGRP];
-        int cnt[NGRP], items[NGRP];
-        for (int g = 0; g < NGRP; ++g) { load[g] = 0; cnt[g] = 0; items[g] = 0; R.grp_base[g * (L + 1)] = 0; }
+    // LPT on wave 0: lane g < NGRP keeps queue g's running load / bucket count / item count in registers;
+    // the lightest queue (ties -> lower g) is found by an 8-lane butterfly.  (Thread 0 doing it alone
+    // with private arrays indexed at run time went through scratch: 73 us at L = 120.)
+    if (t < 64) {
+        long long load = 0;
+        int cnt = 0, items = 0;
+        if (t < NGRP) R.grp_base[t * (L + 1)] = 0;
         for (int i = 0; i < L; ++i) {
             const int b = order_s[i];
             if (m_s[b] == 0) break;  // sorted by work: nothing but idle buckets from here on
-            int g = 0;
-            for (int o = 1; o < NGRP; ++o)
-                if (load[o] < load[g]) g = o;
-            R.grp_bucket[g * L + cnt[g]] = b;
-            items[g] += items_s[b];
-            cnt[g] += 1;
-            R.grp_base[g * (L + 1) + cnt[g]] = items[g];
-            load[g] += work_s[b];
+            long long best = t < NGRP ? load : 0x7fffffffffffffffll;
+            int bg = t;
+#pragma unroll
+            for (int o = 1; o < NGRP; o <<= 1) {
+                const long long ol = __shfl_xor(best, o);
+                const int og = __shfl_xor(bg, o);
+                if (ol < best || (ol == best && og < bg)) { best = ol; bg = og; }
+            }
+            if (t == bg && t < NGRP) {
+                R.grp_bucket[t * L + cnt] = b;
+                items += items_s[b];
+                cnt += 1;
+                R.grp_base[t * (L + 1) + cnt] = items;
+                load += work_s[b];
+            }
         }
-        for (int g = 0; g < NGRP; ++g) { R.grp_n[g] = cnt[g]; R.grp_total[g] = items[g]; }
+        if (t < NGRP) { R.grp_n[t] = cnt; R.grp_total[t] = items; }
     }
 }
 

@@ -143,27 +143,42 @@ __global__ __launch_bounds__(256) void query_norm_kernel(const float* __restrict
         for (int k = lane; k < d; k += 64) { const float v = q[(size_t)i * d + k]; acc += v * v; m = fmaxf(m, fabsf(v)); }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { acc += __shfl_xor(acc, o); m = fmaxf(m, __shfl_xor(m, o)); }
-    if (lane == 0 && i < nq) { qnorm[i] = sqrtf(acc) * 1.0002f; atomicMax(maxbits, __float_as_uint(m)); }
+    if (lane == 0 && i < nq) {
+        qnorm[i] = sqrtf(acc) * 1.0002f;
+        // one word for the batch: look before the atomic (10 000 contended atomicMax took 100 us)
+        const unsigned mb = __float_as_uint(m);
+        if (mb > __hip_atomic_load(maxbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxbits, mb);
+    }
 }
 
-// colmap gather of row-major queries -> fp16 fragments (x qscale); one thread per (col, k16-group, half)
+// colmap gather of row-major queries -> fp16 fragments (x qscale); one thread per (col-block, k16-group,
+// lane): a wave writes one whole 1-KiB fragment (coalesced); each lane reads 32 contiguous bytes of its row
 __global__ void pack_queries16_kernel(const float* __restrict__ q, int d, const int* __restrict__ colmap,
                                       long long ncols, int KG16, const float* __restrict__ qscale,
                                       uint4* __restrict__ dst) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= ncols * KG16 * 2) return;
-    const int hh = (int)(idx & 1);
-    const int g = (int)((idx >> 1) % KG16);
-    const long long col = (idx >> 1) / KG16;
-    const int qi = colmap[col];
+    const int lane = (int)(idx & 63);
+    const int g = (int)((idx >> 6) % KG16);
+    const long long cb = (idx >> 6) / KG16;
+    const int hh = lane >> 5;
+    const int qi = colmap[cb * 32 + (lane & 31)];
     const float s = qscale[0];
     half8 h;
+    const int k0 = 16 * g + 8 * hh;
+    if (qi >= 0 && k0 + 8 <= d && (d & 3) == 0) {
+        const float4 lo = *reinterpret_cast<const float4*>(q + (size_t)qi * d + k0);
+        const float4 hi = *reinterpret_cast<const float4*>(q + (size_t)qi * d + k0 + 4);
+        h[0] = (_Float16)(lo.x * s); h[1] = (_Float16)(lo.y * s); h[2] = (_Float16)(lo.z * s); h[3] = (_Float16)(lo.w * s);
+        h[4] = (_Float16)(hi.x * s); h[5] = (_Float16)(hi.y * s); h[6] = (_Float16)(hi.z * s); h[7] = (_Float16)(hi.w * s);
+    } else {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = 16 * g + 8 * hh + j;
-        h[j] = (_Float16)((qi >= 0 && k < d) ? q[(size_t)qi * d + k] * s : 0.0f);
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + j;
+            h[j] = (_Float16)((qi >= 0 && k < d) ? q[(size_t)qi * d + k] * s : 0.0f);
+        }
     }
-    dst[((size_t)(col >> 5) * KG16 + g) * 64 + hh * 32 + (col & 31)] = *reinterpret_cast<uint4*>(&h);
+    dst[idx] = *reinterpret_cast<uint4*>(&h);
 }
 
 // eps2[col] = 2*eps' of the slot occupying column `col` (header); -1 for idle columns
@@ -215,7 +230,8 @@ struct PrefilterParams {
     const int* nch;
     const int* m;
     const int* cb_start;
-    const int* qt_base;   // [L+1] prefix of the buckets' query-tile counts (pass-1 items)
+    const int* qt_base;   // [L+1] prefix of the query-tile counts of the buckets taken heaviest first (pass-1 items)
+    const int* by_work;   // [L] that order
     const int* grp_bucket;
     const int* grp_base;
     const int* grp_n;
@@ -509,7 +525,7 @@ __global__ __launch_bounds__(256, 2) void prefilter_kernel(PrefilterParams P) {
                         const int mid = (lo + hi) >> 1;
                         if (P.qt_base[mid] <= pair) lo = mid; else hi = mid;
                     }
-                    b = lo;
+                    b = P.by_work[lo];
                     local = (pair - P.qt_base[lo]) * PF_PARTS + (it % PF_PARTS);
                 }
             } else {
