@@ -724,11 +724,15 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         Q.rank_id = h->rank_id.as<unsigned>();
         Q.fallback = h->fallback.as<int>();
         Q.nkeep = h->nkeep.as<int>();
+#ifndef LMI_ABL_NOEMIT  // timing-only ablation builds emit nothing: no re-rank, no fallback
         select_rescore_kernel<<<cdiv(nslots, RS_WAVES), 64 * RS_WAVES, 0, h->stream>>>(Q);
         HIPCHK(hipGetLastError());
+#endif
         CHK(record(h, 7));
+#ifndef LMI_ABL_NOEMIT
         fallback_kernel<<<nslots, 256, 0, h->stream>>>(Q);
         HIPCHK(hipGetLastError());
+#endif
         CHK(record(h, 3));
     }
     MergeParams M;

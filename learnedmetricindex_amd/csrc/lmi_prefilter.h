@@ -259,9 +259,12 @@ struct PreItem {
     uint4* sB1;  // three DISTINCT __shared__ B arrays [4 col-blocks][PF_STAGE_G][64] uint4 = 8 KiB each ...
     uint4* sB2;  // ... and three A arrays [4 waves][PF_RB][PF_STAGE_G][64] (16 KiB each): the LDS-DMA ring
     uint4 *sA0, *sA1, *sA2;
+    uint2* sList;           // pass 2: [4 waves][64] candidate compaction lists
     int lane, w, h, c;
     float lv[NLIST][KPB];   // pass 1 only
-    float thr[NCB];         // pass 2: bound - 2 eps' of this lane's column in col-block n
+    float thr[NCB];         // pass 2: bound - 2 eps' of this lane's column in col-block n (+inf: idle column)
+    unsigned pend_pos, pend_row, pend_col;  // pass 2: this lane's candidate of the previous tile ...
+    float pend_s;                           // ... whose position atomic is in flight
     f32x16 acc[PF_RB][NCB];
 
     template <int SLOT>
@@ -306,40 +309,118 @@ struct PreItem {
         }
     }
 
-    __device__ __forceinline__ void epilogue(int rb_tile0, int n_b, size_t col0, int m_left) {
+    // pass 1: per-lane values-only top-10 lists
+    __device__ __forceinline__ void epilogue_sample(int rb_tile0, int n_b) {
 #pragma unroll
         for (int j = 0; j < PF_RB; ++j) {
             const unsigned rowbase = (unsigned)((rb_tile0 + w * PF_RB + j) * 32);
 #pragma unroll
             for (int n = 0; n < NCB; ++n) {
-                const float t = SAMPLE ? lv[SAMPLE ? n : 0][KPB - 1] : thr[n];
-                unsigned mask = 0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const bool pass = SAMPLE ? (acc[j][n][r] > t) : (acc[j][n][r] >= t);
-                    mask |= (unsigned)(pass && rowbase + acc_row(r, h) < (unsigned)n_b) << r;
+                    const float s = acc[j][n][r];
+                    if (s > lv[SAMPLE ? n : 0][KPB - 1] && rowbase + acc_row(r, h) < (unsigned)n_b)
+                        vlist_insert(lv[SAMPLE ? n : 0], s);
+                    acc[j][n][r] = 0.0f;
                 }
-                while (mask) {
-                    const int r = __builtin_ctz(mask);
-                    mask &= mask - 1;
-                    float s = acc[j][n][0];
-#pragma unroll
-                    for (int i = 1; i < 16; ++i) s = (r == i) ? acc[j][n][i] : s;
-                    if (SAMPLE) {
-                        if (s > lv[SAMPLE ? n : 0][KPB - 1]) vlist_insert(lv[SAMPLE ? n : 0], s);
-                    } else if (n * 32 + c < m_left) {
-                        const size_t col = col0 + n * 32 + c;
-                        const unsigned pos = atomicAdd(P.cand_cnt + col, 1u);
-                        if (pos < (unsigned)PF_CAP) {
-                            P.cand_row[col * PF_CAP + pos] = rowbase + acc_row(r, h);
-                            P.cand_s[col * PF_CAP + pos] = s;
-                        }
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.0f;
             }
         }
+    }
+
+    // pass 2: a candidate's (column, row, shat) goes to the slot's buffer at position atomicAdd(cand_cnt).
+    // A returning global atomic inside the K pipeline drains the LDS-DMA look-ahead (vmcnt is one
+    // in-order counter), so a tile with few candidates (the wave counts them first: <= 64 in its
+    // 64 x 128 scores; expected ~16 at 83 000-row buckets) splits the emission over two tile ends:
+    // the candidates are compacted through a wave-private 64-entry LDS list (ballot + mbcnt, no LDS
+    // atomics) so that lane i owns entry i and issues ITS atomic; position and entry stay in 4
+    // registers while the next tile computes; the stores go out at the next tile end (flush_pending),
+    // long after the atomic returned.  Dense tiles (small buckets: every row is a candidate) take the
+    // direct path, one returning atomic per candidate.
+    __device__ __forceinline__ void flush_pending() {
+        if (pend_pos < (unsigned)PF_CAP) {
+            P.cand_row[(size_t)pend_col * PF_CAP + pend_pos] = pend_row;
+            P.cand_s[(size_t)pend_col * PF_CAP + pend_pos] = pend_s;
+        }
+        pend_pos = 0xffffffffu;
+    }
+
+    __device__ __forceinline__ void epilogue_emit(int rb_tile0, int n_b, size_t col0) {
+        flush_pending();
+        const unsigned row0 = (unsigned)((rb_tile0 + w * PF_RB) * 32);  // first of this wave's 64 rows
+        if (row0 + 32u * PF_RB > (unsigned)n_b) {  // wave-uniform: the bucket's ragged end (zero-padded / clamped rows)
+#pragma unroll
+            for (int j = 0; j < PF_RB; ++j)
+#pragma unroll
+                for (int n = 0; n < NCB; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (row0 + j * 32 + acc_row(r, h) >= (unsigned)n_b) acc[j][n][r] = __builtin_nanf("");  // fails every >= (a bound may be -inf)
+        }
+        // optimistic compaction: (column, row, shat) of every passing score -> list[0..cnt); more than 64
+        // discards the list and re-emits the whole tile on the direct path below
+        uint2* list = sList + w * 64;
+        int tot = 0;  // wave-uniform
+        {
+            // entry key = (column in tile) << 8 | (row in the wave's 64 rows); opaque so that the 128
+            // per-(j,n,r) keys are formed where they are used (base + literal), not hoisted out of the K loop
+            unsigned kb = (unsigned)((c << 8) | (4 * h));
+            asm volatile("" : "+v"(kb));
+#pragma unroll
+            for (int j = 0; j < PF_RB; ++j)
+#pragma unroll
+                for (int n = 0; n < NCB; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        bool pass = acc[j][n][r] >= thr[n];  // thr = +inf for idle columns
+#ifdef LMI_ABL_NOEMIT
+                        pass = pass && thr[n] == 12345.678f;  // never true, keeps the compares alive
+#endif
+                        const unsigned long long mask = __ballot(pass);
+                        if (mask) {
+                            if (pass) {
+                                const int my = tot + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                                    __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                                if (my < 64)
+                                    list[my] = make_uint2(kb + (unsigned)(((n * 32) << 8) | (j * 32 + (r & 3) + 8 * (r >> 2))),
+                                                          __float_as_uint(acc[j][n][r]));
+                            }
+                            tot += (int)__popcll(mask);
+                        }
+                    }
+        }
+        if (tot > 0 && tot <= 64) {
+            if (lane < tot) {
+                const uint2 e = list[lane];
+                pend_col = (unsigned)(col0 + (e.x >> 8));
+                pend_row = row0 + (e.x & 255u);
+                pend_s = __uint_as_float(e.y);
+                pend_pos = atomicAdd(P.cand_cnt + pend_col, 1u);
+            }
+        } else if (tot > 64) {
+            float t3[NCB];
+#pragma unroll
+            for (int n = 0; n < NCB; ++n) { t3[n] = thr[n]; asm volatile("" : "+v"(t3[n])); }
+#pragma unroll
+            for (int j = 0; j < PF_RB; ++j)
+#pragma unroll
+                for (int n = 0; n < NCB; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (acc[j][n][r] >= t3[n]) {
+                            const size_t col = col0 + n * 32 + c;
+                            const unsigned pos = atomicAdd(P.cand_cnt + col, 1u);
+                            if (pos < (unsigned)PF_CAP) {
+                                P.cand_row[col * PF_CAP + pos] = row0 + j * 32 + acc_row(r, h);
+                                P.cand_s[col * PF_CAP + pos] = acc[j][n][r];
+                            }
+                        }
+        }
+#pragma unroll
+        for (int j = 0; j < PF_RB; ++j)
+#pragma unroll
+            for (int n = 0; n < NCB; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.0f;
     }
 
     // SAMPLE: `ch` is the part p in [0, PF_PARTS): the item covers the tiles (p + PF_PARTS*i)*PF_SAMPLE, i = 0,1,..
@@ -370,15 +451,16 @@ struct PreItem {
                 for (int j = 0; j < KPB; ++j) lv[SAMPLE ? n : 0][j] = -INFINITY;
             } else {
                 const float v10 = P.bound1[col0 + n * 32 + c];
-                thr[n] = v10 - P.eps2[col0 + n * 32 + c];
+                thr[n] = n * 32 + c < m_left ? v10 - P.eps2[col0 + n * 32 + c] : INFINITY;
             }
 #pragma unroll
             for (int j = 0; j < PF_RB; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.0f;
         }
+        pend_pos = 0xffffffffu;
         // running pointers of the NEXT stage to load: A rows of this wave, B of wave w
-        int vt_n = 0, t_n = 0, vt_c = 0, t_c = 0;  // vt_* count processed tiles; tile index = vt * TSTEP
+        int vt_n = 0, t_n = 0;  // vt_n counts tiles; tile index = vt * TSTEP
         const uint4* ap0 = aslab + (size_t)min(rb_in_b0 + w * PF_RB + 0, rb_last) * rb_stride;
         const uint4* ap1 = aslab + (size_t)min(rb_in_b0 + w * PF_RB + 1, rb_last) * rb_stride;
         const uint4* qp = bbase;
@@ -386,43 +468,50 @@ struct PreItem {
         // times to land (the one-stage register pipeline left 71 % of the wave time parked on waits).
         // Every wave issues exactly 6 DMAs per stage (waves w >= NCB stage a duplicate col-block into
         // an unused slot) and the stream never stops (past the end the last stage is re-loaded), so
-        // "stage u has landed" is the constant `s_waitcnt vmcnt(6)`: only stage u+1's may be pending.
+        // "stage u has landed" is the constant `s_waitcnt vmcnt(6)`: only stage u+1's may be pending
+        // (the epilogue's few stores/atomics are younger still: the wait only gets more conservative).
+        // A tile is NS3 = NS rounded up to a multiple of 3 stages (the extra ones load, compute nothing),
+        // so every tile starts in ring slot 0 and the epilogue has ONE call site.
+        const int NS3 = (NS + 2) / 3 * 3;
 #define PF_ADVANCE                                                                                \
-        if (t_n + 1 < NS) { ++t_n; ap0 += PF_STAGE_G * 64; ap1 += PF_STAGE_G * 64; qp += PF_STAGE_G * 64; } \
-        else if (vt_n + 1 < nvt) {                                                                \
-            ++vt_n; t_n = 0; qp = bbase;                                                          \
-            ap0 = aslab + (size_t)min(rb_in_b0 + (vt_n * TSTEP * 4 + w) * PF_RB + 0, rb_last) * rb_stride; \
-            ap1 = aslab + (size_t)min(rb_in_b0 + (vt_n * TSTEP * 4 + w) * PF_RB + 1, rb_last) * rb_stride; \
+        if (++t_n < NS) { ap0 += PF_STAGE_G * 64; ap1 += PF_STAGE_G * 64; qp += PF_STAGE_G * 64; } \
+        else if (t_n == NS3) {                                                                    \
+            t_n = 0;                                                                              \
+            if (vt_n + 1 < nvt) {                                                                 \
+                ++vt_n; qp = bbase;                                                               \
+                ap0 = aslab + (size_t)min(rb_in_b0 + (vt_n * TSTEP * 4 + w) * PF_RB + 0, rb_last) * rb_stride; \
+                ap1 = aslab + (size_t)min(rb_in_b0 + (vt_n * TSTEP * 4 + w) * PF_RB + 1, rb_last) * rb_stride; \
+            }                                                                                     \
         }
-#define PF_STEP(SLOT)                                                                             \
+#define PF_STEP(SLOT, LIVE)                                                                       \
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                          \
         __builtin_amdgcn_s_barrier();                                                             \
         issue_dma<(SLOT + 2) % 3>(ap0, ap1, qp);                                                  \
         PF_ADVANCE                                                                                \
-        compute_dma<SLOT>();                                                                      \
-        if (++t_c == NS) {                                                                        \
-            epilogue(rb_in_b0 + vt_c * TSTEP * 4 * PF_RB, n_b, col0, m_left);                     \
-            t_c = 0; ++vt_c;                                                                      \
-        }
-        const int total = nvt * NS;
-        if (total > 0) {
+        if (LIVE) compute_dma<SLOT>();
+        if (nvt > 0) {
             issue_dma<0>(ap0, ap1, qp);
             PF_ADVANCE
             issue_dma<1>(ap0, ap1, qp);
             PF_ADVANCE
         }
-        for (int u = 0; u < total; u += 3) {
-            PF_STEP(0)
-            if (u + 1 >= total) break;
-            PF_STEP(1)
-            if (u + 2 >= total) break;
-            PF_STEP(2)
+        for (int vt = 0; vt < nvt; ++vt) {
+            for (int t = 0; t < NS3; t += 3) {
+                PF_STEP(0, true)
+                PF_STEP(1, t + 1 < NS)
+                PF_STEP(2, t + 2 < NS)
+            }
+            if (SAMPLE) epilogue_sample(rb_in_b0 + vt * TSTEP * 4 * PF_RB, n_b);
+            else epilogue_emit(rb_in_b0 + vt * TSTEP * 4 * PF_RB, n_b, col0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the look-ahead before the LDS is reused
         __syncthreads();
 #undef PF_STEP
 #undef PF_ADVANCE
-        if (!SAMPLE) return;
+        if (!SAMPLE) {
+            flush_pending();
+            return;
+        }
         // ---- pass 1: bound[col] = 10th best of the sample; the 8 (wave, half) value lists of a
         //      column are merged in two rounds of 4 lists (5 KiB in sB0) + a carried list (sB1) ----
         float* buf = reinterpret_cast<float*>(sB0);    // [32 cols][4 lists][KPB]
@@ -509,7 +598,8 @@ __global__ __launch_bounds__(256, 2) void prefilter_kernel(PrefilterParams P) {
     __shared__ __attribute__((aligned(16))) uint4 sA0[4 * PF_RB * PF_STAGE_G * 64];
     __shared__ __attribute__((aligned(16))) uint4 sA1[4 * PF_RB * PF_STAGE_G * 64];
     __shared__ __attribute__((aligned(16))) uint4 sA2[4 * PF_RB * PF_STAGE_G * 64];
-#define PF_ITEM_ARGS P, sB0, sB1, sB2, sA0, sA1, sA2
+    __shared__ uint2 sList[SAMPLE ? 1 : 4 * 64];
+#define PF_ITEM_ARGS P, sB0, sB1, sB2, sA0, sA1, sA2, sList
     int* s_item = reinterpret_cast<int*>(sB1);
     int grp = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & (NGRP - 1));
     for (;;) {
