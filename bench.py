@@ -253,7 +253,7 @@ def main():
         if args.exact:
             kernel, op_bytes, peak_tf = "lmi::scan_kernel", 4, PEAK_F32_MFMA_TFLOPS
         else:
-            kernel, op_bytes, peak_tf = "lmi::prefilter_kernel<false>", 2, PEAK_F16_MFMA_TFLOPS
+            kernel, op_bytes, peak_tf = "lmi::prefilter_kernel<false, 2>", 2, PEAK_F16_MFMA_TFLOPS
         alg_bytes = op_bytes * d * (rows_visited + nq * nb)
         t_mfma, t_hbm = flops / (peak_tf * 1e12), alg_bytes / (PEAK_HBM_GBS * 1e9)
         if t_mfma >= t_hbm:

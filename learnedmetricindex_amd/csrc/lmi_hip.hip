@@ -593,6 +593,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     R.grp_total = R.grp_n + NGRP;
     R.order_tmp = R.grp_total + NGRP;
     R.qt_base = R.order_tmp + L;
+    R.tile_cb = (h->prefilter && h->have16) ? 4 * PF_NG : 4;
 
     HIPCHK(hipMemsetAsync(h->m.p, 0, L * 4, h->stream));
     HIPCHK(hipMemsetAsync(h->head.p, 0, 64, h->stream));
@@ -696,12 +697,13 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         F.cand_cnt = h->cand_cnt.as<unsigned>();
         F.cand_row = h->cand_row.as<unsigned>();
         F.cand_s = h->cand_s.as<float>();
-        prefilter_kernel<true><<<h->num_cus * 2, 256, 0, h->stream>>>(F);   // pass 1: bounds from a sample
+        constexpr int PF_BLOCKS_PER_CU = PF_NG == 1 ? 2 : 1;
+        prefilter_kernel<true, PF_NG><<<h->num_cus * PF_BLOCKS_PER_CU, 256 * PF_NG, 0, h->stream>>>(F);   // pass 1: bounds from a sample
         HIPCHK(hipGetLastError());
         bound_merge_kernel<<<cdiv((long long)ncols, 256), 256, 0, h->stream>>>(F.bound, (long long)ncols, F.bound1);
         HIPCHK(hipGetLastError());
         CHK(record(h, 5));
-        prefilter_kernel<false><<<h->num_cus * 2, 256, 0, h->stream>>>(F);  // pass 2: candidates
+        prefilter_kernel<false, PF_NG><<<h->num_cus * PF_BLOCKS_PER_CU, 256 * PF_NG, 0, h->stream>>>(F);  // pass 2: candidates
         HIPCHK(hipGetLastError());
         CHK(record(h, 6));
         RescoreParams Q;

@@ -261,7 +261,11 @@ struct RouteArrays {
     int* grp_total;       // [NGRP]      items in the group
     int* order_tmp;       // [L] buckets sorted by work, heaviest first
     int* qt_base;         // [L+1] prefix of the query-tile counts of order_tmp[0..] (prefilter pass-1 items)
+    int tile_cb;          // col-blocks per query tile: 4 (exact scan, prefilter NG 1) or 8 (prefilter NG 2)
 };
+
+// query tiles of a bucket with m routed queries: its col-blocks over tiles of tile_cb (tile_cb 4: ceil(m / 128))
+__device__ __forceinline__ int query_tiles(int m, int tile_cb) { return (((m + 31) >> 5) + tile_cb - 1) / tile_cb; }
 
 // Positions are handed out per block through an LDS histogram (one global atomic per bucket and
 // block instead of one per slot: 40 000 returning atomics on 120 hot words took 66 us).
@@ -301,7 +305,7 @@ __global__ __launch_bounds__(256) void route_scan_kernel(int L, RouteArrays R) {
     for (int b = b0; b < b1; ++b) {
         const int m = R.m[b];
         cb += (m + 31) >> 5;
-        items += (long long)((m + TILE_COLS - 1) / TILE_COLS) * R.nch[b];
+        items += (long long)query_tiles(m, R.tile_cb) * R.nch[b];
         part += (long long)m * R.nch[b];
         pairs += (long long)m * R.nb_rows[b];
     }
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(256) void route_scan_kernel(int L, RouteArrays R) {
         R.item_base[b] = (int)eit;
         R.part_base[b] = epart;
         ecb += (m + 31) >> 5;
-        eit += (long long)((m + TILE_COLS - 1) / TILE_COLS) * R.nch[b];
+        eit += (long long)query_tiles(m, R.tile_cb) * R.nch[b];
         epart += (long long)m * R.nch[b];
     }
     if (t == 255) {
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(1024) void route_group_kernel(int L, RouteArrays R)
         const int m = R.m[b];
         m_s[b] = m;
         work_s[b] = (long long)m * R.nb_rows[b];
-        items_s[b] = ((m + TILE_COLS - 1) / TILE_COLS) * R.nch[b];
+        items_s[b] = query_tiles(m, R.tile_cb) * R.nch[b];
     }
     __syncthreads();
     // rank of every bucket by (work desc, id asc); work = queries x rows is a fine proxy
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(1024) void route_group_kernel(int L, RouteArrays R)
             const int b = order_s[i];
             R.order_tmp[i] = b;
             R.qt_base[i] = q;
-            q += (m_s[b] + TILE_COLS - 1) / TILE_COLS;
+            q += query_tiles(m_s[b], R.tile_cb);
         }
         R.qt_base[L] = q;
     }

@@ -217,6 +217,13 @@ __global__ void slot_bound_kernel(const int* __restrict__ bucket_order, const in
 #define LMI_PF_SAMPLE 16
 #endif
 constexpr int PF_SAMPLE = LMI_PF_SAMPLE;  // pass 1 looks at every 16th tile ...
+#ifndef LMI_PF_RING2
+#define LMI_PF_RING2 3  // ring slots of the NG 2 kernel (3 or 4; A/B on MI355X: 4 is 3 % slower, more in flight only raised the load latency)
+#endif
+#ifndef LMI_PF_NG
+#define LMI_PF_NG 2
+#endif
+constexpr int PF_NG = LMI_PF_NG;  // wave groups per prefilter block (PreItem): 1 -> 128-query tiles, 2 -> 256-query tiles
 constexpr int PF_PARTS = 4;    // ... split over 4 items per (bucket, query tile), merged by the consumers
 
 struct PrefilterParams {
@@ -251,16 +258,26 @@ __device__ __forceinline__ void vlist_insert(float (&v)[KPB], float s) {  // val
     v[0] = (s > v[0]) ? s : v[0];
 }
 
-template <int NCB, bool SAMPLE>
+// NG = wave groups per block.  NG 1: 4 waves, 256 vectors x 128 queries, two blocks per CU.  NG 2: 8 waves,
+// 256 vectors x 256 queries, one block per CU: group g (waves 4g..4g+3) owns its share of the tile's
+// col-blocks and both groups read the SAME staged vector fragments, so a CU fetches every vector stage
+// once instead of twice and a bucket has half as many query tiles re-reading its chunks.
+template <int NCB, bool SAMPLE, int NG>
 struct PreItem {
     static constexpr int NLIST = SAMPLE ? NCB : 1;
+    // ring slots: what is in flight (RING - 1 stages) over the load latency bounds the stage rate; NG 2's
+    // one block per CU leaves LDS for a fourth slot (3 x 32 KiB in flight instead of 2 x 24 KiB x 2 blocks)
+    static constexpr int RING = NG == 1 ? 3 : LMI_PF_RING2;
     const PrefilterParams& P;
     uint4* sB0;
-    uint4* sB1;  // three DISTINCT __shared__ B arrays [4 col-blocks][PF_STAGE_G][64] uint4 = 8 KiB each ...
-    uint4* sB2;  // ... and three A arrays [4 waves][PF_RB][PF_STAGE_G][64] (16 KiB each): the LDS-DMA ring
+    uint4* sB1;  // three DISTINCT __shared__ B arrays [4 NG col-blocks][PF_STAGE_G][64] uint4 = 8 NG KiB each ...
+    uint4* sB2;  // ... and three A arrays [4 row-waves][PF_RB][PF_STAGE_G][64] (16 KiB each): the LDS-DMA ring
     uint4 *sA0, *sA1, *sA2;
-    uint2* sList;           // pass 2: [4 waves][64] candidate compaction lists
+    uint4 *sB3, *sA3;       // fourth ring slot (RING 4 only)
+    uint2* sList;           // pass 2: [4 NG waves][64] candidate compaction lists
     int lane, w, h, c;
+    int wr, grp;            // row-wave (0..3) and wave group (0..NG-1): w = 4 grp + wr
+    int cbofs;              // first col-block of this wave's group inside the tile
     float lv[NLIST][KPB];   // pass 1 only
     float thr[NCB];         // pass 2: bound - 2 eps' of this lane's column in col-block n (+inf: idle column)
     unsigned pend_pos, pend_row, pend_col;  // pass 2: this lane's candidate of the previous tile ...
@@ -276,20 +293,23 @@ struct PreItem {
         ap0 = P.slab16 + (((size_t)(ap0 - P.slab16)) & 2047) + lane;
         ap1 = P.slab16 + (((size_t)(ap1 - P.slab16)) & 2047) + 2048 + lane;
 #endif
-        uint4* sA = SLOT == 0 ? sA0 : SLOT == 1 ? sA1 : sA2;
-        uint4* sB = SLOT == 0 ? sB0 : SLOT == 1 ? sB1 : sB2;
+        uint4* sA = SLOT == 0 ? sA0 : SLOT == 1 ? sA1 : SLOT == 2 ? sA2 : sA3;
+        uint4* sB = SLOT == 0 ? sB0 : SLOT == 1 ? sB1 : SLOT == 2 ? sB2 : sB3;
+        // this wave stages row-blocks j = grp, grp + NG, .. of its row-wave's PF_RB (ap0 [, ap1]) and col-block w
 #pragma unroll
         for (int g = 0; g < PF_STAGE_G; ++g) {
-            glds16(reinterpret_cast<const float4*>(ap0 + g * 64), reinterpret_cast<float4*>(sA + ((w * PF_RB + 0) * PF_STAGE_G + g) * 64));
-            glds16(reinterpret_cast<const float4*>(ap1 + g * 64), reinterpret_cast<float4*>(sA + ((w * PF_RB + 1) * PF_STAGE_G + g) * 64));
+            glds16(reinterpret_cast<const float4*>(ap0 + g * 64),
+                   reinterpret_cast<float4*>(sA + ((wr * PF_RB + (NG == 1 ? 0 : grp)) * PF_STAGE_G + g) * 64));
+            if (NG == 1)
+                glds16(reinterpret_cast<const float4*>(ap1 + g * 64), reinterpret_cast<float4*>(sA + ((wr * PF_RB + 1) * PF_STAGE_G + g) * 64));
             glds16(reinterpret_cast<const float4*>(qp + g * 64), reinterpret_cast<float4*>(sB + (w * PF_STAGE_G + g) * 64));
         }
     }
 
     template <int SLOT>
     __device__ __forceinline__ void compute_dma() {
-        const uint4* sA = (SLOT == 0 ? sA0 : SLOT == 1 ? sA1 : sA2) + (w * PF_RB) * PF_STAGE_G * 64 + lane;
-        const uint4* sB = (SLOT == 0 ? sB0 : SLOT == 1 ? sB1 : sB2) + lane;
+        const uint4* sA = (SLOT == 0 ? sA0 : SLOT == 1 ? sA1 : SLOT == 2 ? sA2 : sA3) + (wr * PF_RB) * PF_STAGE_G * 64 + lane;
+        const uint4* sB = (SLOT == 0 ? sB0 : SLOT == 1 ? sB1 : SLOT == 2 ? sB2 : sB3) + cbofs * PF_STAGE_G * 64 + lane;
 #pragma unroll
         for (int g = 0; g < PF_STAGE_G; ++g) {
             half8 bq[NCB];
@@ -313,7 +333,7 @@ struct PreItem {
     __device__ __forceinline__ void epilogue_sample(int rb_tile0, int n_b) {
 #pragma unroll
         for (int j = 0; j < PF_RB; ++j) {
-            const unsigned rowbase = (unsigned)((rb_tile0 + w * PF_RB + j) * 32);
+            const unsigned rowbase = (unsigned)((rb_tile0 + wr * PF_RB + j) * 32);
 #pragma unroll
             for (int n = 0; n < NCB; ++n) {
 #pragma unroll
@@ -346,7 +366,7 @@ struct PreItem {
 
     __device__ __forceinline__ void epilogue_emit(int rb_tile0, int n_b, size_t col0) {
         flush_pending();
-        const unsigned row0 = (unsigned)((rb_tile0 + w * PF_RB) * 32);  // first of this wave's 64 rows
+        const unsigned row0 = (unsigned)((rb_tile0 + wr * PF_RB) * 32);  // first of this wave's 64 rows
         if (row0 + 32u * PF_RB > (unsigned)n_b) {  // wave-uniform: the bucket's ragged end (zero-padded / clamped rows)
 #pragma unroll
             for (int j = 0; j < PF_RB; ++j)
@@ -423,11 +443,14 @@ struct PreItem {
                 for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.0f;
     }
 
+    // The tile = col-blocks [cbt0, cbt0 + ncb_tile) of bucket b; this wave's group owns NCB of them from cbofs
+    // (`idle`: none -- the wave stages its share, computes a duplicate and emits nothing).
     // SAMPLE: `ch` is the part p in [0, PF_PARTS): the item covers the tiles (p + PF_PARTS*i)*PF_SAMPLE, i = 0,1,..
     // of the whole bucket and writes its 10 best values; !SAMPLE: chunk `ch`, every tile.
-    __device__ __forceinline__ void run(int b, int qt, int ch) {
+    __device__ __forceinline__ void run(int b, int cbt0, int ncb_tile, int cbofs_, bool idle, int ch) {
         const int tid = threadIdx.x;
         lane = tid & 63; w = tid >> 6; h = lane >> 5; c = lane & 31;
+        wr = w & 3; grp = w >> 2; cbofs = cbofs_;
         const int KG = P.KG16, NS = KG / PF_STAGE_G;
         const int n_b = P.nb_rows[b];
         const int nrb_b = (n_b + 31) >> 5;
@@ -437,11 +460,11 @@ struct PreItem {
         const int t0 = SAMPLE ? ch * PF_SAMPLE : 0;               // first tile
         const int nvt = nvt_all > t0 ? (nvt_all - t0 + TSTEP - 1) / TSTEP : 0;  // tiles this item processes
         const int rb_in_b0 = SAMPLE ? t0 * 4 * PF_RB : ch * P.chunk_rb;
-        const int cb0 = P.cb_start[b] + qt * 4;
-        const int m_left = P.m[b] - qt * TILE_COLS;
-        const size_t col0 = (size_t)cb0 * 32;
+        const int cb_tile = P.cb_start[b] + cbt0;                 // the tile's first col-block (global)
+        const int m_left = idle ? 0 : P.m[b] - (cbt0 + cbofs) * 32;  // live columns from this group's first one
+        const size_t col0 = (size_t)(cb_tile + cbofs) * 32;
         const uint4* aslab = P.slab16 + ((size_t)P.rb_start[b] * KG) * 64 + lane;
-        const uint4* bbase = P.qfrag16 + ((size_t)(cb0 + min(w, NCB - 1)) * KG) * 64 + lane;
+        const uint4* bbase = P.qfrag16 + ((size_t)(cb_tile + min(w, ncb_tile - 1)) * KG) * 64 + lane;
         const size_t rb_stride = (size_t)KG * 64;
         const int rb_last = nrb_b - 1;
 #pragma unroll
@@ -459,34 +482,39 @@ struct PreItem {
                 for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.0f;
         }
         pend_pos = 0xffffffffu;
-        // running pointers of the NEXT stage to load: A rows of this wave, B of wave w
+        // running pointers of the NEXT stage to load: this wave's share of its row-wave's vectors, col-block w
         int vt_n = 0, t_n = 0;  // vt_n counts tiles; tile index = vt * TSTEP
-        const uint4* ap0 = aslab + (size_t)min(rb_in_b0 + w * PF_RB + 0, rb_last) * rb_stride;
-        const uint4* ap1 = aslab + (size_t)min(rb_in_b0 + w * PF_RB + 1, rb_last) * rb_stride;
+        const int j0 = NG == 1 ? 0 : grp;
+        const uint4* ap0 = aslab + (size_t)min(rb_in_b0 + wr * PF_RB + j0, rb_last) * rb_stride;
+        const uint4* ap1 = aslab + (size_t)min(rb_in_b0 + wr * PF_RB + 1, rb_last) * rb_stride;  // NG 1 only
         const uint4* qp = bbase;
-        // LDS-DMA ring, 3 stages: stage u+2 is issued while stage u computes, so a load has two stage
-        // times to land (the one-stage register pipeline left 71 % of the wave time parked on waits).
-        // Every wave issues exactly 6 DMAs per stage (waves w >= NCB stage a duplicate col-block into
-        // an unused slot) and the stream never stops (past the end the last stage is re-loaded), so
-        // "stage u has landed" is the constant `s_waitcnt vmcnt(6)`: only stage u+1's may be pending
-        // (the epilogue's few stores/atomics are younger still: the wait only gets more conservative).
-        // A tile is NS3 = NS rounded up to a multiple of 3 stages (the extra ones load, compute nothing),
-        // so every tile starts in ring slot 0 and the epilogue has ONE call site.
-        const int NS3 = (NS + 2) / 3 * 3;
+        // LDS-DMA ring of RING slots: stage u+RING-1 is issued while stage u computes, so a load has
+        // RING-1 stage times to land (a one-stage register pipeline left 71 % of the wave time parked on
+        // waits; bytes in flight / load latency is what bounds the stage rate).  Every wave issues exactly
+        // (PF_RB/NG + 1) * PF_STAGE_G DMAs per stage (6 or 4; waves whose col-block is past the tile stage
+        // a duplicate) and the stream never stops (past the end the last stage is re-loaded), so "stage u
+        // has landed" is a constant `s_waitcnt vmcnt((RING-2) x that)`: only the younger stages may be
+        // pending (the epilogue's few stores/atomics are younger still: the wait only gets more
+        // conservative).  A tile is NSR = NS rounded up to a multiple of RING stages (the extra ones load,
+        // compute nothing), so every tile starts in ring slot 0 and the epilogue has ONE call site.
+        static_assert((PF_RB / NG + 1) * PF_STAGE_G == (NG == 1 ? 6 : 4) && (NG == 2 || RING == 3), "vmcnt literals below");
+        const int NSR = (NS + RING - 1) / RING * RING;
 #define PF_ADVANCE                                                                                \
         if (++t_n < NS) { ap0 += PF_STAGE_G * 64; ap1 += PF_STAGE_G * 64; qp += PF_STAGE_G * 64; } \
-        else if (t_n == NS3) {                                                                    \
+        else if (t_n == NSR) {                                                                    \
             t_n = 0;                                                                              \
             if (vt_n + 1 < nvt) {                                                                 \
                 ++vt_n; qp = bbase;                                                               \
-                ap0 = aslab + (size_t)min(rb_in_b0 + (vt_n * TSTEP * 4 + w) * PF_RB + 0, rb_last) * rb_stride; \
-                ap1 = aslab + (size_t)min(rb_in_b0 + (vt_n * TSTEP * 4 + w) * PF_RB + 1, rb_last) * rb_stride; \
+                ap0 = aslab + (size_t)min(rb_in_b0 + (vt_n * TSTEP * 4 + wr) * PF_RB + j0, rb_last) * rb_stride; \
+                ap1 = aslab + (size_t)min(rb_in_b0 + (vt_n * TSTEP * 4 + wr) * PF_RB + 1, rb_last) * rb_stride; \
             }                                                                                     \
         }
 #define PF_STEP(SLOT, LIVE)                                                                       \
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                          \
+        if (NG == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                             \
+        else if (RING == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                      \
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                     \
         __builtin_amdgcn_s_barrier();                                                             \
-        issue_dma<(SLOT + 2) % 3>(ap0, ap1, qp);                                                  \
+        issue_dma<(SLOT + RING - 1) % RING>(ap0, ap1, qp);                                        \
         PF_ADVANCE                                                                                \
         if (LIVE) compute_dma<SLOT>();
         if (nvt > 0) {
@@ -494,12 +522,19 @@ struct PreItem {
             PF_ADVANCE
             issue_dma<1>(ap0, ap1, qp);
             PF_ADVANCE
+            if (RING == 4) {
+                issue_dma<2>(ap0, ap1, qp);
+                PF_ADVANCE
+            }
         }
         for (int vt = 0; vt < nvt; ++vt) {
-            for (int t = 0; t < NS3; t += 3) {
+            for (int t = 0; t < NSR; t += RING) {
                 PF_STEP(0, true)
                 PF_STEP(1, t + 1 < NS)
                 PF_STEP(2, t + 2 < NS)
+                if (RING == 4) {
+                    PF_STEP(3, t + 3 < NS)
+                }
             }
             if (SAMPLE) epilogue_sample(rb_in_b0 + vt * TSTEP * 4 * PF_RB, n_b);
             else epilogue_emit(rb_in_b0 + vt * TSTEP * 4 * PF_RB, n_b, col0);
@@ -512,26 +547,29 @@ struct PreItem {
             flush_pending();
             return;
         }
-        // ---- pass 1: bound[col] = 10th best of the sample; the 8 (wave, half) value lists of a
-        //      column are merged in two rounds of 4 lists (5 KiB in sB0) + a carried list (sB1) ----
-        float* buf = reinterpret_cast<float*>(sB0);    // [32 cols][4 lists][KPB]
-        float* carry = reinterpret_cast<float*>(sB1);  // [32 cols][KPB], touched by its own thread only
+        // ---- pass 1: bound[col] = 10th best of the sample; the 8 (row-wave, half) value lists of a
+        //      column are merged in two rounds of 4 lists (5 KiB per group in sB0) + a carried list (sB1).
+        //      Every wave runs all four n steps (the groups may own different numbers of col-blocks and
+        //      must meet at the same barriers). ----
+        float* buf = reinterpret_cast<float*>(sB0) + grp * (32 * 4 * KPB);  // [32 cols][4 lists][KPB]
+        float* carry = reinterpret_cast<float*>(sB1) + grp * (32 * KPB);    // [32 cols][KPB], touched by its own thread only
 #pragma unroll
-        for (int n = 0; n < NCB; ++n) {
+        for (int n = 0; n < 4; ++n) {
+            const bool live = n < NCB && !idle;
 #pragma unroll
             for (int round = 0; round < 2; ++round) {
                 __syncthreads();
-                if ((w >> 1) == round) {
-                    const int o = (c * 4 + ((w & 1) * 2 + h)) * KPB;
+                if (live && (wr >> 1) == round) {
+                    const int o = (c * 4 + ((wr & 1) * 2 + h)) * KPB;
 #pragma unroll
-                    for (int j = 0; j < KPB; ++j) buf[o + j] = lv[SAMPLE ? n : 0][j];
+                    for (int j = 0; j < KPB; ++j) buf[o + j] = lv[SAMPLE && n < NCB ? n : 0][j];
                 }
                 __syncthreads();
-                if (tid < 32) {
+                if (live && wr == 0 && lane < 32) {
                     float best[KPB];
                     unsigned heads = 0;
                     int hc = (round == 0) ? KPB : 0;  // the carried list is empty in round 0
-                    const int o = tid * 4 * KPB;
+                    const int o = lane * 4 * KPB;
 #pragma unroll
                     for (int j = 0; j < KPB; ++j) {
                         float bs = -INFINITY;
@@ -545,7 +583,7 @@ struct PreItem {
                             }
                         }
                         if (hc < KPB) {
-                            const float s = carry[tid * KPB + hc];
+                            const float s = carry[lane * KPB + hc];
                             if (s > bs) { bs = s; bsrc = 4; }
                         }
                         if (bsrc == 4) ++hc;
@@ -553,10 +591,10 @@ struct PreItem {
                         best[j] = bs;
                     }
 #pragma unroll
-                    for (int j = 0; j < KPB; ++j) carry[tid * KPB + j] = best[j];
+                    for (int j = 0; j < KPB; ++j) carry[lane * KPB + j] = best[j];
                     // this part's 10 best sampled values (descending; -inf where the sample ran out)
                     if (round == 1) {
-                        float* bl = P.bound + (col0 + n * 32 + tid) * (PF_PARTS * KPB) + ch * KPB;
+                        float* bl = P.bound + (col0 + n * 32 + lane) * (PF_PARTS * KPB) + ch * KPB;
 #pragma unroll
                         for (int j = 0; j < KPB; ++j) bl[j] = best[j];
                     }
@@ -590,16 +628,19 @@ __global__ void bound_merge_kernel(const float* __restrict__ parts, long long nc
     bound1[col] = pv;
 }
 
-template <bool SAMPLE>
-__global__ __launch_bounds__(256, 2) void prefilter_kernel(PrefilterParams P) {
-    __shared__ __attribute__((aligned(16))) uint4 sB0[4 * PF_STAGE_G * 64];
-    __shared__ __attribute__((aligned(16))) uint4 sB1[4 * PF_STAGE_G * 64];
-    __shared__ __attribute__((aligned(16))) uint4 sB2[4 * PF_STAGE_G * 64];
+template <bool SAMPLE, int NG>
+__global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void prefilter_kernel(PrefilterParams P) {
+    __shared__ __attribute__((aligned(16))) uint4 sB0[4 * NG * PF_STAGE_G * 64];
+    __shared__ __attribute__((aligned(16))) uint4 sB1[4 * NG * PF_STAGE_G * 64];
+    __shared__ __attribute__((aligned(16))) uint4 sB2[4 * NG * PF_STAGE_G * 64];
     __shared__ __attribute__((aligned(16))) uint4 sA0[4 * PF_RB * PF_STAGE_G * 64];
     __shared__ __attribute__((aligned(16))) uint4 sA1[4 * PF_RB * PF_STAGE_G * 64];
     __shared__ __attribute__((aligned(16))) uint4 sA2[4 * PF_RB * PF_STAGE_G * 64];
-    __shared__ uint2 sList[SAMPLE ? 1 : 4 * 64];
-#define PF_ITEM_ARGS P, sB0, sB1, sB2, sA0, sA1, sA2, sList
+    constexpr bool RING4 = NG == 2 && LMI_PF_RING2 == 4;
+    __shared__ __attribute__((aligned(16))) uint4 sB3[RING4 ? 4 * NG * PF_STAGE_G * 64 : 1];
+    __shared__ __attribute__((aligned(16))) uint4 sA3[RING4 ? 4 * PF_RB * PF_STAGE_G * 64 : 1];
+    __shared__ uint2 sList[SAMPLE ? 1 : 4 * NG * 64];
+#define PF_ITEM_ARGS P, sB0, sB1, sB2, sA0, sA1, sA2, sB3, sA3, sList
     int* s_item = reinterpret_cast<int*>(sB1);
     int grp = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & (NGRP - 1));
     for (;;) {
@@ -645,15 +686,25 @@ __global__ __launch_bounds__(256, 2) void prefilter_kernel(PrefilterParams P) {
         const int b = s_item[0], local = s_item[1];
         __syncthreads();
         if (b < 0) return;
-        const int m_b = P.m[b];
-        const int nqt = (m_b + TILE_COLS - 1) / TILE_COLS;
+        // query tiles of the bucket: its col-blocks split evenly over nqt = ceil(col-blocks / (4 NG)) tiles
+        // (route_scan_kernel / route_group_kernel count the same nqt); a tile's col-blocks split over the groups
+        const int ncb_b = (P.m[b] + 31) >> 5;
+        const int nqt = (ncb_b + 4 * NG - 1) / (4 * NG);
+        const int per = (ncb_b + nqt - 1) / nqt;
         const int qt = SAMPLE ? local / PF_PARTS : local % nqt, ch = SAMPLE ? local % PF_PARTS : local / nqt;
-        const int ncb = min(4, (m_b - qt * TILE_COLS + 31) >> 5);
-        switch (ncb) {
-            case 1: { PreItem<1, SAMPLE> it{PF_ITEM_ARGS}; it.run(b, qt, ch); break; }
-            case 2: { PreItem<2, SAMPLE> it{PF_ITEM_ARGS}; it.run(b, qt, ch); break; }
-            case 3: { PreItem<3, SAMPLE> it{PF_ITEM_ARGS}; it.run(b, qt, ch); break; }
-            default: { PreItem<4, SAMPLE> it{PF_ITEM_ARGS}; it.run(b, qt, ch); break; }
+        const int cbt0 = qt * per;
+        const int ncb_tile = min(per, ncb_b - cbt0);
+        const int wgrp = (int)(threadIdx.x >> 8);
+        const int ncb_g0 = NG == 1 ? ncb_tile : (ncb_tile + 1) >> 1;
+        int ncb_w = wgrp ? ncb_tile - ncb_g0 : ncb_g0;
+        int cbofs = wgrp ? ncb_g0 : 0;
+        const bool idle = ncb_w == 0;
+        if (idle) { ncb_w = 1; cbofs = 0; }
+        switch (ncb_w) {
+            case 1: { PreItem<1, SAMPLE, NG> it{PF_ITEM_ARGS}; it.run(b, cbt0, ncb_tile, cbofs, idle, ch); break; }
+            case 2: { PreItem<2, SAMPLE, NG> it{PF_ITEM_ARGS}; it.run(b, cbt0, ncb_tile, cbofs, idle, ch); break; }
+            case 3: { PreItem<3, SAMPLE, NG> it{PF_ITEM_ARGS}; it.run(b, cbt0, ncb_tile, cbofs, idle, ch); break; }
+            default: { PreItem<4, SAMPLE, NG> it{PF_ITEM_ARGS}; it.run(b, cbt0, ncb_tile, cbofs, idle, ch); break; }
         }
     }
 }
