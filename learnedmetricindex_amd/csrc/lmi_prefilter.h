@@ -220,6 +220,10 @@ constexpr int PF_SAMPLE = LMI_PF_SAMPLE;  // pass 1 looks at every 16th tile ...
 #ifndef LMI_PF_RING2
 #define LMI_PF_RING2 3  // ring slots of the NG 2 kernel (3 or 4; A/B on MI355X: 4 is 3 % slower, more in flight only raised the load latency)
 #endif
+#ifndef LMI_PF_FUSED
+#define LMI_PF_FUSED 1  // NG 2: DMA pieces interleaved with the MFMA groups of the stage
+#endif
+constexpr int PF_FUSED = LMI_PF_FUSED;
 #ifndef LMI_PF_NG
 #define LMI_PF_NG 2
 #endif
@@ -280,6 +284,7 @@ struct PreItem {
     int cbofs;              // first col-block of this wave's group inside the tile
     float lv[NLIST][KPB];   // pass 1 only
     float thr[NCB];         // pass 2: bound - 2 eps' of this lane's column in col-block n (+inf: idle column)
+    half8 p_a, p_b[NCB];    // NG 2: operands of the stage's deferred last MFMA group (step_fused)
     unsigned pend_pos, pend_row, pend_col;  // pass 2: this lane's candidate of the previous tile ...
     float pend_s;                           // ... whose position atomic is in flight
     f32x16 acc[PF_RB][NCB];
@@ -327,6 +332,87 @@ struct PreItem {
                     acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bq[n], acc[j][n], 0, 0, 0);
             }
         }
+    }
+
+    // NG 2: stage SLOT's MFMAs with the 4 DMA pieces of stage SLOT+RING-1 (slot DST) issued one before each
+    // group of NCB MFMAs.  The fragment reads are inline asm: hipcc orders every ds_read it can see behind
+    // ALL pending LDS-DMA (`s_waitcnt vmcnt(0)`: it cannot tell the ring slots apart once the loop's back
+    // edge merges its bookkeeping), which drains the look-ahead; the ring's own `s_waitcnt vmcnt(N)` +
+    // barrier is the real ordering.  Reads run one MFMA group ahead of their use; every fragment of the
+    // stage has registers of its own (nothing an in-flight MFMA still reads is overwritten).
+    template <int OFF>
+    static __device__ __forceinline__ void lds_rd(half8& r, unsigned addr) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+    }
+    template <int G>
+    __device__ __forceinline__ void rd_b(half8 (&b)[NCB], unsigned aB) {
+        lds_rd<(0 * PF_STAGE_G + G) * 1024>(b[0], aB);
+        if (NCB > 1) lds_rd<(1 * PF_STAGE_G + G) * 1024>(b[NCB > 1 ? 1 : 0], aB);
+        if (NCB > 2) lds_rd<(2 * PF_STAGE_G + G) * 1024>(b[NCB > 2 ? 2 : 0], aB);
+        if (NCB > 3) lds_rd<(3 * PF_STAGE_G + G) * 1024>(b[NCB > 3 ? 3 : 0], aB);
+    }
+    // the reads issued so far have landed; the operands are "defined" here for the compiler
+    static __device__ __forceinline__ void lds_wait(half8& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a) :: "memory"); }
+    static __device__ __forceinline__ void lds_wait(half8& a, half8 (&b)[NCB]) {
+        if (NCB == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b[0]) :: "memory");
+        if (NCB == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b[0]), "+v"(b[NCB > 1 ? 1 : 0]) :: "memory");
+        if (NCB == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b[0]), "+v"(b[NCB > 1 ? 1 : 0]), "+v"(b[NCB > 2 ? 2 : 0]) :: "memory");
+        if (NCB == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b[0]), "+v"(b[NCB > 1 ? 1 : 0]), "+v"(b[NCB > 2 ? 2 : 0]), "+v"(b[NCB > 3 ? 3 : 0]) :: "memory");
+    }
+    template <int J>
+    __device__ __forceinline__ void mma(const half8& a, const half8 (&b)[NCB]) {
+#pragma unroll
+        for (int n = 0; n < NCB; ++n)
+            acc[J][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[n], acc[J][n], 0, 0, 0);
+    }
+
+    // The stage's last MFMA group is deferred across the next barrier (its operands p_a, p_b are already
+    // in registers, so the ring slot is free): it runs while the next stage's first fragment reads are in
+    // flight -- right after a barrier both waves of a SIMD wait for LDS at the same time.
+    template <int SLOT, int DST>
+    __device__ __forceinline__ void step_fused(const uint4* ap0, const uint4* qp, bool pending) {
+        static_assert(PF_STAGE_G == 2 && PF_RB == 2, "written out for 2 k-groups x 2 row-blocks");
+        const uint4* sA = (SLOT == 0 ? sA0 : SLOT == 1 ? sA1 : SLOT == 2 ? sA2 : sA3) + (wr * PF_RB) * PF_STAGE_G * 64 + lane;
+        const uint4* sB = (SLOT == 0 ? sB0 : SLOT == 1 ? sB1 : SLOT == 2 ? sB2 : sB3) + cbofs * PF_STAGE_G * 64 + lane;
+        const unsigned aA = (unsigned)reinterpret_cast<uintptr_t>(sA);  // generic address of LDS: low 32 bits = LDS offset
+        const unsigned aB = (unsigned)reinterpret_cast<uintptr_t>(sB);
+        float4* dA = reinterpret_cast<float4*>((DST == 0 ? sA0 : DST == 1 ? sA1 : DST == 2 ? sA2 : sA3) + (wr * PF_RB + grp) * PF_STAGE_G * 64);
+        float4* dB = reinterpret_cast<float4*>((DST == 0 ? sB0 : DST == 1 ? sB1 : DST == 2 ? sB2 : sB3) + w * PF_STAGE_G * 64);
+        half8 a00, a10, a01, a11, b0[NCB], b1[NCB];  // a<j><g>
+        // fragment (j, g) of A at (j * G + g) KiB, (n, g) of B at (n * G + g) KiB
+        rd_b<0>(b0, aB);
+        lds_rd<(0 * PF_STAGE_G + 0) * 1024>(a00, aA);
+        lds_rd<(1 * PF_STAGE_G + 0) * 1024>(a10, aA);
+        if (pending) mma<1>(p_a, p_b);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_wait(a00, b0);
+        lds_wait(a10);
+        rd_b<1>(b1, aB);
+        lds_rd<(0 * PF_STAGE_G + 1) * 1024>(a01, aA);
+        lds_rd<(1 * PF_STAGE_G + 1) * 1024>(a11, aA);
+#ifndef LMI_ABL_NOLOAD
+        glds16(reinterpret_cast<const float4*>(ap0), dA);
+#endif
+        mma<0>(a00, b0);
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef LMI_ABL_NOLOAD
+        glds16(reinterpret_cast<const float4*>(ap0 + 64), dA + 64);
+#endif
+        mma<1>(a10, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_wait(a01, b1);
+        lds_wait(a11);
+#ifndef LMI_ABL_NOLOAD
+        glds16(reinterpret_cast<const float4*>(qp), dB);
+#endif
+        mma<0>(a01, b1);
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef LMI_ABL_NOLOAD
+        glds16(reinterpret_cast<const float4*>(qp + 64), dB + 64);
+#endif
+        p_a = a11;
+#pragma unroll
+        for (int n = 0; n < NCB; ++n) p_b[n] = b1[n];
     }
 
     // pass 1: per-lane values-only top-10 lists
@@ -509,14 +595,32 @@ struct PreItem {
                 ap1 = aslab + (size_t)min(rb_in_b0 + (vt_n * TSTEP * 4 + wr) * PF_RB + 1, rb_last) * rb_stride; \
             }                                                                                     \
         }
-#define PF_STEP(SLOT, LIVE)                                                                       \
+#ifdef LMI_ABL_NOWAIT  // timing-only ablation builds: garbage results
+#define PF_WAIT_LANDED
+#else
+#define PF_WAIT_LANDED                                                                            \
         if (NG == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                             \
         else if (RING == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                      \
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                     \
-        __builtin_amdgcn_s_barrier();                                                             \
-        issue_dma<(SLOT + RING - 1) % RING>(ap0, ap1, qp);                                        \
-        PF_ADVANCE                                                                                \
-        if (LIVE) compute_dma<SLOT>();
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#endif
+#ifdef LMI_ABL_NOBAR
+#define PF_BARRIER
+#else
+#define PF_BARRIER __builtin_amdgcn_s_barrier();
+#endif
+        // LMI_PF_FUSED (NG 2): the stage's 4 DMA pieces are issued one before each group of 4 MFMAs instead of
+        // all at once after the barrier (where both waves of a SIMD sit in DMA issue with the MFMA pipe idle).
+#define PF_STEP(SLOT, LIVE)                                                                       \
+        PF_WAIT_LANDED                                                                            \
+        PF_BARRIER                                                                                \
+        if (NG == 2 && PF_FUSED && (LIVE)) {                                                      \
+            step_fused<SLOT, (SLOT + RING - 1) % RING>(ap0, qp, SLOT > 0 || t > 0);               \
+            PF_ADVANCE                                                                            \
+        } else {                                                                                  \
+            issue_dma<(SLOT + RING - 1) % RING>(ap0, ap1, qp);                                    \
+            PF_ADVANCE                                                                            \
+            if (LIVE) compute_dma<SLOT>();                                                        \
+        }
         if (nvt > 0) {
             issue_dma<0>(ap0, ap1, qp);
             PF_ADVANCE
@@ -536,6 +640,7 @@ struct PreItem {
                     PF_STEP(3, t + 3 < NS)
                 }
             }
+            if (NG == 2 && PF_FUSED) mma<1>(p_a, p_b);  // the tile's last deferred group
             if (SAMPLE) epilogue_sample(rb_in_b0 + vt * TSTEP * 4 * PF_RB, n_b);
             else epilogue_emit(rb_in_b0 + vt * TSTEP * 4 * PF_RB, n_b, col0);
         }
@@ -543,6 +648,8 @@ struct PreItem {
         __syncthreads();
 #undef PF_STEP
 #undef PF_ADVANCE
+#undef PF_WAIT_LANDED
+#undef PF_BARRIER
         if (!SAMPLE) {
             flush_pending();
             return;
