@@ -415,7 +415,7 @@ struct PreItem {
         for (int n = 0; n < NCB; ++n) p_b[n] = b1[n];
     }
 
-    // pass 1: per-lane values-only top-10 lists
+    // pass 1: per-lane values-only top-10 lists (predicated insert; a ballot + branch per score was 20 % slower)
     __device__ __forceinline__ void epilogue_sample(int rb_tile0, int n_b) {
 #pragma unroll
         for (int j = 0; j < PF_RB; ++j) {
@@ -882,11 +882,18 @@ __device__ __forceinline__ void write_rank_list(int lane, float my_s, unsigned m
 // selection passes; the query is staged in LDS once per wave; every survivor's row is streamed in
 // 128-byte pieces (8 independent 16-byte loads in flight per lane) through the k-ordered fmaf chain.
 constexpr int RS_WAVES = 4;
+#ifndef LMI_RS_AHEAD
+#define LMI_RS_AHEAD 8  // 128-byte lines of a survivor's row requested ahead of the chain (select_rescore_kernel)
+#endif
+#ifndef LMI_RS_WAVES_PER_EU
+#define LMI_RS_WAVES_PER_EU 6  // the kernel is latency-bound (random 3-KiB rows, a serial chain): occupancy is its parallelism
+#endif
 constexpr int RS_MAXD = 1024;  // queries up to this many dims are staged in LDS (else read from L2)
 
-__global__ __launch_bounds__(64 * RS_WAVES) void select_rescore_kernel(RescoreParams P) {
+__global__ __launch_bounds__(64 * RS_WAVES) __attribute__((amdgpu_waves_per_eu(LMI_RS_WAVES_PER_EU))) void select_rescore_kernel(RescoreParams P) {
     __shared__ unsigned keep_row[RS_WAVES][PF_KEEP];
     __shared__ __attribute__((aligned(16))) float qs[RS_WAVES][RS_MAXD];
+    __shared__ unsigned sink[RS_WAVES][64];  // destination of the prefetching LDS-DMA loads (never read)
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int p = blockIdx.x * RS_WAVES + wv;
     if (p >= P.nslots) return;
@@ -911,47 +918,51 @@ __global__ __launch_bounds__(64 * RS_WAVES) void select_rescore_kernel(RescorePa
         for (int k = lane; k < P.d; k += 64) qs[wv][k] = qg[k];
     const float* cs = P.cand_s + (size_t)col * PF_CAP;
     const unsigned* cr = P.cand_row + (size_t)col * PF_CAP;
+    // The kernel is latency-bound (random 3-KiB rows, one serial chain per survivor), so its speed is its
+    // occupancy: registers are kept to the candidates' order-preserving integer images (the rows are
+    // re-read for the ~14 survivors only) and one 128-byte piece of the row in flight per lane.
     constexpr int PER = PF_CAP / 64;
-    float cv[PER];
-    unsigned cw[PER];
+    const int nper = (int)((cnt + 63u) >> 6);  // wave-uniform: register slots in use (~4 of 16 at C2)
+    unsigned key[PER];  // monotone image of shat; 0 = no candidate
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int e = lane + 64 * i;
-        cv[i] = e < (int)cnt ? cs[e] : -INFINITY;
-        cw[i] = e < (int)cnt ? cr[e] : NOROW;
+        key[i] = 0u;
+        if (i < nper && e < (int)cnt) {
+            const unsigned bits = __float_as_uint(cs[e]);
+            key[i] = bits ^ ((bits >> 31) ? 0xffffffffu : 0x80000000u);
+        }
     }
-    // That: 10 selection passes in (value desc, position asc) order, all in registers
-    float pv = INFINITY;
-    int pi = -1;
-    for (int t = 0; t < KPB; ++t) {
-        float bv = -INFINITY;
-        int bi = 0x7fffffff;
+    // That = 10th largest shat: bisection on the keys, counting with ballots (32 x nper compares and
+    // scalar popcounts; ten argmax passes over the wave cost 120 ds_bpermute round trips per slot).
+    // Fewer than 10 candidates: -inf, everything survives.
+    float pv = -INFINITY;
+    if (cnt >= (unsigned)KPB) {
+        unsigned T = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned probe = T | (1u << bit);
+            int c = 0;
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int e = lane + 64 * i;
-            const bool live = e < (int)cnt;
-            const bool after = (cv[i] < pv) || (cv[i] == pv && e > pi);
-            if (live && after && (cv[i] > bv || (cv[i] == bv && e < bi))) { bv = cv[i]; bi = e; }
+            for (int i = 0; i < PER; ++i)
+                if (i < nper) c += (int)__popcll(__ballot(key[i] >= probe));
+            if (c >= KPB) T = probe;
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o);
-            const int oi = __shfl_xor(bi, o);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-        }
-        pv = bv;  // -inf once the candidates are exhausted (fewer than 10): everything survives
-        pi = bi;
+        pv = __uint_as_float(T ^ ((T >> 31) ? 0x80000000u : 0xffffffffu));
     }
     const float cut = pv - P.eps2[col];
+    const unsigned cbits = __float_as_uint(cut);
+    // key of the cut; (-inf) - eps = -inf maps below every candidate's key
+    const unsigned kcut = cut != cut ? 1u : cbits ^ ((cbits >> 31) ? 0xffffffffu : 0x80000000u);
     // survivors -> keep_row[] (order is irrelevant: the final sort is by (score, row))
     unsigned nk = 0;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        const bool keep = (lane + 64 * i) < (int)cnt && cv[i] >= cut;
+        if (i >= nper) break;
+        const bool keep = key[i] != 0u && key[i] >= kcut;
         const unsigned long long bal = __ballot(keep);
         if (keep) {
             const unsigned k = nk + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
-            if (k < (unsigned)PF_KEEP) keep_row[wv][k] = cw[i];
+            if (k < (unsigned)PF_KEEP) keep_row[wv][k] = cr[lane + 64 * i];
         }
         nk += (unsigned)__popcll(bal);
     }
@@ -974,7 +985,51 @@ __global__ __launch_bounds__(64 * RS_WAVES) void select_rescore_kernel(RescorePa
         const float* qv = q_lds ? qs[wv] : qg;
         float acc = 0.0f;
         int k = 0;
-        if ((P.d & 3) == 0) {
+        if (q_lds && (P.d & 31) == 0) {
+            // One 128-byte line of the row per step and lane.  With only that line outstanding the DRAM
+            // sees 24 isolated accesses per 3-KiB row (2.1 TB/s measured).  Registers for more lines cost
+            // occupancy, so the lines RS_AHEAD steps ahead are pulled into L2/MALL by 4-byte-per-lane
+            // LDS-DMA loads into a sink (no VGPRs; issued AFTER the step's own loads, since vmcnt returns in
+            // order).  The query is read from LDS by inline asm: hipcc would order a visible ds_read
+            // behind every pending LDS-DMA.
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            const unsigned qaddr = (unsigned)reinterpret_cast<uintptr_t>(&qs[wv][0]);
+            constexpr int RS_AHEAD = LMI_RS_AHEAD;
+#pragma unroll
+            for (int j = 1; j <= RS_AHEAD; ++j)
+                if (j * 32 < P.d)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x + j * 32),
+                                                     (__attribute__((address_space(3))) void*)&sink[wv][0], 4, 0, 0);
+            for (; k < P.d; k += 32) {
+                // the step's line by inline asm, then exactly one prefetch (past the end: the last line again),
+                // then `vmcnt(1)`: the line has landed, the prefetch may still be out (hipcc waits for vmcnt(0))
+                f32x4 xv[8];
+                const float* xk = x + k;
+                asm volatile("global_load_dwordx4 %0, %8, off\n\tglobal_load_dwordx4 %1, %8, off offset:16\n\t"
+                             "global_load_dwordx4 %2, %8, off offset:32\n\tglobal_load_dwordx4 %3, %8, off offset:48\n\t"
+                             "global_load_dwordx4 %4, %8, off offset:64\n\tglobal_load_dwordx4 %5, %8, off offset:80\n\t"
+                             "global_load_dwordx4 %6, %8, off offset:96\n\tglobal_load_dwordx4 %7, %8, off offset:112"
+                             : "=&v"(xv[0]), "=&v"(xv[1]), "=&v"(xv[2]), "=&v"(xv[3]), "=&v"(xv[4]), "=&v"(xv[5]), "=&v"(xv[6]), "=&v"(xv[7])
+                             : "v"(xk) : "memory");
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x + min(k + (RS_AHEAD + 1) * 32, P.d - 32)),
+                                                 (__attribute__((address_space(3))) void*)&sink[wv][0], 4, 0, 0);
+                asm volatile("s_waitcnt vmcnt(1)"
+                             : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]), "+v"(xv[4]), "+v"(xv[5]), "+v"(xv[6]), "+v"(xv[7])
+                             :: "memory");
+                f32x4 qq[8];
+                const unsigned qa = qaddr + (unsigned)k * 4u;
+                asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\t"
+                             "ds_read_b128 %3, %8 offset:48\n\tds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\t"
+                             "ds_read_b128 %6, %8 offset:96\n\tds_read_b128 %7, %8 offset:112\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(qq[0]), "=&v"(qq[1]), "=&v"(qq[2]), "=&v"(qq[3]), "=&v"(qq[4]), "=&v"(qq[5]), "=&v"(qq[6]), "=&v"(qq[7])
+                             : "v"(qa) : "memory");
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    acc = __builtin_fmaf(qq[i].x, xv[i].x, acc); acc = __builtin_fmaf(qq[i].y, xv[i].y, acc);
+                    acc = __builtin_fmaf(qq[i].z, xv[i].z, acc); acc = __builtin_fmaf(qq[i].w, xv[i].w, acc);
+                }
+            }
+        } else if ((P.d & 3) == 0) {
             for (; k + 32 <= P.d; k += 32) {  // 8 independent 16-byte loads in flight, then 32 chained fmas
                 float4 xv[8];
 #pragma unroll
@@ -990,24 +1045,23 @@ __global__ __launch_bounds__(64 * RS_WAVES) void select_rescore_kernel(RescorePa
         for (; k < P.d; ++k) acc = __builtin_fmaf(qv[k], x[k], acc);
         s = acc;
     }
-    // 10 best by (score desc, row asc)
-    float my_s = -INFINITY;
-    unsigned my_r = NOROW;
-    for (int j = 0; j < KPB; ++j) {
-        float bs = s;
-        unsigned br = row;
-        int wl = lane;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float os = __shfl_xor(bs, o);
-            const unsigned orr = __shfl_xor(br, o);
-            const int ol = __shfl_xor(wl, o);
-            if (better(os, orr, bs, br) || (os == bs && orr == br && ol < wl)) { bs = os; br = orr; wl = ol; }
-        }
-        if (lane == j) { my_s = bs; my_r = br; }
-        if (lane == wl) { s = -INFINITY; row = NOROW; }
+    // 10 best by (score desc, row asc): a survivor's output position is the number of survivors that beat
+    // it (rows are distinct, so positions are too); the owner lane writes the entry itself.
+    int pos = 0;
+    for (int l = 0; l < (int)nk; ++l) {
+        const float os = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), l));
+        const unsigned orr = (unsigned)__builtin_amdgcn_readlane((int)row, l);
+        pos += better(os, orr, s, row) ? 1 : 0;
     }
-    write_rank_list(lane, my_s, my_r, n_b, rb0, P.raw, P.ids_slab, rd, ri);
+    const int nreal = min(min((int)nk, KPB), n_b);
+    if (lane < (int)nk && pos < KPB) {
+        rd[pos] = P.raw ? s : 1.0f - s;
+        ri[pos] = P.raw ? row : P.ids_slab[(size_t)rb0 * 32 + row];
+    }
+    if (lane >= nreal && lane < KPB) {  // faiss padding (Q4): -FLT_MAX similarity, last id of the bucket
+        rd[lane] = P.raw ? -FMAXV : 1.0f - (-FMAXV);
+        ri[lane] = P.raw ? NOROW : P.ids_slab[(size_t)rb0 * 32 + (n_b - 1)];
+    }
 }
 
 // statistics on request: out[0] += survivors, out[1] += fallback slots
