@@ -465,6 +465,14 @@ __device__ __forceinline__ void glds16(const float4* gsrc, float4* lds_wave_base
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// the same with the instruction's immediate offset OFF (bytes), which the hardware adds to BOTH addresses:
+// consecutive 1-KiB fragments of one stream share the address registers and the M0 base
+template <int OFF>
+__device__ __forceinline__ void glds16o(const float4* gsrc, float4* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, OFF, 0);
+}
+
 // sorted (descending) insert of (s,row) into a 10-entry register list; caller checked s > v[9].
 __device__ __forceinline__ void list_insert(float (&v)[KPB], unsigned (&id)[KPB], float s, unsigned row) {
 #pragma unroll

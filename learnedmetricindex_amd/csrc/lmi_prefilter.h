@@ -295,19 +295,19 @@ struct PreItem {
         return;
 #endif
 #ifdef LMI_ABL_HOTA    // every block streams the same 64 KiB of A: all L2 hits
-        ap0 = P.slab16 + (((size_t)(ap0 - P.slab16)) & 2047) + lane;
-        ap1 = P.slab16 + (((size_t)(ap1 - P.slab16)) & 2047) + 2048 + lane;
+        ap0 = P.slab16 + (((size_t)(ap0 - P.slab16)) & 2047);
+        ap1 = P.slab16 + (((size_t)(ap1 - P.slab16)) & 2047) + 2048;
 #endif
         uint4* sA = SLOT == 0 ? sA0 : SLOT == 1 ? sA1 : SLOT == 2 ? sA2 : sA3;
         uint4* sB = SLOT == 0 ? sB0 : SLOT == 1 ? sB1 : SLOT == 2 ? sB2 : sB3;
         // this wave stages row-blocks j = grp, grp + NG, .. of its row-wave's PF_RB (ap0 [, ap1]) and col-block w
 #pragma unroll
         for (int g = 0; g < PF_STAGE_G; ++g) {
-            glds16(reinterpret_cast<const float4*>(ap0 + g * 64),
+            glds16(reinterpret_cast<const float4*>(ap0 + g * 64 + lane),
                    reinterpret_cast<float4*>(sA + ((wr * PF_RB + (NG == 1 ? 0 : grp)) * PF_STAGE_G + g) * 64));
             if (NG == 1)
-                glds16(reinterpret_cast<const float4*>(ap1 + g * 64), reinterpret_cast<float4*>(sA + ((wr * PF_RB + 1) * PF_STAGE_G + g) * 64));
-            glds16(reinterpret_cast<const float4*>(qp + g * 64), reinterpret_cast<float4*>(sB + (w * PF_STAGE_G + g) * 64));
+                glds16(reinterpret_cast<const float4*>(ap1 + g * 64 + lane), reinterpret_cast<float4*>(sA + ((wr * PF_RB + 1) * PF_STAGE_G + g) * 64));
+            glds16(reinterpret_cast<const float4*>(qp + g * 64 + lane), reinterpret_cast<float4*>(sB + (w * PF_STAGE_G + g) * 64));
         }
     }
 
@@ -391,24 +391,24 @@ struct PreItem {
         lds_rd<(0 * PF_STAGE_G + 1) * 1024>(a01, aA);
         lds_rd<(1 * PF_STAGE_G + 1) * 1024>(a11, aA);
 #ifndef LMI_ABL_NOLOAD
-        glds16(reinterpret_cast<const float4*>(ap0), dA);
+        glds16(reinterpret_cast<const float4*>(ap0 + lane), dA);
 #endif
         mma<0>(a00, b0);
         __builtin_amdgcn_sched_barrier(0);
 #ifndef LMI_ABL_NOLOAD
-        glds16(reinterpret_cast<const float4*>(ap0 + 64), dA + 64);
+        glds16o<1024>(reinterpret_cast<const float4*>(ap0 + lane), dA);
 #endif
         mma<1>(a10, b0);
         __builtin_amdgcn_sched_barrier(0);
         lds_wait(a01, b1);
         lds_wait(a11);
 #ifndef LMI_ABL_NOLOAD
-        glds16(reinterpret_cast<const float4*>(qp), dB);
+        glds16(reinterpret_cast<const float4*>(qp + lane), dB);
 #endif
         mma<0>(a01, b1);
         __builtin_amdgcn_sched_barrier(0);
 #ifndef LMI_ABL_NOLOAD
-        glds16(reinterpret_cast<const float4*>(qp + 64), dB + 64);
+        glds16o<1024>(reinterpret_cast<const float4*>(qp + lane), dB);
 #endif
         p_a = a11;
 #pragma unroll
@@ -535,7 +535,8 @@ struct PreItem {
     // of the whole bucket and writes its 10 best values; !SAMPLE: chunk `ch`, every tile.
     __device__ __forceinline__ void run(int b, int cbt0, int ncb_tile, int cbofs_, bool idle, int ch) {
         const int tid = threadIdx.x;
-        lane = tid & 63; w = tid >> 6; h = lane >> 5; c = lane & 31;
+        lane = tid & 63; h = lane >> 5; c = lane & 31;
+        w = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: stage pointers and LDS destinations stay in SGPRs
         wr = w & 3; grp = w >> 2; cbofs = cbofs_;
         const int KG = P.KG16, NS = KG / PF_STAGE_G;
         const int n_b = P.nb_rows[b];
@@ -549,8 +550,9 @@ struct PreItem {
         const int cb_tile = P.cb_start[b] + cbt0;                 // the tile's first col-block (global)
         const int m_left = idle ? 0 : P.m[b] - (cbt0 + cbofs) * 32;  // live columns from this group's first one
         const size_t col0 = (size_t)(cb_tile + cbofs) * 32;
-        const uint4* aslab = P.slab16 + ((size_t)P.rb_start[b] * KG) * 64 + lane;
-        const uint4* bbase = P.qfrag16 + ((size_t)(cb_tile + min(w, ncb_tile - 1)) * KG) * 64 + lane;
+        // wave-uniform bases; the lane's 16 bytes are added at the DMA (SGPR base + 32-bit lane offset)
+        const uint4* aslab = P.slab16 + ((size_t)P.rb_start[b] * KG) * 64;
+        const uint4* bbase = P.qfrag16 + ((size_t)(cb_tile + min(w, ncb_tile - 1)) * KG) * 64;
         const size_t rb_stride = (size_t)KG * 64;
         const int rb_last = nrb_b - 1;
 #pragma unroll
