@@ -652,9 +652,15 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         CHK(h->cand_s.reserve(ncols * PF_CAP * 4));
         CHK(h->fallback.reserve((size_t)nslots * 4));
         CHK(h->nkeep.reserve((size_t)nslots * 4));
-        CHK(h->pf_bound.reserve(ncols * PF_PARTS * KPB * 4));
+        // pass-1 items per (bucket, query tile): enough of them to fill the chip.  The host only knows an
+        // estimate of the (bucket, tile) pairs: this rank's share of the slots / 256 + its buckets.
+        long long owned_rows = 0, owned_buckets = 0;
+        for (int b = 0; b < L; ++b) { owned_rows += h->h_nb_rows[b]; owned_buckets += h->h_nb_rows[b] > 0; }
+        const double pairs_est = (double)nslots * (double)owned_rows / (double)std::max<long long>(1, h->N) / (32.0 * 4 * PF_NG) + (double)owned_buckets;
+        const int pf_parts = pairs_est * 4 >= 4.0 * h->num_cus ? 4 : pairs_est * 8 >= 4.0 * h->num_cus ? 8 : PF_PARTS_MAX;
+        CHK(h->pf_bound.reserve(ncols * pf_parts * KPB * 4));
         HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->pf_bound.p), (int)0xFF800000u /* -inf */,
-                                 ncols * PF_PARTS * KPB, h->stream));
+                                 ncols * pf_parts * KPB, h->stream));
         HIPCHK(hipMemsetAsync(h->qmaxbits.p, 0, 16, h->stream));
         HIPCHK(hipMemsetAsync(h->cand_cnt.p, 0, ncols * 4, h->stream));
         HIPCHK(hipMemsetAsync(h->stats.as<long long>() + 2, 0, 16, h->stream));
@@ -691,6 +697,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         F.qt_base = R.qt_base;
         F.by_work = R.order_tmp;
         F.head = S.head;
+        F.parts = pf_parts;
         F.bound = h->pf_bound.as<float>();
         F.bound1 = S.col_thr;
         F.eps2 = h->eps2.as<float>();
@@ -700,7 +707,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         constexpr int PF_BLOCKS_PER_CU = PF_NG == 1 ? 2 : 1;
         prefilter_kernel<true, PF_NG><<<h->num_cus * PF_BLOCKS_PER_CU, 256 * PF_NG, 0, h->stream>>>(F);   // pass 1: bounds from a sample
         HIPCHK(hipGetLastError());
-        bound_merge_kernel<<<cdiv((long long)ncols, 256), 256, 0, h->stream>>>(F.bound, (long long)ncols, F.bound1);
+        bound_merge_kernel<<<cdiv((long long)ncols, 256), 256, 0, h->stream>>>(F.bound, (long long)ncols, pf_parts, F.bound1);
         HIPCHK(hipGetLastError());
         CHK(record(h, 5));
         prefilter_kernel<false, PF_NG><<<h->num_cus * PF_BLOCKS_PER_CU, 256 * PF_NG, 0, h->stream>>>(F);  // pass 2: candidates

@@ -228,7 +228,8 @@ constexpr int PF_FUSED = LMI_PF_FUSED;
 #define LMI_PF_NG 2
 #endif
 constexpr int PF_NG = LMI_PF_NG;  // wave groups per prefilter block (PreItem): 1 -> 128-query tiles, 2 -> 256-query tiles
-constexpr int PF_PARTS = 4;    // ... split over 4 items per (bucket, query tile), merged by the consumers
+constexpr int PF_PARTS_MAX = 16;  // ... split over P.parts = 4, 8 or 16 items per (bucket, query tile) (the host picks: enough
+                                 // items to fill the chip also when a rank owns 1/8 of the buckets), merged by the consumers
 
 struct PrefilterParams {
     const uint4* slab16;
@@ -248,7 +249,8 @@ struct PrefilterParams {
     const int* grp_n;
     const int* grp_total;
     unsigned* head;       // [NGRP] pass-2 queue heads; [NGRP] = pass-1 head
-    float* bound;         // [columns][PF_PARTS][KPB] pass 1: each part's 10 best sampled shat
+    int parts;            // pass-1 items per (bucket, query tile): 4, 8 or 16
+    float* bound;         // [columns][parts][KPB] pass 1: each part's 10 best sampled shat
     float* bound1;        // [columns] bound_merge_kernel: 10th best of the union of the parts -> pass 2
     const float* eps2;    // 2 eps' per column
     unsigned* cand_cnt;   // [columns]
@@ -531,7 +533,7 @@ struct PreItem {
 
     // The tile = col-blocks [cbt0, cbt0 + ncb_tile) of bucket b; this wave's group owns NCB of them from cbofs
     // (`idle`: none -- the wave stages its share, computes a duplicate and emits nothing).
-    // SAMPLE: `ch` is the part p in [0, PF_PARTS): the item covers the tiles (p + PF_PARTS*i)*PF_SAMPLE, i = 0,1,..
+    // SAMPLE: `ch` is the part p in [0, P.parts): the item covers the tiles (p + P.parts*i)*PF_SAMPLE, i = 0,1,..
     // of the whole bucket and writes its 10 best values; !SAMPLE: chunk `ch`, every tile.
     __device__ __forceinline__ void run(int b, int cbt0, int ncb_tile, int cbofs_, bool idle, int ch) {
         const int tid = threadIdx.x;
@@ -543,7 +545,7 @@ struct PreItem {
         const int nrb_b = (n_b + 31) >> 5;
         const int nrb_all = SAMPLE ? nrb_b : min(P.chunk_rb, nrb_b - ch * P.chunk_rb);
         const int nvt_all = (nrb_all + 4 * PF_RB - 1) / (4 * PF_RB);
-        const int TSTEP = SAMPLE ? PF_SAMPLE * PF_PARTS : 1;      // tile stride
+        const int TSTEP = SAMPLE ? PF_SAMPLE * P.parts : 1;       // tile stride
         const int t0 = SAMPLE ? ch * PF_SAMPLE : 0;               // first tile
         const int nvt = nvt_all > t0 ? (nvt_all - t0 + TSTEP - 1) / TSTEP : 0;  // tiles this item processes
         const int rb_in_b0 = SAMPLE ? t0 * 4 * PF_RB : ch * P.chunk_rb;
@@ -703,7 +705,7 @@ struct PreItem {
                     for (int j = 0; j < KPB; ++j) carry[lane * KPB + j] = best[j];
                     // this part's 10 best sampled values (descending; -inf where the sample ran out)
                     if (round == 1) {
-                        float* bl = P.bound + (col0 + n * 32 + lane) * (PF_PARTS * KPB) + ch * KPB;
+                        float* bl = P.bound + (col0 + n * 32 + lane) * (size_t)(P.parts * KPB) + ch * KPB;
 #pragma unroll
                         for (int j = 0; j < KPB; ++j) bl[j] = best[j];
                     }
@@ -714,25 +716,27 @@ struct PreItem {
     }
 };
 
-// 10th best of the union of the PF_PARTS sampled lists of every column (each sorted descending)
-__global__ void bound_merge_kernel(const float* __restrict__ parts, long long ncols, float* __restrict__ bound1) {
+// 10th best of the union of the `nparts` sampled lists of every column (each sorted descending): ten steps
+// of a merge by the lists' heads (4-bit cursors)
+__global__ void bound_merge_kernel(const float* __restrict__ parts, long long ncols, int nparts, float* __restrict__ bound1) {
     const long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= ncols) return;
-    float v[PF_PARTS * KPB];
-#pragma unroll
-    for (int i = 0; i < PF_PARTS * KPB; ++i) v[i] = parts[col * (PF_PARTS * KPB) + i];
-    float pv = INFINITY;
-    int pi = -1;
-    for (int j = 0; j < KPB; ++j) {  // selection in (value desc, position asc) order
+    const float* v = parts + col * (long long)(nparts * KPB);
+    unsigned long long heads = 0;  // 16 lists x 4 bits
+    float pv = -INFINITY;
+    for (int j = 0; j < KPB; ++j) {
         float bv = -INFINITY;
-        int bi = 0x7fffffff;
-#pragma unroll
-        for (int i = 0; i < PF_PARTS * KPB; ++i) {
-            const bool after = (v[i] < pv) || (v[i] == pv && i > pi);
-            if (after && (v[i] > bv || (v[i] == bv && i < bi))) { bv = v[i]; bi = i; }
+        int bi = -1;
+        for (int i = 0; i < nparts; ++i) {
+            const int hd = (int)((heads >> (4 * i)) & 15ull);
+            if (hd < KPB) {
+                const float s = v[i * KPB + hd];
+                if (s > bv) { bv = s; bi = i; }
+            }
         }
-        pv = bv;
-        pi = bi;
+        pv = bv;  // -inf once the sample is exhausted: fewer than 10 sampled rows
+        if (bi < 0) break;
+        heads += 1ull << (4 * bi);
     }
     bound1[col] = pv;
 }
@@ -756,17 +760,17 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void prefilter_kernel(Pr
         if (threadIdx.x == 0) {
             int b = -1, local = 0;
             if (SAMPLE) {  // one plain queue of (bucket, query tile) items
-                const int tot = P.qt_base[P.L] * PF_PARTS;
+                const int tot = P.qt_base[P.L] * P.parts;
                 const int it = (int)atomicAdd(&P.head[NGRP], 1u);
                 if (it < tot) {
-                    const int pair = it / PF_PARTS;  // (bucket, query tile) pair; parts adjacent in the queue
+                    const int pair = it / P.parts;  // (bucket, query tile) pair; parts adjacent in the queue
                     int lo = 0, hi = P.L;
                     while (hi - lo > 1) {
                         const int mid = (lo + hi) >> 1;
                         if (P.qt_base[mid] <= pair) lo = mid; else hi = mid;
                     }
                     b = P.by_work[lo];
-                    local = (pair - P.qt_base[lo]) * PF_PARTS + (it % PF_PARTS);
+                    local = (pair - P.qt_base[lo]) * P.parts + (it % P.parts);
                 }
             } else {
                 for (int tries = 0; tries < NGRP; ++tries) {
@@ -800,7 +804,7 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void prefilter_kernel(Pr
         const int ncb_b = (P.m[b] + 31) >> 5;
         const int nqt = (ncb_b + 4 * NG - 1) / (4 * NG);
         const int per = (ncb_b + nqt - 1) / nqt;
-        const int qt = SAMPLE ? local / PF_PARTS : local % nqt, ch = SAMPLE ? local % PF_PARTS : local / nqt;
+        const int qt = SAMPLE ? local / P.parts : local % nqt, ch = SAMPLE ? local % P.parts : local / nqt;
         const int cbt0 = qt * per;
         const int ncb_tile = min(per, ncb_b - cbt0);
         const int wgrp = (int)(threadIdx.x >> 8);
