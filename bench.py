@@ -198,6 +198,21 @@ def main():
         gt = gt_i.cpu().numpy().astype(np.int64)
         recall = float(np.mean([len(set(a) & set(b)) / float(k) for a, b in zip(got, gt)]))
 
+    # ------------------------------------------------------------------ host boundary (PCIe inclusive), N=1
+    # host numpy in -> host numpy out through the C ABI with host pointers (pageable memory): reported
+    # beside the bench line, never as `value`
+    host_boundary = None
+    if rank == 0 and world == 1 and not args.emulate_shard:
+        qh_all = queries.cpu().numpy()
+        eng.search(qh_all, qh_all, nb, k)
+        t_h = time.perf_counter()
+        for _ in range(3):
+            hd, hi, _hb = eng.search(qh_all, qh_all, nb, k)
+        t_h = (time.perf_counter() - t_h) / 3
+        assert np.array_equal(hi.view(np.int32), out_i.cpu().numpy().view(np.int32)), "host-pointer path differs"
+        host_boundary = {"value": round(nq / t_h, 1), "unit": "queries/s", "ms_per_batch": round(t_h * 1e3, 3),
+                         "what": "lmi_search with host pointers: pageable query upload + search + result download"}
+
     # ------------------------------------------------------------------ CPU baseline (oracle), rank 0, N=1
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -298,6 +313,7 @@ def main():
             "prefilter": None if args.exact else {"survivors_per_slot": round(pf_survivors / max(1, nq * nb), 2),
                                                    "fallback_slots": int(pf_fallbacks)},
             "cpu_baseline": cpu,
+            "host_boundary": host_boundary,
             **({"diagnostic": f"emulated shard {args.emulate_shard}: NOT a bench line"} if args.emulate_shard else {}),
             "phases_ms": {"inference": round(float(phases[0]), 4), "route_pack": round(float(phases[1]), 4),
                           "scan": round(float(phases[2]), 4), "merge": round(float(phases[3]), 4),
