@@ -123,3 +123,34 @@ def test_wide_vectors_beyond_lds_query_staging(capi, oracle):
     np.testing.assert_array_equal(ii[0], (rows[I[0]] + 1).astype(np.uint32))
     np.testing.assert_array_equal(dd[0], np.float32(1) - D[0])
     idx.close()
+
+
+@pytest.mark.parametrize("d", [96, 80])
+def test_query_tile_shapes(capi, oracle, d):
+    """Every split of a bucket's queries over 256-query tiles and the two wave groups of a block: buckets that
+    receive 1 ... 600 queries (1-8 col-blocks per tile, uneven groups, an idle group, several tiles) and hold
+    a ragged number of rows (several 2048-row chunks, a partial last tile); d = 96 is 3 stages of 32 k,
+    d = 80 pads a stage.  Prefilter and exact mode must agree bit for bit; one bucket is checked against the oracle."""
+    rs = np.random.RandomState(21)
+    m_per_bucket = [1, 31, 33, 64, 65, 96, 127, 129, 160, 200, 255, 257, 300, 385, 513, 600]
+    L = len(m_per_bucket)
+    sizes = [rs.randint(300, 5000) for _ in range(L)]
+    sizes[3], sizes[7] = 4096 + 7, 37
+    labels = np.concatenate([np.full(n, b) for b, n in enumerate(sizes)])
+    rs.shuffle(labels)
+    X = rs.randn(labels.size, d).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    order = np.concatenate([np.full(m, b) for b, m in enumerate(m_per_bucket)]).astype(np.int32)
+    rs.shuffle(order)
+    order = order[:, None]
+    Q = rs.randn(order.shape[0], d).astype(np.float32)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    (d1, i1, sv, fb), (d0, i0, _, _) = both_modes(capi, X, labels, L, Q, order, chunk_rows=2048)
+    np.testing.assert_array_equal(i1, i0)
+    np.testing.assert_array_equal(d1, d0)
+    b = 12
+    rows = np.flatnonzero(labels == b)
+    qsel = np.flatnonzero(order[:, 0] == b)
+    D, I = oracle.knn_ip(Q[qsel], X[rows], 10)
+    np.testing.assert_array_equal(i1[qsel], (rows[I] + 1).astype(np.uint32))
+    np.testing.assert_array_equal(d1[qsel], np.float32(1) - D)
