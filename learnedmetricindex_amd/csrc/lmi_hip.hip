@@ -145,7 +145,7 @@ extern "C" LMI_API int lmi_create(int device, lmi_index** out) {
     h->num_cus = prop.multiProcessorCount;
     // route_group_kernel stages 20 bytes per bucket in dynamic LDS (fan-outs up to 8 000 buckets)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&route_group_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));  // its static LDS: 36 bytes
     int occ = 0;
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_kernel, 256, SCAN_LDS));
     h->scan_blocks_per_cu = std::max(1, std::min(occ, RB == 1 ? 2 : 1));
@@ -595,11 +595,40 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     R.qt_base = R.order_tmp + L;
     R.tile_cb = (h->prefilter && h->have16) ? 4 * PF_NG : 4;
 
-    HIPCHK(hipMemsetAsync(h->m.p, 0, L * 4, h->stream));
-    HIPCHK(hipMemsetAsync(h->head.p, 0, 64, h->stream));
-    HIPCHK(hipMemsetAsync(h->colmap.p, 0xFF, (size_t)ncb_bound * 32 * 4, h->stream));
-    HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->col_thr.p), (int)0xFF800000u /* -inf */,
-                             (size_t)ncb_bound * 32, h->stream));
+    const bool fast = h->prefilter && h->have16;
+    const size_t ncols = (size_t)ncb_bound * 32;
+    int pf_parts = 4;
+    FillRanges Z;
+    Z.count = 0;
+    auto fill = [&](void* ptr, long long words, unsigned value) { Z.p[Z.count] = static_cast<unsigned*>(ptr); Z.n[Z.count] = words; Z.v[Z.count] = value; ++Z.count; };
+    fill(h->m.p, L, 0u);
+    fill(h->head.p, 16, 0u);
+    fill(h->colmap.p, (long long)ncols, 0xFFFFFFFFu);
+    fill(h->col_thr.p, (long long)ncols, 0xFF800000u /* -inf */);
+    if (fast) {
+        CHK(h->qnorm.reserve((size_t)nq * 4));
+        CHK(h->qmaxbits.reserve(16));
+        CHK(h->qfrag16.reserve((size_t)ncb_bound * h->KG16 * 1024));
+        CHK(h->eps2.reserve(ncols * 4));
+        CHK(h->cand_cnt.reserve(ncols * 4));
+        CHK(h->cand_row.reserve(ncols * PF_CAP * 4));
+        CHK(h->cand_s.reserve(ncols * PF_CAP * 4));
+        CHK(h->fallback.reserve((size_t)nslots * 4));
+        CHK(h->nkeep.reserve((size_t)nslots * 4));
+        // pass-1 items per (bucket, query tile): enough of them to fill the chip.  The host only knows an
+        // estimate of the (bucket, tile) pairs: this rank's share of the slots / 256 + its buckets.
+        long long owned_rows = 0, owned_buckets = 0;
+        for (int b = 0; b < L; ++b) { owned_rows += h->h_nb_rows[b]; owned_buckets += h->h_nb_rows[b] > 0; }
+        const double pairs_est = (double)nslots * (double)owned_rows / (double)std::max<long long>(1, h->N) / (32.0 * 4 * PF_NG) + (double)owned_buckets;
+        pf_parts = pairs_est * 4 >= 4.0 * h->num_cus ? 4 : pairs_est * 8 >= 4.0 * h->num_cus ? 8 : PF_PARTS_MAX;
+        CHK(h->pf_bound.reserve(ncols * pf_parts * KPB * 4));
+        fill(h->pf_bound.p, (long long)(ncols * pf_parts * KPB), 0xFF800000u /* -inf */);
+        fill(h->qmaxbits.p, 4, 0u);
+        fill(h->cand_cnt.p, (long long)ncols, 0u);
+        fill(h->stats.as<long long>() + 2, 4, 0u);
+    }
+    fill_ranges_kernel<<<h->num_cus * 4, 256, 0, h->stream>>>(Z);
+    HIPCHK(hipGetLastError());
     route_count_kernel<<<cdiv(nslots, 256), 256, 0, h->stream>>>(d_order, nslots, L, R, h->slot_local.as<int>());
     HIPCHK(hipGetLastError());
     route_scan_kernel<<<1, 256, 0, h->stream>>>(L, R);
@@ -609,7 +638,6 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     route_fill_kernel<<<cdiv(nslots, 256), 256, 0, h->stream>>>(d_order, h->slot_local.as<int>(), nslots, nb,
                                                                R.cb_start, h->colmap.as<int>(), h->slot_col.as<int>());
     HIPCHK(hipGetLastError());
-    const bool fast = h->prefilter && h->have16;
     ScanParams S;
     S.slab = h->slab.as<float4>();
     S.qfrag = h->qfrag.as<float4>();
@@ -641,41 +669,16 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         CHK(record(h, 3));
     } else {
         // fp16 prefilter + exact re-rank (lmi_prefilter.h)
-        const size_t ncols = (size_t)ncb_bound * 32;
-        CHK(h->qnorm.reserve((size_t)nq * 4));
-        CHK(h->qmaxbits.reserve(16));
-        CHK(h->qscale.reserve(16));
-        CHK(h->qfrag16.reserve((size_t)ncb_bound * h->KG16 * 1024));
-        CHK(h->eps2.reserve(ncols * 4));
-        CHK(h->cand_cnt.reserve(ncols * 4));
-        CHK(h->cand_row.reserve(ncols * PF_CAP * 4));
-        CHK(h->cand_s.reserve(ncols * PF_CAP * 4));
-        CHK(h->fallback.reserve((size_t)nslots * 4));
-        CHK(h->nkeep.reserve((size_t)nslots * 4));
-        // pass-1 items per (bucket, query tile): enough of them to fill the chip.  The host only knows an
-        // estimate of the (bucket, tile) pairs: this rank's share of the slots / 256 + its buckets.
-        long long owned_rows = 0, owned_buckets = 0;
-        for (int b = 0; b < L; ++b) { owned_rows += h->h_nb_rows[b]; owned_buckets += h->h_nb_rows[b] > 0; }
-        const double pairs_est = (double)nslots * (double)owned_rows / (double)std::max<long long>(1, h->N) / (32.0 * 4 * PF_NG) + (double)owned_buckets;
-        const int pf_parts = pairs_est * 4 >= 4.0 * h->num_cus ? 4 : pairs_est * 8 >= 4.0 * h->num_cus ? 8 : PF_PARTS_MAX;
-        CHK(h->pf_bound.reserve(ncols * pf_parts * KPB * 4));
-        HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->pf_bound.p), (int)0xFF800000u /* -inf */,
-                                 ncols * pf_parts * KPB, h->stream));
-        HIPCHK(hipMemsetAsync(h->qmaxbits.p, 0, 16, h->stream));
-        HIPCHK(hipMemsetAsync(h->cand_cnt.p, 0, ncols * 4, h->stream));
-        HIPCHK(hipMemsetAsync(h->stats.as<long long>() + 2, 0, 16, h->stream));
         query_norm_kernel<<<cdiv(nq, 4), 256, 0, h->stream>>>(d_qs, nq, h->d, h->qnorm.as<float>(), h->qmaxbits.as<unsigned>());
-        HIPCHK(hipGetLastError());
-        make_scale_kernel<<<1, 1, 0, h->stream>>>(h->qmaxbits.as<unsigned>(), h->qscale.as<float>());
         HIPCHK(hipGetLastError());
         {
             long long total = (long long)ncols * h->KG16 * 2;
             pack_queries16_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(d_qs, h->d, h->colmap.as<int>(), (long long)ncols,
-                                                                          h->KG16, h->qscale.as<float>(), h->qfrag16.as<uint4>());
+                                                                          h->KG16, h->qmaxbits.as<unsigned>(), h->qfrag16.as<uint4>());
             HIPCHK(hipGetLastError());
         }
         slot_bound_kernel<<<cdiv(nslots, 256), 256, 0, h->stream>>>(d_order, h->slot_col.as<int>(), nslots, nb, h->KG16 * 16,
-                                                                   h->qnorm.as<float>(), h->qscale.as<float>(),
+                                                                   h->qnorm.as<float>(), h->qmaxbits.as<unsigned>(),
                                                                    h->bnorm.as<unsigned>(), h->eps2.as<float>());
         HIPCHK(hipGetLastError());
         CHK(record(h, 2));

@@ -370,43 +370,46 @@ __global__ __launch_bounds__(1024) void route_group_kernel(int L, RouteArrays R)
         order_s[rank] = b;
     }
     __syncthreads();
-    if (t == 64) {  // query-tile prefix over the buckets heaviest first (prefilter pass-1 queue: LPT)
+    // query-tile prefix over the buckets heaviest first (prefilter pass-1 queue: LPT); thread i sums its own
+    // prefix (a serial scan by one thread was the kernel's critical path)
+    for (int i = t; i <= L; i += 1024) {
         int q = 0;
-        for (int i = 0; i < L; ++i) {
-            const int b = order_s[i];
-            R.order_tmp[i] = b;
-            R.qt_base[i] = q;
-            q += query_tiles(m_s[b], R.tile_cb);
-        }
-        R.qt_base[L] = q;
+        for (int j = 0; j < i; ++j) q += query_tiles(m_s[order_s[j]], R.tile_cb);
+        R.qt_base[i] = q;
+        if (i < L) R.order_tmp[i] = order_s[i];
     }
-    // LPT on wave 0: lane g < NGRP keeps queue g's running load / bucket count / item count in registers;
-    // the lightest queue (ties -> lower g) is found by an 8-lane butterfly.  (Thread 0 doing it alone
-    // with private arrays indexed at run time went through scratch: 73 us at L = 120.)
-    if (t < 64) {
-        long long load = 0;
-        int cnt = 0, items = 0;
-        if (t < NGRP) R.grp_base[t * (L + 1)] = 0;
-        for (int i = 0; i < L; ++i) {
-            const int b = order_s[i];
-            if (m_s[b] == 0) break;  // sorted by work: nothing but idle buckets from here on
-            long long best = t < NGRP ? load : 0x7fffffffffffffffll;
-            int bg = t;
-#pragma unroll
-            for (int o = 1; o < NGRP; o <<= 1) {
-                const long long ol = __shfl_xor(best, o);
-                const int og = __shfl_xor(bg, o);
-                if (ol < best || (ol == best && og < bg)) { best = ol; bg = og; }
-            }
-            if (t == bg && t < NGRP) {
-                R.grp_bucket[t * L + cnt] = b;
-                items += items_s[b];
-                cnt += 1;
-                R.grp_base[t * (L + 1) + cnt] = items;
-                load += work_s[b];
-            }
-        }
-        if (t < NGRP) { R.grp_n[t] = cnt; R.grp_total[t] = items; }
+    // Buckets -> queues in "snake" order over the work-sorted list (ranks 0..7 -> queues 0..7, ranks 8..15 ->
+    // queues 7..0, ..): every thread places its own bucket, the prefix of a queue's item counts is a loop
+    // over its <= L/8 earlier members.  (Exact LPT is serial: 54-73 us at L = 120 whichever way it was
+    // written -- scratch arrays, a wave butterfly, select chains; the snake's queue loads differ by a few
+    // per cent and draining queues steal anyway.)
+    __shared__ int active_s, total_s[NGRP];
+    if (t == 0) active_s = 0;
+    if (t < NGRP) { total_s[t] = 0; R.grp_base[t * (L + 1)] = 0; }
+    __syncthreads();
+    {
+        int mine = 0;
+        for (int b = t; b < L; b += 1024) mine += m_s[b] > 0;
+        if (mine) atomicAdd(&active_s, mine);
+    }
+    __syncthreads();
+    const int A = active_s;  // buckets with queries: ranks 0 .. A-1 (idle buckets have zero work and sort last)
+    for (int i = t; i < A; i += 1024) {
+        const int b = order_s[i];
+        const int r = i / NGRP, ph = i % NGRP;
+        const int g = (r & 1) ? NGRP - 1 - ph : ph;
+        int prefix = 0;
+        for (int rr = 0; rr < r; ++rr) prefix += items_s[order_s[rr * NGRP + ((rr & 1) ? NGRP - 1 - g : g)]];
+        R.grp_bucket[g * L + r] = b;
+        R.grp_base[g * (L + 1) + r + 1] = prefix + items_s[b];
+        atomicAdd(&total_s[g], items_s[b]);
+    }
+    __syncthreads();
+    if (t < NGRP) {
+        const int rows = A / NGRP, rem = A % NGRP;
+        const int ph = (rows & 1) ? NGRP - 1 - t : t;  // this queue's position in the partial last row
+        R.grp_n[t] = rows + (ph < rem ? 1 : 0);
+        R.grp_total[t] = total_s[t];
     }
 }
 

@@ -61,11 +61,15 @@ __global__ void absmax_kernel(const float* __restrict__ x, long long n, unsigned
 }
 
 // scale[0] <- power of two s with max*s in [0.5, 1) (1 if max == 0); scale[1] <- 1/s
-__global__ void make_scale_kernel(const unsigned* __restrict__ maxbits, float* __restrict__ scale) {
-    const float m = __uint_as_float(*maxbits);
+__device__ __forceinline__ float scale_of_max(unsigned maxbits) {
+    const float m = __uint_as_float(maxbits);
     int e = 0;
     float s = 1.0f;
     if (m > 0.0f && m < INFINITY) { (void)frexpf(m, &e); s = ldexpf(1.0f, -e); }
+    return s;
+}
+__global__ void make_scale_kernel(const unsigned* __restrict__ maxbits, float* __restrict__ scale) {
+    const float s = scale_of_max(*maxbits);
     scale[0] = s;
     scale[1] = 1.0f / s;
 }
@@ -133,20 +137,50 @@ __global__ void pf_selftest_kernel(int* __restrict__ ok) {
     if (lane == 0) *ok = (all == ~0ull) ? 1 : 0;
 }
 
+// ---- per batch: one launch initialises every per-call array (eight hipMemsetAsync calls took 37 us) ----
+struct FillRanges {
+    static constexpr int MAXR = 8;
+    unsigned* p[MAXR];
+    long long n[MAXR];   // 32-bit words
+    unsigned v[MAXR];
+    int count;
+};
+__global__ void fill_ranges_kernel(FillRanges F) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (int r = 0; r < F.count; ++r)
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < F.n[r]; i += stride) F.p[r][i] = F.v[r];
+}
+
 // ---- per batch: query scale, norms, fp16 packing, per-slot bound ---------------------------------
 __global__ __launch_bounds__(256) void query_norm_kernel(const float* __restrict__ q, int nq, int d,
                                                          float* __restrict__ qnorm, unsigned* __restrict__ maxbits) {
-    // one wave per query (coalesced); the norm only has to be an upper bound: 1.0002 covers binary32
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // one wave per query (coalesced 16-byte loads); the norm only has to be an upper bound: 1.0002 covers
+    // binary32.  One atomicMax per block on the batch's word, and only if it would raise it.
+    __shared__ unsigned smax[4];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wv;
     float acc = 0.0f, m = 0.0f;
-    if (i < nq)
-        for (int k = lane; k < d; k += 64) { const float v = q[(size_t)i * d + k]; acc += v * v; m = fmaxf(m, fabsf(v)); }
+    if (i < nq) {
+        const float* row = q + (size_t)i * d;
+        if ((d & 3) == 0) {
+            for (int k = lane * 4; k < d; k += 256) {
+                const float4 v = *reinterpret_cast<const float4*>(row + k);
+                acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+                m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            }
+        } else {
+            for (int k = lane; k < d; k += 64) { const float v = row[k]; acc += v * v; m = fmaxf(m, fabsf(v)); }
+        }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { acc += __shfl_xor(acc, o); m = fmaxf(m, __shfl_xor(m, o)); }
-    if (lane == 0 && i < nq) {
-        qnorm[i] = sqrtf(acc) * 1.0002f;
-        // one word for the batch: look before the atomic (10 000 contended atomicMax took 100 us)
-        const unsigned mb = __float_as_uint(m);
+    if (lane == 0) {
+        if (i < nq) qnorm[i] = sqrtf(acc) * 1.0002f;
+        smax[wv] = __float_as_uint(m);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned mb = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
         if (mb > __hip_atomic_load(maxbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxbits, mb);
     }
 }
@@ -154,7 +188,7 @@ __global__ __launch_bounds__(256) void query_norm_kernel(const float* __restrict
 // colmap gather of row-major queries -> fp16 fragments (x qscale); one thread per (col-block, k16-group,
 // lane): a wave writes one whole 1-KiB fragment (coalesced); each lane reads 32 contiguous bytes of its row
 __global__ void pack_queries16_kernel(const float* __restrict__ q, int d, const int* __restrict__ colmap,
-                                      long long ncols, int KG16, const float* __restrict__ qscale,
+                                      long long ncols, int KG16, const unsigned* __restrict__ qmaxbits,
                                       uint4* __restrict__ dst) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= ncols * KG16 * 2) return;
@@ -163,7 +197,7 @@ __global__ void pack_queries16_kernel(const float* __restrict__ q, int d, const 
     const long long cb = (idx >> 6) / KG16;
     const int hh = lane >> 5;
     const int qi = colmap[cb * 32 + (lane & 31)];
-    const float s = qscale[0];
+    const float s = scale_of_max(qmaxbits[0]);  // the batch's power-of-two scale (query_norm_kernel)
     half8 h;
     const int k0 = 16 * g + 8 * hh;
     if (qi >= 0 && k0 + 8 <= d && (d & 3) == 0) {
@@ -183,13 +217,13 @@ __global__ void pack_queries16_kernel(const float* __restrict__ q, int d, const 
 
 // eps2[col] = 2*eps' of the slot occupying column `col` (header); -1 for idle columns
 __global__ void slot_bound_kernel(const int* __restrict__ bucket_order, const int* __restrict__ slot_col, int nslots,
-                                  int nb, int dpad, const float* __restrict__ qnorm, const float* __restrict__ qscale,
+                                  int nb, int dpad, const float* __restrict__ qnorm, const unsigned* __restrict__ qmaxbits,
                                   const unsigned* __restrict__ bnorm_bits, float* __restrict__ eps2) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= nslots) return;
     const int col = slot_col[p];
     if (col < 0) return;
-    const float qn = qnorm[p / nb] * qscale[0];
+    const float qn = qnorm[p / nb] * scale_of_max(qmaxbits[0]);
     const float xn = __uint_as_float(bnorm_bits[bucket_order[p]]);
     const float u = 4.8828125e-4f, sub = 2.98023224e-8f;  // 2^-11, 2^-25
     const float rel = 2.0f * u + u * u + 2.5f * (float)dpad * 5.96046448e-8f;
