@@ -130,11 +130,18 @@ __global__ __launch_bounds__(256) void mlp_layer_kernel(const float4* __restrict
         int cb = cb0 + n < ncb ? cb0 + n : ncb - 1;  // clamp: duplicates are computed and discarded
         bp[n] = Xf + (size_t)cb * KG * 64 + lane;
     }
-    for (int g = 0; g < KG; ++g) {
-        float4 a = ap[(size_t)g * 64];
-        float4 b[CBW];
+    // operands straight from L2 (the weights are shared by every block, the activations by the block row):
+    // k-group g+1 is requested before the MFMAs of group g
+    float4 a = ap[0];
+    float4 b[CBW];
 #pragma unroll
-        for (int n = 0; n < CBW; ++n) b[n] = bp[n][(size_t)g * 64];
+    for (int n = 0; n < CBW; ++n) b[n] = bp[n][0];
+    for (int g = 0; g < KG; ++g) {
+        const int gn = g + 1 < KG ? g + 1 : g;
+        const float4 a_next = ap[(size_t)gn * 64];
+        float4 b_next[CBW];
+#pragma unroll
+        for (int n = 0; n < CBW; ++n) b_next[n] = bp[n][(size_t)gn * 64];
         const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -144,6 +151,9 @@ __global__ __launch_bounds__(256) void mlp_layer_kernel(const float4* __restrict
                 acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv, acc[n], 0, 0, 0);
             }
         }
+        a = a_next;
+#pragma unroll
+        for (int n = 0; n < CBW; ++n) b[n] = b_next[n];
     }
 #pragma unroll
     for (int n = 0; n < CBW; ++n) {
