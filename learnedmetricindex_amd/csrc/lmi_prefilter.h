@@ -292,9 +292,17 @@ struct PrefilterParams {
     float* cand_s;        // [columns][PF_CAP]
 };
 
-__device__ __forceinline__ void vlist_insert(float (&v)[KPB], float s) {  // values-only sorted insert
+// Pass 1 keeps the PF_LK best values per lane and column.  The bound only has to be the 10th best of SOME
+// subset of the bucket's scores: the union of the 8 (row-wave, half) lists x parts of a column holds the
+// sample's ten best unless five of them fall into one list; a shorter list is a cheaper insert (the
+// epilogue of pass 1 is VALU-bound) and a higher entry threshold.
+#ifndef LMI_PF_LK
+#define LMI_PF_LK 4
+#endif
+constexpr int PF_LK = LMI_PF_LK;
+__device__ __forceinline__ void vlist_insert(float (&v)[PF_LK], float s) {  // values-only sorted insert
 #pragma unroll
-    for (int t = KPB - 1; t > 0; --t) v[t] = (s > v[t - 1]) ? v[t - 1] : ((s > v[t]) ? s : v[t]);
+    for (int t = PF_LK - 1; t > 0; --t) v[t] = (s > v[t - 1]) ? v[t - 1] : ((s > v[t]) ? s : v[t]);
     v[0] = (s > v[0]) ? s : v[0];
 }
 
@@ -318,7 +326,7 @@ struct PreItem {
     int lane, w, h, c;
     int wr, grp;            // row-wave (0..3) and wave group (0..NG-1): w = 4 grp + wr
     int cbofs;              // first col-block of this wave's group inside the tile
-    float lv[NLIST][KPB];   // pass 1 only
+    float lv[NLIST][PF_LK]; // pass 1 only
     float thr[NCB];         // pass 2: bound - 2 eps' of this lane's column in col-block n (+inf: idle column)
     half8 p_a, p_b[NCB];    // NG 2: operands of the stage's deferred last MFMA group (step_fused)
     unsigned pend_pos, pend_row, pend_col;  // pass 2: this lane's candidate of the previous tile ...
@@ -461,7 +469,7 @@ struct PreItem {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float s = acc[j][n][r];
-                    if (s > lv[SAMPLE ? n : 0][KPB - 1] && rowbase + acc_row(r, h) < (unsigned)n_b)
+                    if (s > lv[SAMPLE ? n : 0][PF_LK - 1] && rowbase + acc_row(r, h) < (unsigned)n_b)
                         vlist_insert(lv[SAMPLE ? n : 0], s);
                     acc[j][n][r] = 0.0f;
                 }
@@ -595,7 +603,7 @@ struct PreItem {
         for (int n = 0; n < NCB; ++n) {
             if (SAMPLE) {
 #pragma unroll
-                for (int j = 0; j < KPB; ++j) lv[SAMPLE ? n : 0][j] = -INFINITY;
+                for (int j = 0; j < PF_LK; ++j) lv[SAMPLE ? n : 0][j] = -INFINITY;
             } else {
                 const float v10 = P.bound1[col0 + n * 32 + c];
                 thr[n] = n * 32 + c < m_left ? v10 - P.eps2[col0 + n * 32 + c] : INFINITY;
@@ -696,7 +704,7 @@ struct PreItem {
         //      column are merged in two rounds of 4 lists (5 KiB per group in sB0) + a carried list (sB1).
         //      Every wave runs all four n steps (the groups may own different numbers of col-blocks and
         //      must meet at the same barriers). ----
-        float* buf = reinterpret_cast<float*>(sB0) + grp * (32 * 4 * KPB);  // [32 cols][4 lists][KPB]
+        float* buf = reinterpret_cast<float*>(sB0) + grp * (32 * 4 * PF_LK);  // [32 cols][4 lists][PF_LK]
         float* carry = reinterpret_cast<float*>(sB1) + grp * (32 * KPB);    // [32 cols][KPB], touched by its own thread only
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
@@ -705,16 +713,16 @@ struct PreItem {
             for (int round = 0; round < 2; ++round) {
                 __syncthreads();
                 if (live && (wr >> 1) == round) {
-                    const int o = (c * 4 + ((wr & 1) * 2 + h)) * KPB;
+                    const int o = (c * 4 + ((wr & 1) * 2 + h)) * PF_LK;
 #pragma unroll
-                    for (int j = 0; j < KPB; ++j) buf[o + j] = lv[SAMPLE && n < NCB ? n : 0][j];
+                    for (int j = 0; j < PF_LK; ++j) buf[o + j] = lv[SAMPLE && n < NCB ? n : 0][j];
                 }
                 __syncthreads();
                 if (live && wr == 0 && lane < 32) {
                     float best[KPB];
                     unsigned heads = 0;
                     int hc = (round == 0) ? KPB : 0;  // the carried list is empty in round 0
-                    const int o = lane * 4 * KPB;
+                    const int o = lane * 4 * PF_LK;
 #pragma unroll
                     for (int j = 0; j < KPB; ++j) {
                         float bs = -INFINITY;
@@ -722,8 +730,8 @@ struct PreItem {
 #pragma unroll
                         for (int src = 0; src < 4; ++src) {
                             const int hd = (heads >> (4 * src)) & 15;
-                            if (hd < KPB) {
-                                const float s = buf[o + src * KPB + hd];
+                            if (hd < PF_LK) {
+                                const float s = buf[o + src * PF_LK + hd];
                                 if (s > bs) { bs = s; bsrc = src; }
                             }
                         }
