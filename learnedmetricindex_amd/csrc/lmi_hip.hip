@@ -100,8 +100,8 @@ struct lmi_index {
     bool pf_hw_ok = false;   // fp16 subnormal self-test passed on this device
     bool have16 = false;     // slab16 built by lmi_buckets_end
     int KG16 = 0;
-    DevBuf slab16, rowmajor, xscale, xmaxbits, bnorm;
-    DevBuf qnorm, qmaxbits, qscale, qfrag16, eps2, cand_cnt, cand_row, cand_s, fallback, pf_bound, nkeep;
+    DevBuf slab16, rowmajor, xscale, xmaxbits, bnorm, bdelta, qdelta;
+    DevBuf qnorm, qscale, qfrag16, eps2, cand_cnt, cand_row, cand_s, fallback, pf_bound, nkeep;
     int last_nslots = 0;
     bool last_fast = false;
 
@@ -179,7 +179,7 @@ extern "C" LMI_API int lmi_destroy(lmi_index* h) {
     DevBuf* bufs[] = {&h->slab, &h->ids_slab, &h->pos, &h->d_nb_rows, &h->d_rb_start, &h->d_nch, &h->stage,
                       &h->act[0], &h->act[1], &h->xfrag, &h->logits, &h->order, &h->q_nav, &h->q_srch, &h->m,
                       &h->cb_start, &h->item_base, &h->part_base, &h->stats, &h->head, &h->slot_local,
-                      &h->slot_col, &h->colmap, &h->qfrag, &h->grp, &h->col_thr, &h->slab16, &h->rowmajor, &h->xscale, &h->xmaxbits, &h->bnorm, &h->qnorm, &h->qmaxbits, &h->qscale, &h->qfrag16, &h->eps2, &h->cand_cnt, &h->cand_row, &h->cand_s, &h->fallback, &h->pf_bound, &h->nkeep, &h->part_score, &h->part_row, &h->rank_d,
+                      &h->slot_col, &h->colmap, &h->qfrag, &h->grp, &h->col_thr, &h->slab16, &h->rowmajor, &h->xscale, &h->xmaxbits, &h->bnorm, &h->bdelta, &h->qdelta, &h->qnorm, &h->qscale, &h->qfrag16, &h->eps2, &h->cand_cnt, &h->cand_row, &h->cand_s, &h->fallback, &h->pf_bound, &h->nkeep, &h->part_score, &h->part_row, &h->rank_d,
                       &h->rank_id, &h->out_d, &h->out_id, &h->out_key};
     for (DevBuf* b : bufs) b->release();
     for (int r = 0; r < lmi_index::EV_RING; ++r)
@@ -364,9 +364,11 @@ extern "C" LMI_API int lmi_buckets_end(lmi_index* h) {
         CHK(h->xmaxbits.reserve(16));
         CHK(h->xscale.reserve(16));
         CHK(h->bnorm.reserve((size_t)h->L * 4));
+        CHK(h->bdelta.reserve((size_t)h->L * 4));
         CHK(h->slab16.reserve((size_t)h->n_rb_total * h->KG16 * 1024));
         HIPCHK(hipMemsetAsync(h->xmaxbits.p, 0, 16, h->stream));
         HIPCHK(hipMemsetAsync(h->bnorm.p, 0, (size_t)h->L * 4, h->stream));
+        HIPCHK(hipMemsetAsync(h->bdelta.p, 0, (size_t)h->L * 4, h->stream));
         absmax_kernel<<<h->num_cus * 8, 256, 0, h->stream>>>(h->rowmajor.as<float>(), n_rows * h->d, h->xmaxbits.as<unsigned>());
         HIPCHK(hipGetLastError());
         make_scale_kernel<<<1, 1, 0, h->stream>>>(h->xmaxbits.as<unsigned>(), h->xscale.as<float>());
@@ -377,7 +379,8 @@ extern "C" LMI_API int lmi_buckets_end(lmi_index* h) {
         HIPCHK(hipGetLastError());
         dim3 g(64, h->L);
         bucket_norm_kernel<<<g, 256, 0, h->stream>>>(h->rowmajor.as<float>(), h->d, h->d_rb_start.as<int>(),
-                                                    h->d_nb_rows.as<int>(), h->xscale.as<float>(), h->bnorm.as<unsigned>());
+                                                    h->d_nb_rows.as<int>(), h->xscale.as<float>(), h->bnorm.as<unsigned>(),
+                                                    h->bdelta.as<unsigned>());
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(h->stream));
         h->have16 = true;
@@ -607,7 +610,8 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     fill(h->col_thr.p, (long long)ncols, 0xFF800000u /* -inf */);
     if (fast) {
         CHK(h->qnorm.reserve((size_t)nq * 4));
-        CHK(h->qmaxbits.reserve(16));
+        CHK(h->qdelta.reserve((size_t)nq * 4));
+        CHK(h->qscale.reserve((size_t)nq * 4));
         CHK(h->qfrag16.reserve((size_t)ncb_bound * h->KG16 * 1024));
         CHK(h->eps2.reserve(ncols * 4));
         CHK(h->cand_cnt.reserve(ncols * 4));
@@ -623,7 +627,6 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         pf_parts = pairs_est * 4 >= 4.0 * h->num_cus ? 4 : pairs_est * 8 >= 4.0 * h->num_cus ? 8 : PF_PARTS_MAX;
         CHK(h->pf_bound.reserve(ncols * pf_parts * KPB * 4));
         fill(h->pf_bound.p, (long long)(ncols * pf_parts * KPB), 0xFF800000u /* -inf */);
-        fill(h->qmaxbits.p, 4, 0u);
         fill(h->cand_cnt.p, (long long)ncols, 0u);
         fill(h->stats.as<long long>() + 2, 4, 0u);
     }
@@ -669,17 +672,18 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         CHK(record(h, 3));
     } else {
         // fp16 prefilter + exact re-rank (lmi_prefilter.h)
-        query_norm_kernel<<<cdiv(nq, 4), 256, 0, h->stream>>>(d_qs, nq, h->d, h->qnorm.as<float>(), h->qmaxbits.as<unsigned>());
+        query_norm_kernel<<<cdiv(nq, 4), 256, 0, h->stream>>>(d_qs, nq, h->d, h->qnorm.as<float>(), h->qdelta.as<float>(),
+                                                              h->qscale.as<float>());
         HIPCHK(hipGetLastError());
         {
             long long total = (long long)ncols * h->KG16 * 2;
             pack_queries16_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(d_qs, h->d, h->colmap.as<int>(), (long long)ncols,
-                                                                          h->KG16, h->qmaxbits.as<unsigned>(), h->qfrag16.as<uint4>());
+                                                                          h->KG16, h->qscale.as<float>(), h->qfrag16.as<uint4>());
             HIPCHK(hipGetLastError());
         }
         slot_bound_kernel<<<cdiv(nslots, 256), 256, 0, h->stream>>>(d_order, h->slot_col.as<int>(), nslots, nb, h->KG16 * 16,
-                                                                   h->qnorm.as<float>(), h->qmaxbits.as<unsigned>(),
-                                                                   h->bnorm.as<unsigned>(), h->eps2.as<float>());
+                                                                   h->qnorm.as<float>(), h->qdelta.as<float>(),
+                                                                   h->bnorm.as<unsigned>(), h->bdelta.as<unsigned>(), h->eps2.as<float>());
         HIPCHK(hipGetLastError());
         CHK(record(h, 2));
         PrefilterParams F;

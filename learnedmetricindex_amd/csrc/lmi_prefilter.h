@@ -94,21 +94,30 @@ __global__ void convert16_kernel(const float* __restrict__ rows, int d, long lon
     dst[((size_t)(p >> 5) * KG16 + g) * 64 + hh * 32 + (p & 31)] = *reinterpret_cast<uint4*>(&h);
 }
 
-// per-bucket max of the scaled row norm, rounded up (bits of non-negative floats order like ints)
+// per-bucket max of the scaled row norm ||x'|| and of the norm of the row's fp16 rounding error
+// ||x^ - x'|| (x' = x * scale exactly, x^ = the _Float16 image convert16_kernel stores; the difference of
+// the two is exact in binary32), both rounded up (bits of non-negative floats order like ints)
 __global__ void bucket_norm_kernel(const float* __restrict__ rows, int d, const int* __restrict__ rb_start,
                                    const int* __restrict__ nb_rows, const float* __restrict__ scale,
-                                   unsigned* __restrict__ bnorm_bits) {
+                                   unsigned* __restrict__ bnorm_bits, unsigned* __restrict__ bdelta_bits) {
     const int b = blockIdx.y;
     const int n_b = nb_rows[b];
     const float s = scale[0];
-    float best = 0.0f;
+    float best = 0.0f, bestd = 0.0f;
     for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < n_b; row += gridDim.x * blockDim.x) {
         const float* x = rows + ((size_t)rb_start[b] * 32 + row) * d;
-        float acc = 0.0f;
-        for (int k = 0; k < d; ++k) acc += x[k] * x[k];
-        best = fmaxf(best, sqrtf(acc) * s * 1.0002f);  // 1.0002: covers the binary32 error of the sum
+        float acc = 0.0f, dl = 0.0f;
+        for (int k = 0; k < d; ++k) {
+            const float xs = x[k] * s;
+            const float e = (float)(_Float16)xs - xs;
+            acc += xs * xs;
+            dl += e * e;
+        }
+        best = fmaxf(best, sqrtf(acc) * 1.0002f);  // 1.0002: covers the binary32 error of the sum
+        bestd = fmaxf(bestd, sqrtf(dl) * 1.0002f);
     }
     if (best > 0.0f) atomicMax(bnorm_bits + b, __float_as_uint(best));
+    if (bestd > 0.0f) atomicMax(bdelta_bits + b, __float_as_uint(bestd));
 }
 
 // ---- hardware self-test: the bound assumes that fp16 SUBNORMAL operands enter the MFMA and the
@@ -153,42 +162,57 @@ __global__ void fill_ranges_kernel(FillRanges F) {
 
 // ---- per batch: query scale, norms, fp16 packing, per-slot bound ---------------------------------
 __global__ __launch_bounds__(256) void query_norm_kernel(const float* __restrict__ q, int nq, int d,
-                                                         float* __restrict__ qnorm, unsigned* __restrict__ maxbits) {
-    // one wave per query (coalesced 16-byte loads); the norm only has to be an upper bound: 1.0002 covers
-    // binary32.  One atomicMax per block on the batch's word, and only if it would raise it.
-    __shared__ unsigned smax[4];
+                                                         float* __restrict__ qnorm, float* __restrict__ qdelta,
+                                                         float* __restrict__ qscale) {
+    // One wave per query (coalesced 16-byte loads).  Every query gets its own power-of-two scale s
+    // (max|q| * s in [0.5, 1): a slot's scores are only ever compared with scores of the same query), its
+    // scaled norm ||q'|| and the norm of its fp16 rounding error ||q^ - q'|| (q^ - q' is exact in binary32);
+    // 1.0002 covers the binary32 error of the sums: both are upper bounds.
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + wv;
-    float acc = 0.0f, m = 0.0f;
-    if (i < nq) {
-        const float* row = q + (size_t)i * d;
-        if ((d & 3) == 0) {
-            for (int k = lane * 4; k < d; k += 256) {
-                const float4 v = *reinterpret_cast<const float4*>(row + k);
-                acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-                m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-            }
-        } else {
-            for (int k = lane; k < d; k += 64) { const float v = row[k]; acc += v * v; m = fmaxf(m, fabsf(v)); }
+    if (i >= nq) return;
+    const float* row = q + (size_t)i * d;
+    const bool vec = (d & 3) == 0;
+    float m = 0.0f;
+    if (vec) {
+        for (int k = lane * 4; k < d; k += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(row + k);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         }
+    } else {
+        for (int k = lane; k < d; k += 64) m = fmaxf(m, fabsf(row[k]));
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { acc += __shfl_xor(acc, o); m = fmaxf(m, __shfl_xor(m, o)); }
-    if (lane == 0) {
-        if (i < nq) qnorm[i] = sqrtf(acc) * 1.0002f;
-        smax[wv] = __float_as_uint(m);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    const float s = scale_of_max(__float_as_uint(m));
+    float acc = 0.0f, dl = 0.0f;
+    auto term = [&](float v) {
+        const float vs = v * s;
+        const float e = (float)(_Float16)vs - vs;
+        acc += vs * vs;
+        dl += e * e;
+    };
+    if (vec) {
+        for (int k = lane * 4; k < d; k += 256) {  // second pass over the row: L1/L2 hits
+            const float4 v = *reinterpret_cast<const float4*>(row + k);
+            term(v.x); term(v.y); term(v.z); term(v.w);
+        }
+    } else {
+        for (int k = lane; k < d; k += 64) term(row[k]);
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned mb = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
-        if (mb > __hip_atomic_load(maxbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxbits, mb);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { acc += __shfl_xor(acc, o); dl += __shfl_xor(dl, o); }
+    if (lane == 0) {
+        qnorm[i] = sqrtf(acc) * 1.0002f;
+        qdelta[i] = sqrtf(dl) * 1.0002f;
+        qscale[i] = s;
     }
 }
 
 // colmap gather of row-major queries -> fp16 fragments (x qscale); one thread per (col-block, k16-group,
 // lane): a wave writes one whole 1-KiB fragment (coalesced); each lane reads 32 contiguous bytes of its row
 __global__ void pack_queries16_kernel(const float* __restrict__ q, int d, const int* __restrict__ colmap,
-                                      long long ncols, int KG16, const unsigned* __restrict__ qmaxbits,
+                                      long long ncols, int KG16, const float* __restrict__ qscale,
                                       uint4* __restrict__ dst) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= ncols * KG16 * 2) return;
@@ -197,7 +221,7 @@ __global__ void pack_queries16_kernel(const float* __restrict__ q, int d, const 
     const long long cb = (idx >> 6) / KG16;
     const int hh = lane >> 5;
     const int qi = colmap[cb * 32 + (lane & 31)];
-    const float s = scale_of_max(qmaxbits[0]);  // the batch's power-of-two scale (query_norm_kernel)
+    const float s = qi >= 0 ? qscale[qi] : 1.0f;  // the query's power-of-two scale (query_norm_kernel)
     half8 h;
     const int k0 = 16 * g + 8 * hh;
     if (qi >= 0 && k0 + 8 <= d && (d & 3) == 0) {
@@ -217,17 +241,19 @@ __global__ void pack_queries16_kernel(const float* __restrict__ q, int d, const 
 
 // eps2[col] = 2*eps' of the slot occupying column `col` (header); -1 for idle columns
 __global__ void slot_bound_kernel(const int* __restrict__ bucket_order, const int* __restrict__ slot_col, int nslots,
-                                  int nb, int dpad, const float* __restrict__ qnorm, const unsigned* __restrict__ qmaxbits,
-                                  const unsigned* __restrict__ bnorm_bits, float* __restrict__ eps2) {
+                                  int nb, int dpad, const float* __restrict__ qnorm, const float* __restrict__ qdelta,
+                                  const unsigned* __restrict__ bnorm_bits, const unsigned* __restrict__ bdelta_bits,
+                                  float* __restrict__ eps2) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= nslots) return;
     const int col = slot_col[p];
     if (col < 0) return;
-    const float qn = qnorm[p / nb] * scale_of_max(qmaxbits[0]);
-    const float xn = __uint_as_float(bnorm_bits[bucket_order[p]]);
-    const float u = 4.8828125e-4f, sub = 2.98023224e-8f;  // 2^-11, 2^-25
-    const float rel = 2.0f * u + u * u + 2.5f * (float)dpad * 5.96046448e-8f;
-    const float e = rel * qn * xn + 1.001f * sub * sqrtf((float)dpad) * (qn + xn) + (float)dpad * sub * sub;
+    const int b = bucket_order[p];
+    const float qn = qnorm[p / nb], dq = qdelta[p / nb];
+    const float xn = __uint_as_float(bnorm_bits[b]), dx = __uint_as_float(bdelta_bits[b]);
+    // |<q^,x^> - <q',x'>| = |<q^-q', x^> + <q', x^-x'>| <= dq (xn + dx) + qn dx   (Cauchy-Schwarz, measured norms)
+    // + the two binary32 summations (MFMA accumulation, canonical chain): 2.5 d 2^-24 (qn + dq)(xn + dx)
+    const float e = dq * (xn + dx) + qn * dx + 2.5f * (float)dpad * 5.96046448e-8f * (qn + dq) * (xn + dx);
     eps2[col] = 2.0f * e * 1.001f;
 }
 
