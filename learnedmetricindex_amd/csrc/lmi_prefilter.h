@@ -252,8 +252,9 @@ __global__ void slot_bound_kernel(const int* __restrict__ bucket_order, const in
     const float qn = qnorm[p / nb], dq = qdelta[p / nb];
     const float xn = __uint_as_float(bnorm_bits[b]), dx = __uint_as_float(bdelta_bits[b]);
     // |<q^,x^> - <q',x'>| = |<q^-q', x^> + <q', x^-x'>| <= dq (xn + dx) + qn dx   (Cauchy-Schwarz, measured norms)
-    // + the two binary32 summations (MFMA accumulation, canonical chain): 2.5 d 2^-24 (qn + dq)(xn + dx)
-    const float e = dq * (xn + dx) + qn * dx + 2.5f * (float)dpad * 5.96046448e-8f * (qn + dq) * (xn + dx);
+    // + the two binary32 summations: the canonical chain rounds to nearest (<= d 2^-24 sum|terms|), the MFMA's
+    // internal additions are allowed to truncate (<= d 2^-23 sum|terms|): 4 d 2^-24 (qn + dq)(xn + dx) with slack
+    const float e = dq * (xn + dx) + qn * dx + 4.0f * (float)dpad * 5.96046448e-8f * (qn + dq) * (xn + dx);
     eps2[col] = 2.0f * e * 1.001f;
 }
 
