@@ -273,12 +273,18 @@ extern "C" LMI_API int lmi_buckets_begin(lmi_index* h, int64_t N, int d, int L, 
     }
     h->h_rb_start.assign(L + 1, 0);
     h->h_nch.assign(L, 0);
+    // a bucket is scanned in at most 1024 chunks: very large buckets get larger chunks than the handle's setting
+    {
+        int max_rows = 0;
+        for (int b = 0; b < L; ++b) max_rows = std::max(max_rows, h->h_nb_rows[b]);
+        const int need = (int)rup(cdiv(max_rows, 1024), 256);
+        if (need > h->chunk_rows) h->chunk_rows = need;
+    }
     const int chunk_rb = h->chunk_rows / 32;
     for (int b = 0; b < L; ++b) {
         int nrb = cdiv(h->h_nb_rows[b], 32);
         h->h_rb_start[b + 1] = h->h_rb_start[b] + nrb;
         h->h_nch[b] = cdiv(nrb, chunk_rb);
-        if (h->h_nch[b] > 1024) return fail("lmi_buckets_begin: bucket %d needs %d chunks (> 1024); raise chunk rows", b, h->h_nch[b]);
     }
     h->n_rb_total = h->h_rb_start[L];
     // bucket-contiguous position of every object (stable: ascending original row inside a bucket,
