@@ -1032,14 +1032,15 @@ __global__ __launch_bounds__(64 * RS_WAVES) __attribute__((amdgpu_waves_per_eu(L
     unsigned nk = 0;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        if (i >= nper) break;
-        const bool keep = key[i] != 0u && key[i] >= kcut;
-        const unsigned long long bal = __ballot(keep);
-        if (keep) {
-            const unsigned k = nk + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
-            if (k < (unsigned)PF_KEEP) keep_row[wv][k] = cr[lane + 64 * i];
+        if (i < nper) {
+            const bool keep = key[i] != 0u && key[i] >= kcut;
+            const unsigned long long bal = __ballot(keep);
+            if (keep) {
+                const unsigned k = nk + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+                if (k < (unsigned)PF_KEEP) keep_row[wv][k] = cr[lane + 64 * i];
+            }
+            nk += (unsigned)__popcll(bal);
         }
-        nk += (unsigned)__popcll(bal);
     }
     if (nk > (unsigned)PF_KEEP) {
         if (lane == 0) P.fallback[p] = 1;

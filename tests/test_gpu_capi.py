@@ -120,3 +120,33 @@ def test_error_paths(capi):
     with pytest.raises(capi.LmiError, match="outside"):
         idx.buckets_begin(np.array([0, 5]), 8, 3)
     idx.close()
+
+
+def test_timings_ring_mean(capi):
+    """lmi_timings_reset / lmi_timings_mean: the phase times of the calls since the reset, averaged with one
+    stream synchronisation (bench.py reads them once after its timed loop)."""
+    g = load_golden("G3")
+    Xn, Qn, Xs, Qs = inputs_for("G3", g)
+    layers = layers_from(g)
+    nb, k = int(g["n_buckets"]), int(g["k"])
+    L = layers[-1][0].shape[0]
+    idx = capi.Index(0)
+    idx.set_mlp(layers)
+    idx.set_buckets(Xs, g["data_prediction"][:, 0], L)
+    idx.search(Qn, Qs, nb, k)
+    idx.timings_reset()
+    ms0, n0 = idx.timings_mean()
+    assert n0 == 0 and not ms0.any()
+    for _ in range(3):
+        idx.search(Qn, Qs, nb, k)
+    ms, n = idx.timings_mean()
+    assert n == 3
+    last = idx.timings()
+    assert ms[capi.T_TOTAL] > 0 and ms[capi.T_SCAN] > 0 and ms[capi.T_INFERENCE] > 0
+    assert ms[capi.T_TOTAL] >= ms[capi.T_SCAN]
+    assert 0.2 * last[capi.T_TOTAL] < ms[capi.T_TOTAL] < 5 * last[capi.T_TOTAL]
+    for _ in range(140):  # more calls than the ring holds: the newest 128 are averaged
+        idx.mlp_topk(Qn[:8], nb)
+    _, n = idx.timings_mean()
+    assert n == 128
+    idx.close()
