@@ -92,7 +92,7 @@ def main():
 
     from learnedmetricindex_amd import _capi
     from learnedmetricindex_amd.li.model import NeuralNetwork, linear_layers
-    from learnedmetricindex_amd.sharded import ShardedSearcher, assign_buckets
+    from learnedmetricindex_amd.sharded import ShardedSearcher, assign_buckets, estimate_bucket_work
 
     t_setup = time.time()
     # ------------------------------------------------------------------ synthetic data
@@ -138,12 +138,19 @@ def main():
     torch.cuda.synchronize()
     labels_h = labels.cpu().numpy().astype(np.int64)
     sizes = np.bincount(labels_h, minlength=L)
-    owner = assign_buckets(sizes, world, weights=sizes.astype(np.float64) ** 2)
+    # Expected scan work of a bucket = its rows x the queries it will receive.  The second factor is estimated
+    # at build time by routing a sample of the DATA through the MLP (top-nb, like a query): every rank computes
+    # the same estimate, no knowledge of the query batch is used.
+    work_w = estimate_bucket_work(eng, gen_rows(1, 0, pieces[0][1])[: min(20_000, N)], nb, sizes)
+    owner = assign_buckets(sizes, world, weights=work_w)
     owned = (owner == rank).astype(np.uint8) if world > 1 else None
+    shard_world = world
     if args.emulate_shard:
         assert world == 1, "--emulate-shard is a single-GPU diagnostic"
         er, ew = (int(v) for v in args.emulate_shard.split("/"))
-        owner = assign_buckets(sizes, ew, weights=sizes.astype(np.float64) ** 2)
+        shard_world = ew
+        owner = assign_buckets(sizes, ew, weights=work_w)
+        owner_all = owner.copy()
         owned = (owner == er).astype(np.uint8)
         owner = np.where(owner == er, 0, -1)
         args.no_cpu_baseline = args.no_recall = True
@@ -188,6 +195,12 @@ def main():
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
     elapsed = float(tm.item())
     flops, pairs, items = eng.scan_stats()
+    if rank == 0 and shard_world > 1:  # how even the bucket assignment turned out for this batch
+        own = owner_all if args.emulate_shard else owner
+        bo_h = bo.cpu().numpy().ravel()
+        bo_h = bo_h[(bo_h >= 0) & (bo_h < L)]
+        per_rank = np.bincount(own[bo_h], weights=sizes[bo_h].astype(np.float64), minlength=shard_world)
+        log(f"[bench] scan work per rank (pairs, share of the mean): {np.round(per_rank / per_rank.mean(), 3).tolist()}")
     pf_active, pf_survivors, pf_fallbacks = eng.prefilter_stats()
     # ------------------------------------------------------------------ recall@10 vs exact brute force
     recall = None

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
                                               ("G4", 3, 15, 2), ("G4", 1, 5, 2), ("G5", 4, 10, 8)])
 def test_sharded_equals_single(oracle, name, nb, k, world):
     from learnedmetricindex_amd import _capi
-    from learnedmetricindex_amd.sharded import ShardedSearcher, assign_buckets
+    from learnedmetricindex_amd.sharded import ShardedSearcher, assign_buckets, estimate_bucket_work
 
     g = load_golden(name)
     Xn, Qn, Xs, Qs = inputs_for(name, g)
@@ -23,7 +23,6 @@ def test_sharded_equals_single(oracle, name, nb, k, world):
     dp = g["data_prediction"]
     L = layers[-1][0].shape[0]
     sizes = np.bincount(dp[:, 0], minlength=L)
-    owner = assign_buckets(sizes, world, weights=sizes.astype(np.float64) ** 2)
     dev = torch.device("cuda", 0)
     qn, qs = torch.from_numpy(Qn).to(dev), torch.from_numpy(Qs).to(dev)
     nq = Qn.shape[0]
@@ -33,6 +32,10 @@ def test_sharded_equals_single(oracle, name, nb, k, world):
     single.set_stream(stream)
     single.set_mlp(layers)
     single.set_buckets(Xs, dp[:, 0], L)
+    # bucket ownership from the build-time work estimate (a data sample routed like queries)
+    work = estimate_bucket_work(single, torch.from_numpy(Xn[:2000]).to(dev), nb, sizes)
+    assert work.shape == sizes.shape and (work[sizes > 0] > 0).all() and (work[sizes == 0] == 0).all()
+    owner = assign_buckets(sizes, world, weights=work)
     sd, si, sbo = ShardedSearcher(single, 0, 1).search(qn, qs, nb, k)
     torch.cuda.synchronize()
     kout = si.shape[1]
