@@ -84,11 +84,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # LMI_BENCH_BACKEND=gloo rehearses the multi-rank path on fewer cards than ranks (ranks share devices,
+    # collectives staged on the host); the measured configuration is always one rank per GPU over RCCL
+    backend = os.environ.get("LMI_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from learnedmetricindex_amd import _capi
     from learnedmetricindex_amd.li.model import NeuralNetwork, linear_layers
@@ -190,6 +198,7 @@ def main():
     # hipEvents recorded on the kernels' own stream around every phase of every step; read once, after the
     # timed region (the handle keeps the newest 128 sets), so the loop itself has no host synchronisation
     phases, n_timed = eng.timings_mean()
+    phases = phases * searcher.calls_per_search  # a search with sharded inference is two C-ABI calls (MLP slice, scan)
     tm = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
@@ -296,7 +305,7 @@ def main():
         if world == 1 and not overridden and os.path.exists(tj):
             traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
         roof.update({"traffic": traffic, "kernel": kernel, "flops_per_launch": flops, "bytes_per_launch": alg_bytes,
-                     "avg_launch_ms": round(dom_s * 1e3, 4), "launches_timed": int(n_timed),
+                     "avg_launch_ms": round(dom_s * 1e3, 4), "launches_timed": int(n_timed) // searcher.calls_per_search,
                      "floors_ms": {"mfma": round(t_mfma * 1e3, 3), "hbm": round(t_hbm * 1e3, 3)},
                      # the whole scan phase (all its kernels) priced as SURVEY 8d does: algorithmic f32 flops
                      # against the f32 MFMA peak, whatever precision the prefilter used
@@ -320,7 +329,9 @@ def main():
             "config": {"workload": f"{N}x{d} unit-norm gaussian-mixture vectors, 1-level LMI ({L} leaves, "
                                    f"{cfg['model']} {d}->512->{L} trained {args.epochs} epochs), top-{nb} buckets, "
                                    f"{nq}-query batch, k={k}",
-                       "baseline_config": args.config, "parallelism": "single GPU" if world == 1 else f"bucket-sharded x{world} + 1 all-gather",
+                       "baseline_config": args.config, "parallelism": "single GPU" if world == 1 else
+                                      f"bucket-sharded x{world}: MLP on 1/{world} of the batch + all-gather of the bucket order, "
+                                      f"scan of the owned buckets + all-gather of the per-rank top-k",
                        "scan_pairs": int(pairs), "scan_items": int(items)},
             "roofline": roof,
             "prefilter": None if args.exact else {"survivors_per_slot": round(pf_survivors / max(1, nq * nb), 2),

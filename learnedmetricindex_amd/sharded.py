@@ -57,15 +57,47 @@ def pack_block(xp, dists, ids, keys):
     return torch.stack([dists.view(torch.int32), ids.view(torch.int32), keys.view(torch.int32)])
 
 
+def _all_gather_cat(t, world: int, group=None):
+    """all_gather_into_tensor along dim 0.  RCCL ("nccl") takes device tensors as they are; under `gloo`
+    (CPU rehearsals of the multi-rank path, also with tensors living on a GPU) the payload is staged on the host."""
+    import torch
+    import torch.distributed as dist
+
+    t = t.contiguous()
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype)
+        dist.all_gather_into_tensor(out, t.cpu(), group=group)
+        return out.to(t.device)
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t, group=group)
+    return out
+
+
 def all_gather_blocks(block, world: int, group=None):
     """The one collective of the path: [world, 3, nq, kout] <- all_gather(block)."""
     import torch
     import torch.distributed as dist
 
     shape = tuple(block.shape)
-    out = torch.empty((world * shape[0],) + shape[1:], dtype=block.dtype, device=block.device)
-    dist.all_gather_into_tensor(out, block.contiguous(), group=group)  # rank-major concatenation
+    out = _all_gather_cat(block, world, group)  # rank-major concatenation
     return out.view((world,) + shape)
+
+
+def row_slice(nq: int, rank: int, world: int):
+    """(per, lo, hi): rank's contiguous share [lo, hi) of nq rows in equal slices of `per` rows (the last ones short or empty)."""
+    per = -(-nq // world)
+    lo = min(rank * per, nq)
+    return per, lo, min(lo + per, nq)
+
+
+def all_gather_rows(local, nq: int, world: int, group=None):
+    """[nq, ...] <- the ranks' [per, ...] slices concatenated in rank order (rows past a rank's share are padding)."""
+    import torch
+    import torch.distributed as dist
+
+    per = local.shape[0]
+    assert per * world >= nq
+    return _all_gather_cat(local, world, group)[:nq]
 
 
 def merge_blocks_numpy(gathered: np.ndarray, kout: int):
@@ -81,11 +113,19 @@ def merge_blocks_numpy(gathered: np.ndarray, kout: int):
 
 
 class ShardedSearcher:
-    """Device-side driver of the sharded search for one rank (torch tensors in, torch tensors out)."""
+    """Device-side driver of the sharded search for one rank (torch tensors in, torch tensors out).
 
-    def __init__(self, index, rank: int, world: int, group=None):
+    `shard_inference` (default on for world > 1): every rank runs the MLP on its 1/world slice of the query
+    batch and the bucket order is all-gathered (nq*nb*4 bytes), instead of every rank routing the whole batch
+    (at 8 ranks the replicated MLP was a sixth of a rank's step).  `calls_per_search` tells a caller that
+    averages `Index.timings_mean()` how many C-ABI calls one search makes."""
+
+    def __init__(self, index, rank: int, world: int, group=None, shard_inference: bool = True):
         self.index, self.rank, self.world, self.group = index, rank, world, group
+        self.shard_inference = bool(shard_inference) and world > 1
+        self.calls_per_search = 2 if self.shard_inference else 1
         self._buf = None
+        self._bo_loc = None
 
     def search(self, qn_t, qs_t, nb: int, k: int):
         import torch
@@ -99,8 +139,17 @@ class ShardedSearcher:
                          torch.empty((nq, kout), dtype=torch.int32, device=dev),
                          torch.empty((nq, nb), dtype=torch.int32, device=dev))
         blk, out_d, out_i, bo = self._buf
-        # the three planes of `blk` are written in place by lmi_search
-        self.index.search_device(qn_t, qs_t, nb, k, blk[0], blk[1], blk[2], bo)
+        # the three planes of `blk` are written in place by lmi_search / lmi_scan_topk
+        if self.shard_inference:
+            per, lo, hi = row_slice(nq, self.rank, self.world)
+            if self._bo_loc is None or self._bo_loc.shape != (per, nb):
+                self._bo_loc = torch.full((per, nb), -1, dtype=torch.int32, device=qn_t.device)
+            if hi > lo:
+                self.index.mlp_topk_device(qn_t[lo:hi], nb, self._bo_loc[: hi - lo])
+            bo = all_gather_rows(self._bo_loc, nq, self.world, self.group)
+            self.index.scan_topk_device(qs_t, bo, nb, k, blk[0], blk[1], blk[2])
+        else:
+            self.index.search_device(qn_t, qs_t, nb, k, blk[0], blk[1], blk[2], bo)
         if self.world == 1:
             return blk[0].view(torch.float32), blk[1], bo
         g = all_gather_blocks(blk, self.world, self.group)  # [world, 3, nq, kout]

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
                                               ("G4", 3, 15, 2), ("G4", 1, 5, 2), ("G5", 4, 10, 8)])
 def test_sharded_equals_single(oracle, name, nb, k, world):
     from learnedmetricindex_amd import _capi
-    from learnedmetricindex_amd.sharded import ShardedSearcher, assign_buckets, estimate_bucket_work
+    from learnedmetricindex_amd.sharded import ShardedSearcher, assign_buckets, estimate_bucket_work, row_slice
 
     g = load_golden(name)
     Xn, Qn, Xs, Qs = inputs_for(name, g)
@@ -45,6 +45,7 @@ def test_sharded_equals_single(oracle, name, nb, k, world):
 
     blocks = []
     handles = []
+    bo_parts = []
     for r in range(world):
         h = _capi.Index(0, chunk_rows=256)
         h.set_stream(stream)
@@ -53,8 +54,23 @@ def test_sharded_equals_single(oracle, name, nb, k, world):
         assert h.bucket_sizes().sum() == sizes[owner == r].sum()
         blk = torch.empty((3, nq, kout), dtype=torch.int32, device=dev)
         h.search_device(qn, qs, nb, k, blk[0], blk[1], blk[2], None)
+        # query-sharded inference (ShardedSearcher's default for world > 1): the rank routes its slice only;
+        # scanning with the gathered order must give the same block
+        per, lo, hi = row_slice(nq, r, world)
+        part = torch.full((per, nb), -1, dtype=torch.int32, device=dev)
+        if hi > lo:
+            h.mlp_topk_device(qn[lo:hi], nb, part[: hi - lo])
+        bo_parts.append(part)
         blocks.append(blk)
         handles.append(h)
+    bo_cat = torch.cat(bo_parts)[:nq].contiguous()  # == all_gather_rows' result
+    torch.cuda.synchronize()
+    assert torch.equal(bo_cat, sbo)
+    for r, h in enumerate(handles):
+        blk2 = torch.empty((3, nq, kout), dtype=torch.int32, device=dev)
+        h.scan_topk_device(qs, bo_cat, nb, k, blk2[0], blk2[1], blk2[2])
+        torch.cuda.synchronize()
+        assert torch.equal(blk2, blocks[r])
     gathered = torch.stack(blocks).contiguous()  # == all_gather_into_tensor's result
     out_d = torch.empty((nq, kout), dtype=torch.float32, device=dev)
     out_i = torch.empty((nq, kout), dtype=torch.int32, device=dev)

@@ -58,7 +58,14 @@ def _worker(rank, world, port, name, nb, k, out_dir):
         blk = torch.from_numpy(sharded.pack_block(np, d, i, keys))
         gathered = sharded.all_gather_blocks(blk, world)            # the one collective
         md, mi = sharded.merge_blocks_numpy(gathered.numpy(), kout)
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), d=md, i=mi, owner=owner)
+        # query-sharded inference: this rank routes its slice of the batch only, the bucket order is gathered
+        nq = Qn.shape[0]
+        per, lo, hi = sharded.row_slice(nq, rank, world)
+        loc = torch.full((per, nb), -1, dtype=torch.int32)
+        if hi > lo:
+            loc[: hi - lo] = torch.from_numpy(oracle.precompute_bucket_order(layers, Qn[lo:hi], nb)[:, :, 0].astype(np.int32))
+        bo = sharded.all_gather_rows(loc, nq, world).numpy()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), d=md, i=mi, owner=owner, bo=bo)
     finally:
         dist.destroy_process_group()
 
@@ -79,8 +86,10 @@ def test_two_rank_result_identical_to_single(oracle, tmp_path, name, nb, k):
     mp.spawn(_worker, args=(world, _free_port(), name, nb, k, str(tmp_path)), nprocs=world, join=True)
     g = load_golden(name)
     Xn, Qn, Xs, Qs = inputs_for(name, g)
-    do, io, _ = oracle.search(layers_from(g), Qn, Xs, Qs, g["data_prediction"], nb, k)
+    do, io, boo = oracle.search(layers_from(g), Qn, Xs, Qs, g["data_prediction"], nb, k)
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    for r in (r0, r1):
+        np.testing.assert_array_equal(r["bo"], boo[:, :, 0])          # gathered bucket order == unsharded routing
     np.testing.assert_array_equal(r0["owner"], r1["owner"])          # same assignment on every rank
     assert set(np.unique(r0["owner"])) == {0, 1}
     for r in (r0, r1):
@@ -103,3 +112,16 @@ def test_assign_buckets_balances_and_is_deterministic():
     w2 = assign_buckets(sizes, 8, weights=sizes.astype(float) ** 2)
     load = np.bincount(w2, weights=sizes.astype(float) ** 2, minlength=8)
     assert load.max() <= load.mean() * 1.15
+
+
+def test_row_slices_cover_the_batch():
+    from learnedmetricindex_amd.sharded import row_slice
+
+    for nq, world in ((10, 3), (10000, 8), (5, 8), (7, 2), (1, 1), (0, 4)):
+        seen = []
+        for r in range(world):
+            per, lo, hi = row_slice(nq, r, world)
+            assert 0 <= lo <= hi <= nq and hi - lo <= per and per * world >= nq
+            assert lo == min(r * per, nq)
+            seen.extend(range(lo, hi))
+        assert seen == list(range(nq))
