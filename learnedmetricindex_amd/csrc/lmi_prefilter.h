@@ -8,14 +8,19 @@
 // the two modes and of both with the oracle).  Slots whose candidate sets overflow fall back to an
 // exact brute-force kernel; nothing is ever approximate in the output.
 //
-// Scaled units.  Index vectors are stored as x' = sx * x in fp16 (sx = one power of two per index
-// with max|x'| in [0.5, 1)), queries as q' = sq * q (one power of two per batch); shat = sum q^_k x^_k
-// approximates s' = sx*sq*s.  With u = 2^-11 (fp16 unit roundoff), sub = 2^-25 (half the fp16
-// subnormal spacing), N = ||q'||*||x'||:
-//   |q^_k - q'_k| <= u|q'_k| + sub (same for x), fp16 x fp16 products are exact in binary32, and any
-//   binary32 summation of d terms errs by at most d*2^-24 * sum|terms| (first order), so
-//   |shat - s'_canonical| <= eps' := (2u + u^2 + 2.5*d*2^-24) * N + 1.001*sub*sqrt(d)*(||q'||+||x'||) + d*sub^2
-//   (the 2.5*d*2^-24 covers the MFMA's accumulation AND the canonical chain's own rounding).
+// Scaled units.  Index vectors are stored as x^ = fp16(x'), x' = sx * x (sx = one power of two per index
+// with max|x'| in [0.5, 1)), queries as q^ = fp16(q'), q' = sq * q (one power of two per QUERY: a slot's
+// scores are only compared with scores of the same query); shat = sum q^_k x^_k approximates s' = sx*sq*s.
+//   fp16 x fp16 products are exact in binary32; a round-to-nearest binary32 summation of d terms errs by at
+//   most d*2^-24 * sum|terms| (the canonical chain), one whose additions may truncate by d*2^-23 * sum|terms|
+//   (allowed for the MFMA's accumulation); and
+//   |<q^,x^> - <q',x'>| = |<q^-q', x^> + <q', x^-x'>| <= ||q^-q'|| ||x^|| + ||q'|| ||x^-x'||     (Cauchy-Schwarz)
+//   where the rounding-error norms are MEASURED (q^_k - q'_k is exact in binary32): per query by
+//   query_norm_kernel, the largest per bucket by bucket_norm_kernel at build time, all rounded up.  So
+//   |shat - s'_canonical| <= eps' := dq (xn + dx) + qn dx + 4 d 2^-24 (qn + dq)(xn + dx)            (slot_bound_kernel)
+//   with qn = ||q'||, dq = ||q^-q'||, xn / dx the bucket's largest ||x'|| / ||x^-x'||.  Subnormal fp16
+//   operands are covered by the measured norms, provided the hardware converts and multiplies them
+//   un-flushed: pf_selftest_kernel checks that once per process.
 // Candidate rule.  Let That be the 10th largest shat of the bucket.  The 10 rows with shat >= That have
 // s'_c >= That - eps', hence the canonical 10th best T_c >= That - eps', hence every row of the
 // canonical top-10 has shat >= T_c - eps' >= That - 2 eps'.  Any lower bound of That may replace it:
@@ -259,17 +264,19 @@ __global__ void slot_bound_kernel(const int* __restrict__ bucket_order, const in
 }
 
 // ------------------------------------------------------------------------------------------------
-// Prefilter kernels: fp16 operands, 256 x 128 block tile (wave = 64 vectors x 128 queries, 8
-// accumulator tiles), both operands by LDS-DMA into a ring of three 24-KiB stages (32 k each), one
-// barrier per stage, stage u+2 in flight while stage u computes.  (A/B on MI355X, 10M x 768: a
-// one-stage register pipeline (A to VGPRs, B via VGPR -> ds_write) spent 71 % of its wave time parked
-// on waits -- an fp16 stage is 8x shorter than an f32 one, shorter than the memory latency; the ring
-// is 25 % faster.)  Two passes over the same code (template SAMPLE):
-//   pass 1 (SAMPLE):  PF_PARTS items per (bucket, query tile) scan every PF_SAMPLE-th 256-row tile of
-//                     the whole bucket (part p takes sampled tiles p, p+PF_PARTS, ..) with per-lane
-//                     VALUES-ONLY top-10 lists, merge the 8 lists of a column and store the part's 10
+// Prefilter kernels: fp16 operands; block tile 256 vectors x 256 queries (8 waves = two groups of four, one
+// block per CU; build option LMI_PF_NG=1: 256 x 128, 4 waves, two blocks per CU); wave = 64 vectors x <= 128
+// queries, 8 accumulator tiles; both operands by LDS-DMA into a ring of three stages (32 k each, 32 KiB),
+// one barrier per stage, stage u+2 in flight while stage u computes; inside a stage the fragment reads are
+// inline asm, the DMA pieces sit between the MFMA groups and the last group is deferred across the barrier
+// (step_fused).  (A/B on MI355X, 10M x 768: a one-stage register pipeline (A to VGPRs, B via VGPR ->
+// ds_write) spent 71 % of its wave time parked on waits -- an fp16 stage is 8x shorter than an f32 one,
+// shorter than the memory latency; the ring is 25 % faster.)  Two passes over the same code (template SAMPLE):
+//   pass 1 (SAMPLE):  P.parts (4, 8 or 16) items per (bucket, query tile) scan every PF_SAMPLE-th 256-row
+//                     tile of the whole bucket (part p takes sampled tiles p, p+parts, ..) with per-lane
+//                     VALUES-ONLY top-PF_LK lists, merge the 8 lists of a column and store the part's 10
 //                     best; the consumer's 10th best of the union of the parts is a lower bound of the
-//                     bucket's 10th best That (-inf if the sample holds < 10 rows);
+//                     bucket's 10th best That (-inf if the lists hold < 10 values);
 //   pass 2 (!SAMPLE): items (bucket, query tile, chunk) from the XCD-affine queues; no lists, no
 //                     inter-item traffic: every row with shat >= bound[col] - 2 eps' is appended to
 //                     the slot's candidate buffer.  About 10 * PF_SAMPLE rows per slot pass.
