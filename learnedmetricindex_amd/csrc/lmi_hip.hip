@@ -779,7 +779,8 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     M.out_d = d_dists;
     M.out_id = d_ids;
     M.out_key = d_keys;
-    merge_kernel<<<nq, 64, 0, h->stream>>>(M);
+    if (M.skip_a && nb <= 16) merge_ranks_kernel<<<cdiv(nq, 64), 64, 0, h->stream>>>(M);  // rank lists exist: a thread per query
+    else merge_kernel<<<nq, 64, 0, h->stream>>>(M);
     HIPCHK(hipGetLastError());
     CHK(record(h, 4));
     h->stats_pending = true;
