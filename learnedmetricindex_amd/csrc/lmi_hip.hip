@@ -752,7 +752,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
 #endif
         CHK(record(h, 7));
 #ifndef LMI_ABL_NOEMIT
-        fallback_kernel<<<nslots, 256, 0, h->stream>>>(Q);
+        fallback_kernel<<<cdiv(nslots, 256), 256, 0, h->stream>>>(Q);
         HIPCHK(hipGetLastError());
 #endif
         CHK(record(h, 3));

@@ -1162,8 +1162,20 @@ __global__ void prefilter_stats_kernel(const int* __restrict__ nkeep, const int*
 __global__ __launch_bounds__(256) void fallback_kernel(RescoreParams P) {
     __shared__ float fs[256 * KPB];
     __shared__ unsigned fr[256 * KPB];
-    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    if (p >= P.nslots || !P.fallback[p]) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // a block looks at 256 slots' flags at once and works through the flagged ones (a launch of one block
+    // per slot spent 13 us finding nothing to do)
+    __shared__ int todo[256], ntodo;
+    if (tid == 0) ntodo = 0;
+    __syncthreads();
+    {
+        const int mine = blockIdx.x * 256 + tid;
+        if (mine < P.nslots && P.fallback[mine]) todo[atomicAdd(&ntodo, 1)] = mine;
+    }
+    __syncthreads();
+    const int nt = ntodo;
+    for (int ti = 0; ti < nt; ++ti) {
+    const int p = todo[ti];
     const int b = P.bucket_order[p];
     const int rb0 = P.rb_start[b], n_b = P.nb_rows[b];
     const float* qv = P.q + (size_t)(p / P.nb) * P.d;
@@ -1178,7 +1190,7 @@ __global__ __launch_bounds__(256) void fallback_kernel(RescoreParams P) {
 #pragma unroll
     for (int j = 0; j < KPB; ++j) { fs[tid * KPB + j] = v[j]; fr[tid * KPB + j] = id[j]; }
     __syncthreads();
-    if (tid >= 64) return;
+    if (tid < 64) {
     // wave 0: lane owns lists lane, lane+64, lane+128, lane+192 (heads 4 bits each)
     unsigned heads = 0;
     float my_s = -INFINITY;
@@ -1209,6 +1221,9 @@ __global__ __launch_bounds__(256) void fallback_kernel(RescoreParams P) {
     }
     write_rank_list(lane, my_s, my_r, n_b, rb0, P.raw, P.ids_slab, P.rank_d + (size_t)p * KPB,
                     P.rank_id + (size_t)p * KPB);
+    }
+    __syncthreads();  // fs / fr are reused by the block's next slot
+    }
 }
 
 }  // namespace lmi
