@@ -62,6 +62,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--chunk-rows", type=int, default=None)
+    ap.add_argument("--timing-level", type=int, default=2, choices=(0, 1, 2),
+                    help="lmi_set_timing: 2 (default) times every phase with hipEvents -- the roofline needs the dominant "
+                         "kernel's duration; 0/1 show the step without the events' bubbles (roofline fields then null/0)")
     ap.add_argument("--exact", action="store_true",
                     help="all-f32 scan (lmi_set_prefilter(0)) instead of fp16 prefilter + exact re-rank; same results")
     ap.add_argument("--emulate-shard", default=None, metavar="R/W",
@@ -139,6 +142,7 @@ def main():
     eng = _capi.Index(local_rank, chunk_rows=args.chunk_rows, prefilter=not args.exact)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     eng.set_mlp(layers)
+    eng.set_timing(args.timing_level)
     labels = torch.empty(N, dtype=torch.int32, device=dev)
     for p, n in pieces:
         x = gen_rows(1, p, n)
@@ -280,7 +284,8 @@ def main():
 
     if rank == 0:
         scan_s = float(phases[_capi.T_SCAN]) * 1e-3
-        dom_s = float(phases[dom_slot]) * 1e-3
+        dom_s = max(float(phases[dom_slot]) * 1e-3, 1e-12)  # 0 when --timing-level < 2: the roofline fields are meaningless then
+        scan_s = max(scan_s, 1e-12)
         visited = np.unique(bo.cpu().numpy())
         visited = visited[(visited >= 0) & (owner[np.clip(visited, 0, L - 1)] == rank)]
         rows_visited = float(sizes[visited].sum())

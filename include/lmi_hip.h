@@ -136,6 +136,9 @@ LMI_API int lmi_timings(lmi_index *h, float *ms /* [LMI_T_COUNT] */);
 /* Mean of the timing slots over the calls made since lmi_timings_reset (the newest 128 at most), read
  * with ONE stream synchronisation, so a timed loop needs no per-call sync; *n_calls = calls averaged. */
 LMI_API int lmi_timings_reset(lmi_index *h);
+/* How much is timed: 2 (default) every phase, 1 only LMI_T_TOTAL (and LMI_T_INFERENCE), 0 nothing -- every
+ * event recorded between two kernels is a bubble of a few microseconds (7 of them: 9 % of a 1 000-query search). */
+LMI_API int lmi_set_timing(lmi_index *h, int level);
 LMI_API int lmi_timings_mean(lmi_index *h, float *ms /* [LMI_T_COUNT] */, int *n_calls /* nullable */);
 /* Work done by the last scan: flops = 2 * d * sum over (query, rank) of the bucket size;
  * items = work items executed by the persistent scan kernel. */

@@ -52,6 +52,7 @@ SIGNATURES = {
                                   ctypes.c_int, _vp, _vp]),
     "lmi_timings": (ctypes.c_int, [_vp, _vp]),
     "lmi_timings_reset": (ctypes.c_int, [_vp]),
+    "lmi_set_timing": (ctypes.c_int, [_vp, ctypes.c_int]),
     "lmi_timings_mean": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(ctypes.c_int)]),
     "lmi_scan_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double), _i64p, _i64p]),
     "lmi_set_chunk_rows": (ctypes.c_int, [_vp, ctypes.c_int]),
@@ -272,6 +273,10 @@ class Index:
         ms = np.zeros(T_COUNT, dtype=np.float32)
         _check(lib().lmi_timings(self._h, _ptr(ms)))
         return ms
+
+    def set_timing(self, level: int) -> None:
+        """2: every phase (default), 1: total only, 0: no events (each one is a few-microsecond bubble)."""
+        _check(lib().lmi_set_timing(self._h, int(level)))
 
     def timings_reset(self) -> None:
         _check(lib().lmi_timings_reset(self._h))

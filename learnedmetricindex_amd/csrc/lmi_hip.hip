@@ -115,6 +115,7 @@ struct lmi_index {
     hipEvent_t ev_ring[EV_RING][10] = {};
     bool valid_ring[EV_RING][10] = {};
     int ev_cur = 0;
+    int timing_level = 2;  // lmi_set_timing
     long long ev_calls = 0;  // calls since lmi_timings_reset
     hipEvent_t* ev = ev_ring[0];
     bool* ev_valid = valid_ring[0];
@@ -433,6 +434,9 @@ static void begin_call(lmi_index* h) {
 }
 
 static int record(lmi_index* h, int i) {
+    // every recorded event is a ~6 us bubble between two kernels: level 1 keeps the call's first and last
+    // event (LMI_T_TOTAL), level 0 none
+    if (h->timing_level == 0 || (h->timing_level == 1 && i != 0 && i != 1 && i != 4)) return 0;
     HIPCHK(hipEventRecord(h->ev[i], h->stream));
     h->ev_valid[i] = true;
     return 0;
@@ -975,6 +979,13 @@ extern "C" LMI_API int lmi_timings(lmi_index* h, float* ms) {
     CHK(set_dev(h));
     HIPCHK(hipStreamSynchronize(h->stream));
     return read_event_set(h->ev, h->ev_valid, ms);
+}
+
+extern "C" LMI_API int lmi_set_timing(lmi_index* h, int level) {
+    if (!h) return fail("lmi_set_timing: NULL handle");
+    if (level < 0 || level > 2) return fail("lmi_set_timing: level %d outside 0..2", level);
+    h->timing_level = level;
+    return 0;
 }
 
 extern "C" LMI_API int lmi_timings_reset(lmi_index* h) {

@@ -149,4 +149,18 @@ def test_timings_ring_mean(capi):
         idx.mlp_topk(Qn[:8], nb)
     _, n = idx.timings_mean()
     assert n == 128
+    # timing levels: 1 keeps the call's first and last event, 0 records nothing (each event is a bubble)
+    idx.set_timing(1)
+    idx.search(Qn, Qs, nb, k)
+    t1 = idx.timings()
+    assert t1[capi.T_TOTAL] > 0 and t1[capi.T_SCAN] == 0 and t1[capi.T_PF_EMIT] == 0
+    idx.set_timing(0)
+    d0, i0, _ = idx.search(Qn, Qs, nb, k)
+    assert not idx.timings().any()
+    idx.set_timing(2)
+    d2, i2, _ = idx.search(Qn, Qs, nb, k)
+    assert idx.timings()[capi.T_SCAN] > 0
+    np.testing.assert_array_equal(i0, i2)
+    with pytest.raises(capi.LmiError):
+        idx.set_timing(3)
     idx.close()
