@@ -150,7 +150,8 @@ LMI_API int lmi_scan_stats(lmi_index *h, double *flops, int64_t *pairs, int64_t 
  * re-scored exactly and how many (query, rank) slots fell back to the exact brute-force kernel. */
 LMI_API int lmi_set_prefilter(lmi_index *h, int on);
 LMI_API int lmi_prefilter_stats(lmi_index *h, int *active, int64_t *survivors, int64_t *fallbacks);
-/* Tuning: rows per scan chunk (multiple of the 256-row block tile; default 2048). */
+/* Tuning: rows per scan chunk (multiple of the 256-row block tile).  Not called: lmi_buckets_begin picks
+ * 256..2048 by the size of the index (this rank's rows / 4096), and more for buckets beyond 1024 chunks. */
 LMI_API int lmi_set_chunk_rows(lmi_index *h, int rows);
 
 #ifdef __cplusplus

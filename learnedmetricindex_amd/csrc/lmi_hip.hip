@@ -90,6 +90,7 @@ struct lmi_index {
     int64_t N = 0;
     int d = 0, L = 0, KGs = 0;
     int chunk_rows = 2048;
+    bool chunk_rows_auto = true;  // until lmi_set_chunk_rows: lmi_buckets_begin picks 256..2048 by the index size
     int64_t n_rb_total = 0;
     std::vector<int> h_nb_rows, h_rb_start, h_nch;
     DevBuf slab, ids_slab, pos, d_nb_rows, d_rb_start, d_nch;
@@ -201,6 +202,7 @@ extern "C" LMI_API int lmi_set_chunk_rows(lmi_index* h, int rows) {
     if (rows < PF_TILE_ROWS || rows % PF_TILE_ROWS) return fail("lmi_set_chunk_rows: rows must be a positive multiple of %d", PF_TILE_ROWS);
     if (h->building || h->built) return fail("lmi_set_chunk_rows: must be called before lmi_buckets_begin");
     h->chunk_rows = rows;
+    h->chunk_rows_auto = false;
     return 0;
 }
 
@@ -274,10 +276,17 @@ extern "C" LMI_API int lmi_buckets_begin(lmi_index* h, int64_t N, int d, int L, 
     }
     h->h_rb_start.assign(L + 1, 0);
     h->h_nch.assign(L, 0);
-    // a bucket is scanned in at most 1024 chunks: very large buckets get larger chunks than the handle's setting
+    // Chunk rows not set by the caller: small indexes (or small shards) get smaller chunks so that a scan has
+    // many more work items than the 256 blocks that share them (100 000 rows x 1 000 queries: pass 2 0.169 ms
+    // with 2048-row chunks, 0.089 ms with 256; the 1.25M-row shard of an 8-way split that holds the largest
+    // bucket: 0.90 ms with 2048, 0.69 ms with 512); 10M rows keep 2048.
+    // A bucket is scanned in at most 1024 chunks: very large buckets get larger chunks than that.
     {
         int max_rows = 0;
-        for (int b = 0; b < L; ++b) max_rows = std::max(max_rows, h->h_nb_rows[b]);
+        long long owned_rows = 0;
+        for (int b = 0; b < L; ++b) { max_rows = std::max(max_rows, h->h_nb_rows[b]); owned_rows += h->h_nb_rows[b]; }
+        if (h->chunk_rows_auto)
+            h->chunk_rows = (int)std::min<long long>(2048, std::max<long long>(PF_TILE_ROWS, rup(owned_rows / 4096, PF_TILE_ROWS)));
         const int need = (int)rup(cdiv(max_rows, 1024), 256);
         if (need > h->chunk_rows) h->chunk_rows = need;
     }
