@@ -480,10 +480,10 @@ __device__ __forceinline__ void glds16(const float4* gsrc, float4* lds_wave_base
 
 // the same with the instruction's immediate offset OFF (bytes), which the hardware adds to BOTH addresses:
 // consecutive 1-KiB fragments of one stream share the address registers and the M0 base
-template <int OFF>
+template <int OFF, int AUX = 0>  // AUX 2 = nt (non-temporal): a stream that is read once
 __device__ __forceinline__ void glds16o(const float4* gsrc, float4* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, OFF, 0);
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, OFF, AUX);
 }
 
 // sorted (descending) insert of (s,row) into a 10-entry register list; caller checked s > v[9].

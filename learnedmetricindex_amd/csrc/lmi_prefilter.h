@@ -288,6 +288,9 @@ constexpr int PF_SAMPLE = LMI_PF_SAMPLE;  // pass 1 looks at every 16th tile ...
 #ifndef LMI_PF_RING2
 #define LMI_PF_RING2 3  // ring slots of the NG 2 kernel (3 or 4; A/B on MI355X: 4 is 3 % slower, more in flight only raised the load latency)
 #endif
+#ifndef LMI_PF_A_AUX
+#define LMI_PF_A_AUX 0  // cache policy of the vector-fragment DMA (2 = nt: measured 3 % slower, a chunk is read by its 2 query tiles)
+#endif
 #ifndef LMI_PF_FUSED
 #define LMI_PF_FUSED 1  // NG 2: DMA pieces interleaved with the MFMA groups of the stage
 #endif
@@ -469,12 +472,12 @@ struct PreItem {
         lds_rd<(0 * PF_STAGE_G + 1) * 1024>(a01, aA);
         lds_rd<(1 * PF_STAGE_G + 1) * 1024>(a11, aA);
 #ifndef LMI_ABL_NOLOAD
-        glds16(reinterpret_cast<const float4*>(ap0 + lane), dA);
+        glds16o<0, LMI_PF_A_AUX>(reinterpret_cast<const float4*>(ap0 + lane), dA);
 #endif
         mma<0>(a00, b0);
         __builtin_amdgcn_sched_barrier(0);
 #ifndef LMI_ABL_NOLOAD
-        glds16o<1024>(reinterpret_cast<const float4*>(ap0 + lane), dA);
+        glds16o<1024, LMI_PF_A_AUX>(reinterpret_cast<const float4*>(ap0 + lane), dA);
 #endif
         mma<1>(a10, b0);
         __builtin_amdgcn_sched_barrier(0);
