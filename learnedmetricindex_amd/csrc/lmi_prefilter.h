@@ -281,10 +281,19 @@ __global__ void slot_bound_kernel(const int* __restrict__ bucket_order, const in
 //                     inter-item traffic: every row with shat >= bound[col] - 2 eps' is appended to
 //                     the slot's candidate buffer.  About 10 * PF_SAMPLE rows per slot pass.
 // ------------------------------------------------------------------------------------------------
+#ifndef LMI_PF_SAMPLE_ROWS
+#define LMI_PF_SAMPLE_ROWS 2000  // a bucket is sampled at stride s only if it has >= this many rows per unit of s (1300..3500: within 1 %)
+#endif
 #ifndef LMI_PF_SAMPLE
 #define LMI_PF_SAMPLE 16
 #endif
-constexpr int PF_SAMPLE = LMI_PF_SAMPLE;  // pass 1 looks at every 16th tile ...
+constexpr int PF_SAMPLE = LMI_PF_SAMPLE;  // pass 1 looks at every 16th tile of a large bucket ...
+// ... and at every 8th, 4th, 2nd or every tile of buckets below LMI_PF_SAMPLE_ROWS x the stride (see PreItem::run)
+__device__ __forceinline__ int sample_stride(int n_b) {
+    int s = PF_SAMPLE;
+    while (s > 1 && n_b < LMI_PF_SAMPLE_ROWS * s) s >>= 1;
+    return s;
+}
 #ifndef LMI_PF_RING2
 #define LMI_PF_RING2 3  // ring slots of the NG 2 kernel (3 or 4; A/B on MI355X: 4 is 3 % slower, more in flight only raised the load latency)
 #endif
@@ -624,8 +633,13 @@ struct PreItem {
         const int nrb_b = (n_b + 31) >> 5;
         const int nrb_all = SAMPLE ? nrb_b : min(P.chunk_rb, nrb_b - ch * P.chunk_rb);
         const int nvt_all = (nrb_all + 4 * PF_RB - 1) / (4 * PF_RB);
-        const int TSTEP = SAMPLE ? PF_SAMPLE * P.parts : 1;       // tile stride
-        const int t0 = SAMPLE ? ch * PF_SAMPLE : 0;               // first tile
+        // Sampling stride of the bucket: every PF_SAMPLE-th tile for large buckets, denser for small ones, so that
+        // pass 2 never emits more than ~0.5 % of a bucket's rows per slot (10 x stride of them): at 160 candidates
+        // per slot a 5 000-row bucket puts > 64 candidates into every 64 x 128 wave tile and the epilogue
+        // leaves its fast path for one returning atomic per candidate (a few such buckets cost 7 % of pass 2).
+        const int stride = SAMPLE ? sample_stride(n_b) : 1;
+        const int TSTEP = SAMPLE ? stride * P.parts : 1;          // tile stride
+        const int t0 = SAMPLE ? ch * stride : 0;                  // first tile
         const int nvt = nvt_all > t0 ? (nvt_all - t0 + TSTEP - 1) / TSTEP : 0;  // tiles this item processes
         const int rb_in_b0 = SAMPLE ? t0 * 4 * PF_RB : ch * P.chunk_rb;
         const int cb_tile = P.cb_start[b] + cbt0;                 // the tile's first col-block (global)
