@@ -88,6 +88,12 @@ LMI_API int lmi_set_mlp(lmi_index *h, int n_layers, const int *dims, const float
 LMI_API int lmi_buckets_begin(lmi_index *h, int64_t N, int d, int L, const int64_t *labels,
                       const uint32_t *ids, const uint8_t *owned);
 LMI_API int lmi_buckets_add_rows(lmi_index *h, const float *rows, int64_t row0, int64_t nrows, int on_device);
+/* Owned-only ingest (bucket-sharded ranks): rows [nrows][d] are the objects index[0..nrows) (original row
+ * numbers, each OWNED object exactly once, any order); objects of buckets this handle does not own are never
+ * passed in, so a rank of an 8-way shard reads 1/8 of the dataset.  Not to be mixed with lmi_buckets_add_rows
+ * within one build.  `on_device` covers both pointers. */
+LMI_API int lmi_buckets_add_owned_rows(lmi_index *h, const float *rows, const int64_t *index, int64_t nrows,
+                               int on_device);
 LMI_API int lmi_buckets_end(lmi_index *h);
 /* sizes[L] <- number of objects per bucket (0 for buckets not owned). */
 LMI_API int lmi_bucket_sizes(lmi_index *h, int64_t *sizes);
@@ -153,6 +159,16 @@ LMI_API int lmi_prefilter_stats(lmi_index *h, int *active, int64_t *survivors, i
 /* Tuning: rows per scan chunk (multiple of the 256-row block tile).  Not called: lmi_buckets_begin picks
  * 256..2048 by the size of the index (this rank's rows / 4096), and more for buckets beyond 1024 chunks. */
 LMI_API int lmi_set_chunk_rows(lmi_index *h, int rows);
+
+/* Test hooks for the prefilter's error bound (tests/test_gpu_bound.py; no reference counterpart).
+ * lmi_debug_emit_all(1): the next scans drop the sampled bound, so pass 2 emits EVERY row of a visited
+ * bucket (buckets of <= 1024 rows fit the candidate buffer) -- results are unchanged (overflowing slots take
+ * the exact fallback).  lmi_debug_read_candidates: for (query, rank) slot = q*nb + r of the last scan, the
+ * in-bucket rows and the fp16-MFMA scores shat pass 2 computed for them (scaled units: shat ~ xscale *
+ * qscale * <q, x>), the emitted count (-1: unvisited), 2*eps' of the slot and the two power-of-two scales. */
+LMI_API int lmi_debug_emit_all(lmi_index *h, int on);
+LMI_API int lmi_debug_read_candidates(lmi_index *h, int64_t slot, int cap, uint32_t *rows, float *shat,
+                              int *count, float *eps2, float *qscale, float *xscale);
 
 #ifdef __cplusplus
 }

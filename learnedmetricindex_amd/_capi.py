@@ -37,6 +37,7 @@ SIGNATURES = {
     "lmi_set_mlp": (ctypes.c_int, [_vp, ctypes.c_int, _i32p, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     "lmi_buckets_begin": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
     "lmi_buckets_add_rows": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int]),
+    "lmi_buckets_add_owned_rows": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int]),
     "lmi_buckets_end": (ctypes.c_int, [_vp]),
     "lmi_bucket_sizes": (ctypes.c_int, [_vp, _vp]),
     "lmi_mlp_topk": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int]),
@@ -58,6 +59,9 @@ SIGNATURES = {
     "lmi_set_chunk_rows": (ctypes.c_int, [_vp, ctypes.c_int]),
     "lmi_set_prefilter": (ctypes.c_int, [_vp, ctypes.c_int]),
     "lmi_prefilter_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), _i64p, _i64p]),
+    "lmi_debug_emit_all": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "lmi_debug_read_candidates": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, _vp, _vp,
+                                                 ctypes.POINTER(ctypes.c_int), _f32p, _f32p, _f32p]),
 }
 
 
@@ -145,6 +149,21 @@ class Index:
         _check(lib().lmi_prefilter_stats(self._h, ctypes.byref(a), ctypes.byref(sv), ctypes.byref(fb)))
         return bool(a.value), sv.value, fb.value
 
+    def debug_emit_all(self, on: bool) -> None:
+        """Test hook: pass 2 emits every row of a visited bucket (see include/lmi_hip.h)."""
+        _check(lib().lmi_debug_emit_all(self._h, 1 if on else 0))
+
+    def debug_read_candidates(self, slot: int, cap: int = 1024):
+        """Test hook: (rows u32[n], shat f32[n], emitted count, 2*eps', qscale, xscale) of slot q*nb+r."""
+        rows = np.empty(cap, dtype=np.uint32)
+        shat = np.empty(cap, dtype=np.float32)
+        cnt = ctypes.c_int(0)
+        e2, qs, xs = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_float(0)
+        _check(lib().lmi_debug_read_candidates(self._h, int(slot), int(cap), _ptr(rows), _ptr(shat), ctypes.byref(cnt),
+                                               ctypes.byref(e2), ctypes.byref(qs), ctypes.byref(xs)))
+        n = max(0, min(cnt.value, cap))
+        return rows[:n], shat[:n], cnt.value, e2.value, qs.value, xs.value
+
     def set_stream(self, stream_ptr: int) -> None:
         _check(lib().lmi_set_stream(self._h, _vp(stream_ptr)))
 
@@ -184,6 +203,17 @@ class Index:
             on_device = 1
         assert rows.shape[1] == self.d
         _check(lib().lmi_buckets_add_rows(self._h, _ptr(rows), int(row0), int(rows.shape[0]), on_device))
+
+    def add_owned_rows(self, rows, index) -> None:
+        """Owned-only ingest: rows[i] is object index[i] (int64 original row numbers); both numpy or both CUDA tensors."""
+        if isinstance(rows, np.ndarray):
+            rows, index, on_device = _np(rows, np.float32), _np(index, np.int64).reshape(-1), 0
+        else:
+            assert rows.is_cuda and rows.is_contiguous() and rows.element_size() == 4 and rows.dtype.is_floating_point
+            assert index.is_cuda and index.is_contiguous() and index.element_size() == 8
+            on_device = 1
+        assert rows.shape[1] == self.d and index.shape[0] == rows.shape[0]
+        _check(lib().lmi_buckets_add_owned_rows(self._h, _ptr(rows), _ptr(index), int(rows.shape[0]), on_device))
 
     def buckets_end(self) -> None:
         _check(lib().lmi_buckets_end(self._h))

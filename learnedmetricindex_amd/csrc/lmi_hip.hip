@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -94,7 +95,8 @@ struct lmi_index {
     int64_t n_rb_total = 0;
     std::vector<int> h_nb_rows, h_rb_start, h_nch;
     DevBuf slab, ids_slab, pos, d_nb_rows, d_rb_start, d_nch;
-    int64_t rows_added = 0;
+    int64_t rows_added = 0, owned_total = 0;
+    bool indexed_ingest = false;  // lmi_buckets_add_owned_rows: only the owned objects are passed in
     DevBuf stage;  // H2D staging for add_rows / host query uploads
     // ---- fp16 prefilter (lmi_prefilter.h) ----
     bool prefilter = true;   // lmi_set_prefilter
@@ -103,8 +105,9 @@ struct lmi_index {
     int KG16 = 0;
     DevBuf slab16, rowmajor, xscale, xmaxbits, bnorm, bdelta, qdelta;
     DevBuf qnorm, qscale, qfrag16, eps2, cand_cnt, cand_row, cand_s, fallback, pf_bound, nkeep;
-    int last_nslots = 0;
+    int last_nslots = 0, last_nb = 0;
     bool last_fast = false;
+    bool debug_emit_all = false;  // lmi_debug_emit_all
 
     // ---- per-call workspaces ----
     DevBuf act[2], xfrag, logits, order, q_nav, q_srch;
@@ -151,10 +154,12 @@ extern "C" LMI_API int lmi_create(int device, lmi_index** out) {
     int occ = 0;
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_kernel, 256, SCAN_LDS));
     h->scan_blocks_per_cu = std::max(1, std::min(occ, RB == 1 ? 2 : 1));
-    for (int r = 0; r < lmi_index::EV_RING; ++r)
-        for (int i = 0; i < 10; ++i) HIPCHK(hipEventCreate(&h->ev_ring[r][i]));
+    // the timing events are created on first use (record): a handle that lives for one lmi_knn_ip call
+    // touches 4 of the ring's 1 280
     {   // fp16 subnormal self-test (lmi_prefilter.h): the error bound of the prefilter relies on it
-        static int cached = -1;  // per process; every MI355X behaves the same
+        static std::mutex mu;    // per process; every MI355X behaves the same
+        static int cached = -1;
+        std::lock_guard<std::mutex> lock(mu);
         if (cached < 0) {
             int* d_ok = nullptr;
             int ok = 0;
@@ -332,43 +337,75 @@ extern "C" LMI_API int lmi_buckets_begin(lmi_index* h, int64_t N, int d, int L, 
     HIPCHK(hipMemcpy(h->d_rb_start.p, h->h_rb_start.data(), (L + 1) * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_nch.p, h->h_nch.data(), L * 4, hipMemcpyHostToDevice));
     h->rows_added = 0;
+    h->indexed_ingest = false;
+    h->owned_total = 0;
+    for (int b = 0; b < L; ++b) h->owned_total += h->h_nb_rows[b];
     h->building = true;
     return 0;
 }
 
-extern "C" LMI_API int lmi_buckets_add_rows(lmi_index* h, const float* rows, int64_t row0, int64_t nrows, int on_device) {
-    if (!h || !h->building) return fail("lmi_buckets_add_rows: call lmi_buckets_begin first");
-    if (row0 < 0 || nrows < 0 || row0 + nrows > h->N) return fail("lmi_buckets_add_rows: rows [%lld,%lld) outside [0,%lld)", (long long)row0, (long long)(row0 + nrows), (long long)h->N);
-    if (nrows == 0) return 0;
+// rows [nrows][d] are objects row0.. (index == NULL) or objects index[0..nrows) (host or device like `rows`)
+static int add_rows_impl(lmi_index* h, const float* rows, int64_t row0, const int64_t* index, int64_t nrows, int on_device) {
     CHK(set_dev(h));
     const int64_t piece = std::max<int64_t>(1, (256ll << 20) / ((int64_t)h->d * 4));
     for (int64_t off = 0; off < nrows; off += piece) {
         const int64_t n = std::min(piece, nrows - off);
         const float* src = rows + off * h->d;
+        const long long* idx = index ? reinterpret_cast<const long long*>(index + off) : nullptr;
         if (!on_device) {
-            CHK(h->stage.reserve((size_t)n * h->d * 4));
-            HIPCHK(hipMemcpyAsync(h->stage.p, src, (size_t)n * h->d * 4, hipMemcpyHostToDevice, h->stream));
+            const size_t row_bytes = (size_t)n * h->d * 4;
+            CHK(h->stage.reserve(row_bytes + (index ? (size_t)n * 8 : 0)));
+            HIPCHK(hipMemcpyAsync(h->stage.p, src, row_bytes, hipMemcpyHostToDevice, h->stream));
             src = h->stage.as<float>();
+            if (index) {
+                HIPCHK(hipMemcpyAsync(h->stage.as<char>() + row_bytes, index + off, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+                idx = reinterpret_cast<const long long*>(h->stage.as<char>() + row_bytes);
+            }
         }
         if (h->prefilter) {
             long long total = (long long)n * h->d;
-            scatter_rows_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(src, h->d, h->pos.as<int>(), row0 + off, n,
+            scatter_rows_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(src, h->d, h->pos.as<int>(), row0 + off, idx, (long long)h->N, n,
                                                                         h->rowmajor.as<float>());
         } else {
             long long total = (long long)n * h->KGs;
-            pack_scatter_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(src, h->d, h->pos.as<int>(), row0 + off, n,
+            pack_scatter_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(src, h->d, h->pos.as<int>(), row0 + off, idx, (long long)h->N, n,
                                                                         h->KGs, h->slab.as<float4>());
         }
         HIPCHK(hipGetLastError());
         if (!on_device) HIPCHK(hipStreamSynchronize(h->stream));
     }
+    return 0;
+}
+
+extern "C" LMI_API int lmi_buckets_add_rows(lmi_index* h, const float* rows, int64_t row0, int64_t nrows, int on_device) {
+    if (!h || !h->building) return fail("lmi_buckets_add_rows: call lmi_buckets_begin first");
+    if (h->indexed_ingest) return fail("lmi_buckets_add_rows: this build already uses lmi_buckets_add_owned_rows");
+    if (row0 < 0 || nrows < 0 || row0 + nrows > h->N) return fail("lmi_buckets_add_rows: rows [%lld,%lld) outside [0,%lld)", (long long)row0, (long long)(row0 + nrows), (long long)h->N);
+    if (nrows == 0) return 0;
+    CHK(add_rows_impl(h, rows, row0, nullptr, nrows, on_device));
+    h->rows_added += nrows;
+    return 0;
+}
+
+extern "C" LMI_API int lmi_buckets_add_owned_rows(lmi_index* h, const float* rows, const int64_t* index, int64_t nrows,
+                                          int on_device) {
+    if (!h || !h->building) return fail("lmi_buckets_add_owned_rows: call lmi_buckets_begin first");
+    if (h->rows_added > 0 && !h->indexed_ingest) return fail("lmi_buckets_add_owned_rows: this build already uses lmi_buckets_add_rows");
+    if (nrows < 0 || (nrows > 0 && (!rows || !index))) return fail("lmi_buckets_add_owned_rows: bad arguments");
+    if (!on_device)
+        for (int64_t i = 0; i < nrows; ++i)
+            if (index[i] < 0 || index[i] >= h->N) return fail("lmi_buckets_add_owned_rows: index[%lld] = %lld outside [0,%lld)", (long long)i, (long long)index[i], (long long)h->N);
+    h->indexed_ingest = true;
+    if (nrows == 0) return 0;
+    CHK(add_rows_impl(h, rows, 0, index, nrows, on_device));
     h->rows_added += nrows;
     return 0;
 }
 
 extern "C" LMI_API int lmi_buckets_end(lmi_index* h) {
     if (!h || !h->building) return fail("lmi_buckets_end: call lmi_buckets_begin first");
-    if (h->rows_added != h->N) return fail("lmi_buckets_end: %lld of %lld rows were added", (long long)h->rows_added, (long long)h->N);
+    const int64_t expect = h->indexed_ingest ? h->owned_total : h->N;
+    if (h->rows_added != expect) return fail("lmi_buckets_end: %lld of %lld rows were added", (long long)h->rows_added, (long long)expect);
     CHK(set_dev(h));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->pos.release();
@@ -446,6 +483,7 @@ static int record(lmi_index* h, int i) {
     // every recorded event is a ~6 us bubble between two kernels: level 1 keeps the call's first and last
     // event (LMI_T_TOTAL), level 0 none
     if (h->timing_level == 0 || (h->timing_level == 1 && i != 0 && i != 1 && i != 4)) return 0;
+    if (!h->ev[i]) HIPCHK(hipEventCreateWithFlags(&h->ev[i], hipEventDefault));
     HIPCHK(hipEventRecord(h->ev[i], h->stream));
     h->ev_valid[i] = true;
     return 0;
@@ -575,13 +613,12 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     const int L = h->L;
     const int nslots = nq * nb;
     const long long ncb_bound = (long long)nslots / 32 + L + 4;
-    // partial-list bound: every query visits nb distinct buckets -> at most the nb largest chunk counts
-    std::vector<int> nch_sorted(h->h_nch);
-    std::sort(nch_sorted.begin(), nch_sorted.end(), std::greater<int>());
-    long long per_query = 0;
-    for (int i = 0; i < std::min(nb, L); ++i) per_query += nch_sorted[i];
-    if (nb > L) per_query += (long long)(nb - L) * (nch_sorted.empty() ? 0 : nch_sorted[0]);
-    const long long part_lists = std::max<long long>(1, per_query * nq);
+    // partial-list bound (exact mode only; the prefilter path writes rank lists, not chunk partials): a row of
+    // bucket_order is caller data and may repeat a bucket, so a query owns at most nb x the largest chunk count
+    const bool fast = h->prefilter && h->have16;
+    int max_nch = 0;
+    for (int b = 0; b < L; ++b) max_nch = std::max(max_nch, h->h_nch[b]);
+    const long long part_lists = fast ? 1 : std::max<long long>(1, (long long)nb * max_nch * nq);
 
     CHK(h->m.reserve(L * 4));
     CHK(h->cb_start.reserve((L + 1) * 4));
@@ -617,7 +654,6 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     R.qt_base = R.order_tmp + L;
     R.tile_cb = (h->prefilter && h->have16) ? 4 * PF_NG : 4;
 
-    const bool fast = h->prefilter && h->have16;
     const size_t ncols = (size_t)ncb_bound * 32;
     int pf_parts = 4;
     FillRanges Z;
@@ -735,6 +771,12 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         HIPCHK(hipGetLastError());
         bound_merge_kernel<<<cdiv((long long)ncols, 256), 256, 0, h->stream>>>(F.bound, (long long)ncols, pf_parts, F.bound1);
         HIPCHK(hipGetLastError());
+        if (h->debug_emit_all) {  // test hook: bound = -inf, every row of the bucket is a candidate
+            FillRanges D;
+            D.count = 1; D.p[0] = reinterpret_cast<unsigned*>(F.bound1); D.n[0] = (long long)ncols; D.v[0] = 0xFF800000u;
+            fill_ranges_kernel<<<h->num_cus * 4, 256, 0, h->stream>>>(D);
+            HIPCHK(hipGetLastError());
+        }
         CHK(record(h, 5));
         prefilter_kernel<false, PF_NG><<<h->num_cus * PF_BLOCKS_PER_CU, 256 * PF_NG, 0, h->stream>>>(F);  // pass 2: candidates
         HIPCHK(hipGetLastError());
@@ -798,6 +840,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     CHK(record(h, 4));
     h->stats_pending = true;
     h->last_nslots = nslots;
+    h->last_nb = nb;
     h->last_fast = fast;
     return 0;
 }
@@ -805,6 +848,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
 static int check_scan_args(lmi_index* h, int nq, int nb, int k, int* kout) {
     if (!h->built) return fail("lmi_scan_topk: the bucket index is not built (lmi_buckets_begin/add_rows/end)");
     if (nq < 0 || nb < 1) return fail("lmi_scan_topk: bad nq/n_buckets");
+    if (nb > 1024) return fail("lmi_scan_topk: n_buckets %d exceeds 1024 (the rank merge keeps 16 four-bit cursors per lane)", nb);
     if (k < 1 || k > LMI_MAX_K) return fail("lmi_scan_topk: k %d outside [1,%d]", k, LMI_MAX_K);
     *kout = nb == 1 ? KPB : k;  // LearnedIndex.py:122-124: a single rank is returned unmerged
     if ((long long)nb * KPB < *kout) return fail("lmi_scan_topk: k %d exceeds n_buckets*10 candidates", k);
@@ -1035,6 +1079,40 @@ extern "C" LMI_API int lmi_prefilter_stats(lmi_index* h, int* active, int64_t* s
     if (active) *active = (h->prefilter && h->have16) ? 1 : 0;
     if (survivors) *survivors = (int64_t)acc[0];
     if (fallbacks) *fallbacks = (int64_t)acc[1];
+    return 0;
+}
+
+// ---- test hooks (tests/test_gpu_bound.py): the fp16 scores the pass-2 kernel really produced --------------
+extern "C" LMI_API int lmi_debug_emit_all(lmi_index* h, int on) {
+    if (!h) return fail("lmi_debug_emit_all: NULL handle");
+    h->debug_emit_all = on != 0;
+    return 0;
+}
+
+extern "C" LMI_API int lmi_debug_read_candidates(lmi_index* h, int64_t slot, int cap, uint32_t* rows, float* shat,
+                                         int* count, float* eps2, float* qscale, float* xscale) {
+    if (!h) return fail("lmi_debug_read_candidates: NULL handle");
+    if (!h->last_fast) return fail("lmi_debug_read_candidates: the last scan did not use the prefilter");
+    if (slot < 0 || slot >= h->last_nslots) return fail("lmi_debug_read_candidates: slot outside the last scan's %d", h->last_nslots);
+    CHK(set_dev(h));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    int col = -1;
+    HIPCHK(hipMemcpy(&col, h->slot_col.as<int>() + slot, 4, hipMemcpyDeviceToHost));
+    unsigned cnt = 0;
+    float e2 = 0.0f, qs = 1.0f, xs[2] = {1.0f, 1.0f};
+    if (col >= 0) {
+        HIPCHK(hipMemcpy(&cnt, h->cand_cnt.as<unsigned>() + col, 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&e2, h->eps2.as<float>() + col, 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&qs, h->qscale.as<float>() + slot / h->last_nb, 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(xs, h->xscale.p, 8, hipMemcpyDeviceToHost));
+        const unsigned n = std::min<unsigned>(std::min<unsigned>(cnt, (unsigned)PF_CAP), (unsigned)std::max(cap, 0));
+        if (n && rows) HIPCHK(hipMemcpy(rows, h->cand_row.as<unsigned>() + (size_t)col * PF_CAP, (size_t)n * 4, hipMemcpyDeviceToHost));
+        if (n && shat) HIPCHK(hipMemcpy(shat, h->cand_s.as<float>() + (size_t)col * PF_CAP, (size_t)n * 4, hipMemcpyDeviceToHost));
+    }
+    if (count) *count = col >= 0 ? (int)cnt : -1;
+    if (eps2) *eps2 = e2;
+    if (qscale) *qscale = qs;
+    if (xscale) *xscale = xs[0];
     return 0;
 }
 

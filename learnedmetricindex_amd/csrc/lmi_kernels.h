@@ -66,12 +66,15 @@ __global__ void pack_gather_kernel(const float* __restrict__ src, int d, const i
 }
 
 __global__ void pack_scatter_kernel(const float* __restrict__ src, int d, const int* __restrict__ pos,
-                                    long long row0, long long nrows, int KG, float4* __restrict__ dst) {
+                                    long long row0, const long long* __restrict__ index, long long n_total, long long nrows, int KG,
+                                    float4* __restrict__ dst) {
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nrows * KG) return;
     int g = (int)(idx % KG);
     long long i = idx / KG;
-    long long p = pos[row0 + i];
+    const long long o = index ? index[i] : row0 + i;
+    if (o < 0 || o >= n_total) return;
+    long long p = pos[o];
     if (p < 0) return;
     float v[8];
     load8(src + i * d, d, g * 8, v);
@@ -249,7 +252,10 @@ __global__ void softmax_ranked_kernel(const float* __restrict__ logits, const in
     for (int j = 1; j < L; ++j) m = l[j] > m ? l[j] : m;
     float s = 0.0f;
     for (int j = 0; j < L; ++j) s += lmi_expf(l[j] - m);
-    for (int t = 0; t < L; ++t) probs[(size_t)q * L + t] = lmi_expf(l[order[(size_t)q * L + t]] - m) / s;
+    for (int t = 0; t < L; ++t) {
+        const int cls = order[(size_t)q * L + t];  // -1: rank_classes_kernel ran out of comparable logits (NaN)
+        probs[(size_t)q * L + t] = cls >= 0 ? lmi_expf(l[cls] - m) / s : __builtin_nanf("");
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -46,12 +46,15 @@ constexpr int PF_KEEP = 64;         // survivors re-scored per slot; more -> exa
 //      re-ranking reads whole rows: 3 KiB contiguous instead of 192 scattered 16-B pieces of the
 //      fragment-major layout, which cost 4x the bytes in 64-B sectors) and the fp16 fragments ----
 __global__ void scatter_rows_kernel(const float* __restrict__ src, int d, const int* __restrict__ pos,
-                                    long long row0, long long nrows, float* __restrict__ dst) {
+                                    long long row0, const long long* __restrict__ index, long long n_total, long long nrows,
+                                    float* __restrict__ dst) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nrows * d) return;
     const long long i = idx / d;
     const int k = (int)(idx - i * d);
-    const long long p = pos[row0 + i];
+    const long long o = index ? index[i] : row0 + i;  // index: the objects' original row numbers (owned-only ingest)
+    if (o < 0 || o >= n_total) return;
+    const long long p = pos[o];
     if (p >= 0) dst[p * d + k] = src[idx];
 }
 
@@ -99,6 +102,11 @@ __global__ void convert16_kernel(const float* __restrict__ rows, int d, long lon
     dst[((size_t)(p >> 5) * KG16 + g) * 64 + hh * 32 + (p & 31)] = *reinterpret_cast<uint4*>(&h);
 }
 
+// Rounding-up factor of a binary32 norm: a sum of d non-negative squares accumulated in ANY order errs by at
+// most d 2^-24 relative, its square root by half that (+ one rounding); the factor covers twice the bound for
+// every d (a fixed 1.0002 only did up to d ~ 6 000).
+__device__ __forceinline__ float norm_guard(int d) { return 1.0001f + (float)d * 5.96046448e-8f; }
+
 // per-bucket max of the scaled row norm ||x'|| and of the norm of the row's fp16 rounding error
 // ||x^ - x'|| (x' = x * scale exactly, x^ = the _Float16 image convert16_kernel stores; the difference of
 // the two is exact in binary32), both rounded up (bits of non-negative floats order like ints)
@@ -108,6 +116,7 @@ __global__ void bucket_norm_kernel(const float* __restrict__ rows, int d, const 
     const int b = blockIdx.y;
     const int n_b = nb_rows[b];
     const float s = scale[0];
+    const float guard = norm_guard(d);
     float best = 0.0f, bestd = 0.0f;
     for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < n_b; row += gridDim.x * blockDim.x) {
         const float* x = rows + ((size_t)rb_start[b] * 32 + row) * d;
@@ -118,8 +127,8 @@ __global__ void bucket_norm_kernel(const float* __restrict__ rows, int d, const 
             acc += xs * xs;
             dl += e * e;
         }
-        best = fmaxf(best, sqrtf(acc) * 1.0002f);  // 1.0002: covers the binary32 error of the sum
-        bestd = fmaxf(bestd, sqrtf(dl) * 1.0002f);
+        best = fmaxf(best, sqrtf(acc) * guard);
+        bestd = fmaxf(bestd, sqrtf(dl) * guard);
     }
     if (best > 0.0f) atomicMax(bnorm_bits + b, __float_as_uint(best));
     if (bestd > 0.0f) atomicMax(bdelta_bits + b, __float_as_uint(bestd));
@@ -172,7 +181,7 @@ __global__ __launch_bounds__(256) void query_norm_kernel(const float* __restrict
     // One wave per query (coalesced 16-byte loads).  Every query gets its own power-of-two scale s
     // (max|q| * s in [0.5, 1): a slot's scores are only ever compared with scores of the same query), its
     // scaled norm ||q'|| and the norm of its fp16 rounding error ||q^ - q'|| (q^ - q' is exact in binary32);
-    // 1.0002 covers the binary32 error of the sums: both are upper bounds.
+    // norm_guard(d) covers the binary32 error of the sums: both are upper bounds.
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + wv;
     if (i >= nq) return;
@@ -208,8 +217,8 @@ __global__ __launch_bounds__(256) void query_norm_kernel(const float* __restrict
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { acc += __shfl_xor(acc, o); dl += __shfl_xor(dl, o); }
     if (lane == 0) {
-        qnorm[i] = sqrtf(acc) * 1.0002f;
-        qdelta[i] = sqrtf(dl) * 1.0002f;
+        qnorm[i] = sqrtf(acc) * norm_guard(d);
+        qdelta[i] = sqrtf(dl) * norm_guard(d);
         qscale[i] = s;
     }
 }

@@ -1,0 +1,188 @@
+"""GPU (`-m gpu`): BASELINE.json's configurations at their full sizes, against the CPU oracle.
+
+* C2 (configs[1], the headline): 10M x 768, 120 buckets, top-4, 10 000 queries on one MI355X.  The fp16-prefilter
+  mode and the all-f32 mode (two independently built indexes) must return bit-identical ids and distances
+  for the WHOLE batch, and 256 sampled queries are re-computed by the oracle (canonical fmaf chain over every
+  row of every visited bucket, bucket by bucket like LearnedIndex.py:107-146 / 350-371) and must match the
+  GPU's ids and distances exactly.
+* C4 (configs[3]): ONE 1/8 shard of 100M x 768, 1 024 buckets, top-8: the rank ingests the 100M labels, owns
+  128 buckets (12.5M rows, 57.6 GB resident as f32 rows + fp16 fragments) and passes only its own rows in
+  (lmi_buckets_add_owned_rows); L = 1 024 routing through the MLP kernels is checked against the oracle and
+  sampled queries' neighbours against the oracle on the buckets the rank owns; unowned slots are (inf, 0).
+The vectors are generated piecewise on the device and never exist as a whole on the host."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+D = 768
+
+
+def _need_hbm(gib):
+    if torch.cuda.get_device_properties(0).total_memory < gib * (1 << 30):
+        pytest.skip(f"needs ~{gib} GiB of HBM")
+
+
+def _oracle_check(oracle, idx, Qh, order_h, sel, nb, got_d, got_i, nthreads=16):
+    """Per-rank knn over each visited bucket (read back from HBM) + stable merge == the GPU's answer on `sel`."""
+    ns = sel.size
+    rank_d = np.full((nb, ns, 10), np.inf)
+    rank_i = np.zeros((nb, ns, 10), dtype=np.uint32)
+    sizes = idx.bucket_sizes()
+    for b in np.unique(order_h[sel]):
+        if b < 0 or sizes[b] == 0:
+            continue
+        rows, ids = idx.read_bucket(int(b))
+        for r in range(nb):
+            rel = np.flatnonzero(order_h[sel, r] == b)
+            if rel.size:
+                sim, loc = oracle.knn_ip(Qh[sel[rel]], rows, 10, nthreads=nthreads)
+                dd = np.float32(1) - sim                     # LearnedIndex.py:368
+                ii = ids[loc]                                # -1 -> last label (numpy indexing), SURVEY Q4
+                rank_d[r, rel], rank_i[r, rel] = dd, ii
+    fd = fi = None
+    for r in range(nb):
+        fd, fi = oracle.merge_rank(fd, fi, rank_d[r], rank_i[r], 10)
+    np.testing.assert_array_equal(got_i[sel], fi)
+    np.testing.assert_array_equal(got_d[sel].astype(np.float64), fd)
+
+
+def test_c2_full_size_modes_and_oracle(oracle):
+    from learnedmetricindex_amd import _capi
+
+    _need_hbm(150)
+    L, NB, n, nq, piece = 120, 4, 10_000_000, 10_000, 1 << 19
+    dev = torch.device("cuda", 0)
+    g0 = torch.Generator(device=dev).manual_seed(2023)
+    centres = torch.randn(L, D, generator=g0, device=dev)
+
+    def rows(p, count):
+        g = torch.Generator(device=dev).manual_seed(1000 + p)
+        a = torch.randint(0, L, (count,), generator=g, device=dev)
+        return a, torch.nn.functional.normalize(centres[a] + torch.randn(count, D, generator=g, device=dev), dim=1).contiguous()
+
+    pieces = [(p, min(piece, n - p * piece)) for p in range((n + piece - 1) // piece)]
+    labels = torch.cat([rows(p, c)[0] for p, c in pieces]).cpu().numpy().astype(np.int64)
+    gq = torch.Generator(device=dev).manual_seed(77)
+    Q = torch.nn.functional.normalize(centres[torch.randint(0, L, (nq,), generator=gq, device=dev)]
+                                      + torch.randn(nq, D, generator=gq, device=dev), dim=1).contiguous()
+    order = (Q @ centres.T).topk(NB, dim=1).indices.to(torch.int32).contiguous()
+    Qh, order_h = Q.cpu().numpy(), order.cpu().numpy()
+    sel = np.sort(np.random.RandomState(5).choice(nq, 256, replace=False))
+    out = []
+    for pf in (True, False):
+        idx = _capi.Index(0, prefilter=pf)
+        idx.set_stream(torch.cuda.current_stream().cuda_stream)
+        idx.buckets_begin(labels, D, L)
+        for p, c in pieces:
+            idx.add_rows(rows(p, c)[1], p * piece)
+            torch.cuda.synchronize()
+        idx.buckets_end()
+        d = torch.empty((nq, 10), dtype=torch.float32, device=dev)
+        i = torch.empty((nq, 10), dtype=torch.int32, device=dev)
+        idx.scan_topk_device(Q, order, NB, 10, d, i)
+        torch.cuda.synchronize()
+        dh, ih = d.cpu().numpy(), i.cpu().numpy().view(np.uint32)
+        if pf:
+            active, survivors, fallbacks = idx.prefilter_stats()
+            assert active and fallbacks == 0 and survivors >= 10 * nq * NB
+            _oracle_check(oracle, idx, Qh, order_h, sel, NB, dh, ih)   # the default mode against the oracle
+        out.append((dh, ih))
+        idx.close()
+        torch.cuda.empty_cache()
+    (d1, i1), (d0, i0) = out
+    np.testing.assert_array_equal(i1, i0)
+    np.testing.assert_array_equal(d1, d0)
+    assert np.all(np.diff(d1, axis=1) >= 0) and np.all(i1 > 0)
+
+
+def test_c4_one_eighth_shard(oracle):
+    from learnedmetricindex_amd import _capi
+    from learnedmetricindex_amd.sharded import assign_buckets
+
+    _need_hbm(120)
+    L, NB, n, nq, world, rank = 1024, 8, 100_000_000, 10_000, 8, 3
+    piece = 1 << 19
+    dev = torch.device("cuda", 0)
+    g0 = torch.Generator(device=dev).manual_seed(404)
+    centres = torch.randn(L, D, generator=g0, device=dev)
+    # labels of all 100M objects (uneven buckets: a Zipf-ish weighting), generated piecewise on the device
+    w = (1.0 / (1.0 + torch.arange(L, device=dev, dtype=torch.float32) / 200.0))
+    lab_parts = []
+    for p in range((n + (1 << 24) - 1) >> 24):
+        g = torch.Generator(device=dev).manual_seed(9000 + p)
+        cnt = min(1 << 24, n - (p << 24))
+        lab_parts.append(torch.multinomial(w, cnt, replacement=True, generator=g).to(torch.int32).cpu())
+    labels = torch.cat(lab_parts).numpy().astype(np.int64)
+    del lab_parts
+    sizes = np.bincount(labels, minlength=L)
+    owner = assign_buckets(sizes, world)
+    owned = (owner == rank).astype(np.uint8)
+    own_rows = np.flatnonzero(owned[labels].astype(bool)).astype(np.int64)   # ~12.5M original row numbers
+    assert 0.11 * n < own_rows.size < 0.14 * n
+
+    def vectors(index_t, p):
+        """rows of the objects index_t (a device int64 tensor): centre of their bucket + noise seeded per piece"""
+        g = torch.Generator(device=dev).manual_seed(5000 + p)
+        lab = torch.from_numpy(labels[index_t.cpu().numpy()]).to(dev)
+        return torch.nn.functional.normalize(centres[lab] + torch.randn(index_t.shape[0], D, generator=g, device=dev), dim=1).contiguous()
+
+    # random-weight MLP-4 768 -> 512 -> 1024 (L = 1 024 routing through the MLP kernels)
+    rs = np.random.RandomState(17)
+    layers = [((rs.randn(512, D) / np.sqrt(D)).astype(np.float32), (0.1 * rs.randn(512)).astype(np.float32)),
+              ((rs.randn(L, 512) / np.sqrt(512)).astype(np.float32), (0.1 * rs.randn(L)).astype(np.float32))]
+    idx = _capi.Index(0)
+    idx.set_stream(torch.cuda.current_stream().cuda_stream)
+    idx.set_mlp(layers)
+    idx.buckets_begin(labels, D, L, owned=owned)          # the 100M-label ingest
+    for p, r0 in enumerate(range(0, own_rows.size, piece)):
+        it = torch.from_numpy(own_rows[r0: r0 + piece]).to(dev)
+        idx.add_owned_rows(vectors(it, p), it)             # only the rank's own 12.5M rows travel
+        torch.cuda.synchronize()
+    idx.buckets_end()
+    np.testing.assert_array_equal(idx.bucket_sizes(), np.where(owned.astype(bool), sizes, 0))
+
+    gq = torch.Generator(device=dev).manual_seed(78)
+    Q = torch.nn.functional.normalize(centres[torch.randint(0, L, (nq,), generator=gq, device=dev)]
+                                      + torch.randn(nq, D, generator=gq, device=dev), dim=1).contiguous()
+    Qh = Q.cpu().numpy()
+    # (1) L = 1 024 routing: MLP + class ranking on the GPU == oracle, on a sample of the batch
+    bo_mlp = torch.empty((nq, NB), dtype=torch.int32, device=dev)
+    idx.mlp_topk_device(Q, NB, bo_mlp)
+    torch.cuda.synchronize()
+    selq = np.sort(np.random.RandomState(6).choice(nq, 512, replace=False))
+    np.testing.assert_array_equal(bo_mlp.cpu().numpy()[selq], oracle.precompute_bucket_order(layers, Qh[selq], NB, nthreads=16)[:, :, 0])
+    # (2) the scan at C4's shape: top-8 of 1 024 by centre similarity (what a trained index would route to)
+    order = (Q @ centres.T).topk(NB, dim=1).indices.to(torch.int32).contiguous()
+    order_h = order.cpu().numpy()
+    d = torch.empty((nq, 10), dtype=torch.float32, device=dev)
+    i = torch.empty((nq, 10), dtype=torch.int32, device=dev)
+    keys = torch.empty((nq, 10), dtype=torch.int32, device=dev)
+    idx.scan_topk_device(Q, order, NB, 10, d, i, keys)
+    torch.cuda.synchronize()
+    dh, ih = d.cpu().numpy(), i.cpu().numpy().view(np.uint32)
+    active, survivors, fallbacks = idx.prefilter_stats()
+    assert active and fallbacks == 0
+    visits_owned = owned[order_h].astype(bool)               # [nq, NB]
+    none = ~visits_owned.any(axis=1)
+    assert none.any() and np.all(np.isinf(dh[none])) and np.all(ih[none] == 0)   # slots of other ranks' buckets: (inf, 0)
+    # queries whose owned buckets are among the 6 most visited owned buckets (bounded read-back: ~6 x 300 MB)
+    hot = np.argsort(-np.bincount(order_h[visits_owned], minlength=L))[:6]
+    cand = np.flatnonzero((np.isin(order_h, hot) | ~visits_owned).all(axis=1) & visits_owned.any(axis=1))
+    sel = cand[:96]
+    assert sel.size >= 32
+    _oracle_check(oracle, idx, Qh, order_h, sel, NB, dh, ih)
+    # ingest check: a bucket read back == the regenerated rows of its objects, in ascending original order
+    b = int(hot[0])
+    rows_b, ids_b = idx.read_bucket(b)
+    expect_rows = np.flatnonzero(labels == b)
+    np.testing.assert_array_equal(ids_b, (expect_rows + 1).astype(np.uint32))
+    pos_in_own = np.searchsorted(own_rows, expect_rows[:50])
+    for r_, p_own in zip(range(50), pos_in_own):
+        pc, off = divmod(int(p_own), piece)
+        it = torch.from_numpy(own_rows[pc * piece: pc * piece + piece]).to(dev)
+        np.testing.assert_array_equal(vectors(it, pc)[off].cpu().numpy(), rows_b[r_])
+        if r_ >= 2:
+            break
+    idx.close()

@@ -11,6 +11,9 @@ import pytest
 from helpers import compare_modulo_near_ties, inputs_for, layers_from, load_golden
 
 ONE_LEVEL = ["G1", "G3", "G4", "G5", "G6"]
+# ids (of nq*k) where the canonical-chain result differs from the reference fixture; filled from a run of
+# this file (pytest -s prints them); a change of the oracle that moves a count fails the test
+GOLDEN_ID_DIFFS = {"G1": 0, "G3": 0, "G4": 0, "G5": 0, "G6": 0}
 
 
 @pytest.mark.parametrize("name", ONE_LEVEL)
@@ -35,7 +38,10 @@ def test_search_matches_reference(oracle, name):
     d, n, bo = oracle.search(layers_from(g), Qn, Xs, Qs, g["data_prediction"], nb, k, nthreads=4)
     assert d.dtype == np.float64 and n.dtype == np.uint32 and d.shape == n.shape == (Qs.shape[0], k)
     ndiff = compare_modulo_near_ties(g["ref_dists"], g["ref_nns"], d, n)
-    assert ndiff <= 0.002 * n.size
+    # how many returned ids differ from the reference run (all inside reference near-ties < 2e-6: its BLAS
+    # summation order vs the canonical chain); the counts are listed in DESIGN.md section 3
+    print(f"[golden] {name}: {ndiff} of {n.size} ids differ from the reference fixture (near-ties only)")
+    assert ndiff <= GOLDEN_ID_DIFFS[name], f"{name}: {ndiff} ids differ, {GOLDEN_ID_DIFFS[name]} recorded"
     # per-rank outputs of _search_single_bucket
     groups = oracle.group_buckets(g["data_prediction"])
     ids = np.arange(1, Xs.shape[0] + 1)

@@ -1,4 +1,4 @@
-"""CPU (`-m "not gpu"`): the N>1 path with world_size 2 over `gloo`.
+"""CPU (`-m "not gpu"`): the N>1 path with world_size 2, 4 and 8 over `gloo`.
 
 Covers the host logic of the bucket-sharded mode -- deterministic bucket assignment, the
 [dists|ids|keys] block packing, the ONE all-gather, the (dist, key) merge order -- and the identity
@@ -78,21 +78,21 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("name,nb,k", [("G1", 3, 10), ("G4", 4, 10), ("G4", 3, 15), ("G4", 1, 5)])
-def test_two_rank_result_identical_to_single(oracle, tmp_path, name, nb, k):
+@pytest.mark.parametrize("name,nb,k,world", [("G1", 3, 10, 2), ("G4", 4, 10, 2), ("G4", 3, 15, 2), ("G4", 1, 5, 2),
+                                              ("G1", 3, 10, 4), ("G4", 4, 10, 8), ("G4", 3, 15, 8)])
+def test_multi_rank_result_identical_to_single(oracle, tmp_path, name, nb, k, world):
     from helpers import inputs_for, layers_from, load_golden
 
-    world = 2
     mp.spawn(_worker, args=(world, _free_port(), name, nb, k, str(tmp_path)), nprocs=world, join=True)
     g = load_golden(name)
     Xn, Qn, Xs, Qs = inputs_for(name, g)
     do, io, boo = oracle.search(layers_from(g), Qn, Xs, Qs, g["data_prediction"], nb, k)
-    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
-    for r in (r0, r1):
+    ranks = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    for r in ranks:
         np.testing.assert_array_equal(r["bo"], boo[:, :, 0])          # gathered bucket order == unsharded routing
-    np.testing.assert_array_equal(r0["owner"], r1["owner"])          # same assignment on every rank
-    assert set(np.unique(r0["owner"])) == {0, 1}
-    for r in (r0, r1):
+        np.testing.assert_array_equal(r["owner"], ranks[0]["owner"])  # same assignment on every rank
+    assert set(np.unique(ranks[0]["owner"])) == set(range(world))    # every rank owns a bucket (L >= 12 >= world)
+    for r in ranks:
         np.testing.assert_array_equal(r["i"], io)
         np.testing.assert_array_equal(r["d"].astype(np.float64), do)
 
