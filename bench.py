@@ -1,17 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- queries/sec of the LearnedMetricIndex query hot path on MI355X.
 
-A "step" = one LearnedIndex.search of the whole query batch: MLP forward -> top-n_buckets ->
-routing -> bucket scan -> merge, inputs and outputs resident in HBM (the PCIe-inclusive figure is
-in DESIGN.md).  Default workload = BASELINE.json configs[1]: 10M x 768 synthetic unit-norm vectors
-(LAION-10M shape), 120 leaves, MLP-4 (768->512->120), top-4 buckets, 10k queries, 1 x MI355X.
+A "step" = one LearnedIndex.search of a whole query batch: MLP forward -> top-n_buckets -> routing -> bucket
+scan -> merge.  The timed region is HOST-IN -> HOST-OUT: every step takes its batch from
+pinned host memory and leaves (dists, ids) in pinned host memory; the upload of batch i+1 and the download of
+batch i-1 overlap the search of batch i (learnedmetricindex_amd/pipeline.py).  The index is resident in HBM
+before the timed region (it is built once, like the reference's DataFrames).  The device-resident step
+(inputs/outputs already in HBM) is reported beside it as `resident`.
+Default workload = BASELINE.json configs[1]: 10M x 768 synthetic unit-norm vectors (LAION-10M shape),
+120 leaves, MLP-4 (768->512->120), top-4 buckets, 10k queries, 1 x MI355X.
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: the index is bucket-sharded over the ranks, every rank answers the same batch on its own
-buckets and ONE RCCL all-gather + merge kernel produces the result (total work fixed: "strong").
-Rank 0 prints ONE JSON line (see the keys at the bottom).
+N > 1: the index is bucket-sharded over the ranks (each rank ingests only the rows it owns), every rank
+answers the same batch on its own buckets and an RCCL all-gather + merge kernel produces the result (total
+work fixed: "strong").  Rank 0 prints ONE JSON line (see the keys at the bottom).
 """
 import argparse
 import json
@@ -42,6 +46,303 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+class Workload:
+    """Synthetic data of SURVEY 8d (L Gaussian clusters, unit-norm rows, per-piece counter seeds on the device)
+    + the MLP trained on it + the HBM-resident index.  `sigma` is the cluster noise (1.0 = the survey's
+    generator), `zipf` > 0 draws the cluster of an object with probability ~ 1/(1 + c/zipf) (heavy-tailed
+    bucket sizes), `centre_scale` < 1 pulls the centres together (overlapping clusters)."""
+
+    def __init__(self, args, cfg, dev, rank, world, local_rank, sigma=1.0, zipf=0.0, centre_scale=1.0, tag="main"):
+        import torch
+        import torch.distributed as dist
+
+        from learnedmetricindex_amd import _capi
+        from learnedmetricindex_amd.li.model import NeuralNetwork, linear_layers
+        from learnedmetricindex_amd.sharded import assign_buckets, estimate_bucket_work
+
+        self.args, self.cfg, self.dev, self.rank, self.world, self.tag = args, cfg, dev, rank, world, tag
+        N, d, L, nb, nq = cfg["n"], cfg["d"], cfg["leaves"], cfg["nb"], cfg["nq"]
+        t_setup = time.time()
+        gcpu = torch.Generator().manual_seed(args.seed + (0 if tag == "main" else 7919))
+        centres = (torch.randn(L, d, generator=gcpu) * centre_scale).to(dev)
+        cdf = None
+        if zipf > 0:
+            w = 1.0 / (1.0 + torch.arange(L, dtype=torch.float64) / zipf)
+            cdf = (w / w.sum()).to(dev, torch.float32)
+
+        def gen_rows(tagno: int, piece: int, n: int):
+            g = torch.Generator(device=dev).manual_seed(args.seed * 1_000_003 + tagno * 100_003 + piece)
+            if cdf is None:
+                a = torch.randint(0, L, (n,), generator=g, device=dev)
+            else:
+                a = torch.multinomial(cdf, n, replacement=True, generator=g)
+            x = centres[a] + sigma * torch.randn(n, d, generator=g, device=dev)
+            return torch.nn.functional.normalize(x, dim=1).contiguous()
+
+        self.gen_rows = gen_rows
+        pieces = [(p, min(CHUNK, N - p * CHUNK)) for p in range((N + CHUNK - 1) // CHUNK)]
+        self.queries = gen_rows(7, 0, nq)  # fresh draws, not members of the set
+
+        # ---- MLP: k-means labels -> Adam/CE (the reference's hyper-parameters: 200 epochs, lr 0.01)
+        net = NeuralNetwork(input_dim=d, output_dim=L, lr=0.01, model_type=cfg["model"])
+        if rank == 0:
+            torch.manual_seed(args.seed)
+            ntr = min(args.train_rows, N)
+            xtr = torch.cat([gen_rows(1, p, n) for p, n in pieces[: (ntr + CHUNK - 1) // CHUNK]])[:ntr]
+            cent = xtr[torch.randperm(ntr, device=dev)[:L]].clone()
+            for _ in range(10):  # Lloyd iterations (faiss/sklearn k-means stand-in; offline build step)
+                lab = (xtr @ cent.T).argmax(1)
+                cent = torch.zeros_like(cent).index_add_(0, lab, xtr)
+                cent = torch.nn.functional.normalize(cent, dim=1)
+            lab = (xtr @ cent.T).argmax(1)
+            net.train(xtr, lab, epochs=args.epochs)
+            del xtr, lab, cent
+        if world > 1:
+            for p_ in net.model.parameters():
+                dist.broadcast(p_.data, src=0)
+        self.layers = linear_layers(net.model)
+
+        # ---- placement: argmax MLP(x) over all N (LearnedIndexBuilder.py:76) with the HIP MLP kernels
+        eng = _capi.Index(local_rank, chunk_rows=args.chunk_rows, prefilter=not args.exact)
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        eng.set_mlp(self.layers)
+        eng.set_timing(args.timing_level)
+        labels = torch.empty(N, dtype=torch.int32, device=dev)
+        for p, n in pieces:
+            eng.mlp_topk_device(gen_rows(1, p, n), 1, labels[p * CHUNK: p * CHUNK + n])
+        torch.cuda.synchronize()
+        labels_h = labels.cpu().numpy().astype(np.int64)
+        self.sizes = sizes = np.bincount(labels_h, minlength=L)
+        # Expected scan work of a bucket = its rows x the queries it will receive, the latter estimated at build
+        # time by routing a sample of the DATA through the MLP (every rank computes the same estimate).
+        work_w = estimate_bucket_work(eng, gen_rows(1, 0, pieces[0][1])[: min(20_000, N)], nb, sizes)
+        owner = assign_buckets(sizes, world, weights=work_w)
+        owned = (owner == rank).astype(np.uint8) if world > 1 else None
+        self.shard_world, self.owner_all = world, owner
+        if args.emulate_shard and tag == "main":
+            er, ew = (int(v) for v in args.emulate_shard.split("/"))
+            self.shard_world = ew
+            self.owner_all = assign_buckets(sizes, ew, weights=work_w)
+            owned = (self.owner_all == er).astype(np.uint8)
+            owner = np.where(self.owner_all == er, 0, -1)
+        self.owner = owner
+        eng.buckets_begin(labels_h, d, L, owned=owned)
+        if owned is None:
+            for p, n in pieces:
+                eng.add_rows(gen_rows(1, p, n), p * CHUNK)
+                torch.cuda.synchronize()
+        else:
+            # owned-only ingest: a rank passes in (a real deployment: reads) only the objects of its own buckets
+            own_mask = torch.from_numpy(owned.astype(bool)).to(dev)
+            for p, n in pieces:
+                keep = torch.nonzero(own_mask[labels[p * CHUNK: p * CHUNK + n].long()]).flatten()
+                if keep.numel():
+                    eng.add_owned_rows(gen_rows(1, p, n)[keep].contiguous(), (keep + p * CHUNK).contiguous())
+                torch.cuda.synchronize()
+        eng.buckets_end()
+        del labels
+        torch.cuda.empty_cache()
+        self.eng = eng
+        if rank == 0:
+            log(f"[bench:{tag}] index built in {time.time() - t_setup:.1f}s: N={N} d={d} L={L} bucket sizes "
+                f"min/median/max = {sizes.min()}/{int(np.median(sizes))}/{sizes.max()}, empty={int((sizes == 0).sum())}")
+
+    # ------------------------------------------------------------------------------------------------
+    def run(self, steps, warmup, shard_inference=True, measure_resident=True):
+        """Times `steps` host-in -> host-out searches (pipelined) and, optionally, as many device-resident ones.
+        Returns a dict of raw measurements."""
+        import torch
+        import torch.distributed as dist
+
+        from learnedmetricindex_amd.pipeline import HostPipeline
+        from learnedmetricindex_amd.sharded import ShardedSearcher
+
+        eng, world, rank, dev = self.eng, self.world, self.rank, self.dev
+        nb, nq, d, k = self.cfg["nb"], self.cfg["nq"], self.cfg["d"], self.args.k
+        searcher = ShardedSearcher(eng, rank, world, shard_inference=shard_inference)
+
+        def sync_all():
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+                torch.cuda.synchronize()
+
+        q_host = self.queries.cpu().pin_memory()  # the batch as it arrives: host memory (pinned, DMA-able)
+        pipe = HostPipeline(eng, nq, d, d, nb, k, depth=int(os.environ.get("LMI_PIPE_DEPTH", "2")), same_queries=True, want_bucket_order=True,
+                            search_fn=(lambda qn, qs: searcher.search(qn, qs, nb, k)) if world > 1 else None)
+        for _ in range(warmup):
+            pipe.submit(q_host)
+        pipe.drain()
+        sync_all()
+        eng.timings_reset()
+        stamps = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ticket = pipe.submit(q_host)
+            stamps.append(time.perf_counter() - t0)
+        pipe.drain()
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        if os.environ.get("LMI_BENCH_DEBUG") and rank == 0:
+            log(f"[bench:{self.tag}] submit returned at (ms): {[round(v * 1e3, 2) for v in stamps]}; end {elapsed * 1e3:.2f}")
+        # hipEvents recorded on the kernels' own stream around every phase of every step; read once, after the
+        # timed region (the handle keeps the newest 128 sets), so the loop itself has no host synchronisation
+        phases, n_timed = eng.timings_mean()
+        phases = phases * searcher.calls_per_search
+        out_d, out_i = (a.copy() for a in pipe.result(ticket))
+        bo = pipe.bucket_order(ticket).copy()
+        tm = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        res = dict(elapsed=float(tm.item()), phases=phases, n_timed=int(n_timed) // searcher.calls_per_search,
+                   out_d=out_d, out_i=out_i, bo=bo, calls=searcher.calls_per_search)
+        if measure_resident:
+            eng.set_stream(torch.cuda.current_stream().cuda_stream)
+            q = self.queries
+            for _ in range(max(1, warmup)):
+                searcher.search(q, q, nb, k)
+            sync_all()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                rd, ri, _ = searcher.search(q, q, nb, k)
+            sync_all()
+            tr = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+            res["resident_elapsed"] = float(tr.item())
+            assert np.array_equal(ri.cpu().numpy().view(np.uint32), out_i), "resident and host-boundary results differ"
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        res["scan_stats"] = eng.scan_stats()
+        res["pf_stats"] = eng.prefilter_stats()
+        return res
+
+    def recall(self, out_i, nr):
+        import torch
+
+        from learnedmetricindex_amd.sharded import ShardedSearcher
+
+        L, k = self.cfg["leaves"], self.args.k
+        q = self.queries[:nr].contiguous()
+        _, gt_i, _ = ShardedSearcher(self.eng, self.rank, self.world).search(q, q, L, k)
+        gt = gt_i.cpu().numpy().astype(np.int64)
+        got = out_i[:nr].astype(np.int64)
+        return float(np.mean([len(set(a) & set(b)) / float(k) for a, b in zip(got, gt)]))
+
+
+def cpu_baselines(wl, res, args):
+    """rank 0, N = 1: the CPU restatements timed on this box's host cores, on the same index and queries."""
+    import torch
+
+    from oracle import cpu_baseline as cb
+    from oracle import lmi_oracle
+
+    eng, layers = wl.eng, wl.layers
+    N, d, L, nb, nq, k = wl.cfg["n"], wl.cfg["d"], wl.cfg["leaves"], wl.cfg["nb"], wl.cfg["nq"], args.k
+    host_cores = os.cpu_count() or 1
+    nthr = args.cpu_threads or min(16, host_cores)  # the GPU box's CPU share for one GPU is 16 cores
+    out_d, out_i, bo = res["out_d"], res["out_i"], res["bo"]
+    variants = {}
+
+    # ---- (0) the bit-exact checker: oracle/lmi_oracle.c on a query sample (canonical fmaf chains; slow by design)
+    ns = min(args.cpu_queries, nq)
+    qh_all = wl.queries.cpu().numpy()
+    qh = qh_all[:ns]
+    t_cpu = time.perf_counter()
+    order_o = lmi_oracle.precompute_bucket_order(layers, qh, nb, nthreads=nthr)
+    t_cpu = time.perf_counter() - t_cpu
+    assert np.array_equal(order_o[:, :, 0], bo[:ns]), "oracle bucket order differs from the GPU's"
+    # host copy of the index in bucket order (not timed: the reference's frames are resident before search too)
+    sizes = eng.bucket_sizes()
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    slab = torch.empty((int(offsets[-1]), d), dtype=torch.float32)
+    slab_np = slab.numpy()
+    ids_all = np.empty(int(offsets[-1]), dtype=np.uint32)
+    t_copy = time.perf_counter()
+    for b in range(L):
+        if sizes[b]:
+            eng.read_bucket(b, rows_out=slab_np[offsets[b]: offsets[b + 1]], ids_out=ids_all[offsets[b]: offsets[b + 1]])
+    t_copy = time.perf_counter() - t_copy
+    rank_d = np.full((nb, ns, 10), np.inf)
+    rank_i = np.zeros((nb, ns, 10), dtype=np.uint32)
+    for b in np.unique(order_o[:, :, 0]):
+        if sizes[b] == 0:
+            continue
+        rows, ids = slab_np[offsets[b]: offsets[b + 1]], ids_all[offsets[b]: offsets[b + 1]]
+        t1 = time.perf_counter()
+        for r in range(nb):
+            rel = np.flatnonzero(order_o[:, r, 0] == b)
+            if rel.size:
+                sim, idx = lmi_oracle.knn_ip(qh[rel], rows, 10, nthreads=nthr)
+                rank_d[r, rel] = np.float32(1) - sim
+                rank_i[r, rel] = ids[idx]
+        t_cpu += time.perf_counter() - t1
+    t1 = time.perf_counter()
+    fd = fi = None
+    for r in range(nb):
+        fd, fi = lmi_oracle.merge_rank(fd, fi, rank_d[r], rank_i[r], k)
+    t_cpu += time.perf_counter() - t1
+    assert np.array_equal(fi, out_i[:ns]) and np.array_equal(fd, out_d[:ns].astype(np.float64)), \
+        "CPU oracle and GPU results differ on the sampled queries"
+    variants["oracle_checker"] = {"value": round(ns / t_cpu, 3), "unit": "queries/s", "cores": nthr, "queries": ns,
+                                  "what": "oracle/lmi_oracle.c: canonical k-ordered fmaf chains (bit-exact with the GPU, "
+                                          "asserted); a checker, not a tuned CPU implementation"}
+
+    # ---- (1) best-effort CPU: bucket-contiguous slab + torch-CPU matmul/topk, all ranks of a bucket in one product
+    nq_b = min(args.cpu_best_queries, nq)
+    qt = torch.from_numpy(qh_all[:nq_b])
+    bd, bi, border, secs = cb.best_effort(slab, offsets, ids_all, layers, qt, nb, k, threads=nthr)
+    variants["best_effort_torch"] = {
+        "value": round(nq_b / secs, 2), "unit": "queries/s", "cores": nthr, "queries": nq_b, "seconds": round(secs, 3),
+        "id_set_agreement_with_gpu": round(cb.id_agreement(bi, out_i[:nq_b]), 6),
+        "what": "bucket-contiguous slab in host memory, torch-CPU addmm/relu/topk routing, per visited bucket ONE "
+                "matmul for all its (query, rank) slots + topk(10), stable sort merge; full index, no pandas"}
+
+    # ---- (2) reference-structured: pandas groupby + .loc gather + BLAS + partial sort, per rank x bucket.
+    # Its cost is linear in the rows it touches (SURVEY 8a: 75 % is pandas data movement) and the whole 10M-row
+    # batch takes minutes on a CPU (reference README: 220 s), so it runs on a BOUNDED sample: `--cpu-ref-buckets`
+    # whole buckets at their full size (all ranks, real routing of the first `--cpu-ref-queries` queries), and
+    # the batch rate is the measured time scaled by rows(all buckets) / rows(sampled buckets).
+    import pandas as pd
+    from threadpoolctl import threadpool_limits
+
+    nq_r = min(args.cpu_ref_queries, nq)
+    order_r = bo[:nq_r]
+    visited = np.bincount(order_r.ravel(), minlength=L)
+    cand = np.flatnonzero((sizes > 0) & (visited > 0))
+    pick = np.sort(np.random.RandomState(args.seed).choice(cand, size=min(args.cpu_ref_buckets, cand.size), replace=False))
+    rows_s = np.concatenate([slab_np[offsets[b]: offsets[b + 1]] for b in pick])
+    labels_s = np.concatenate([ids_all[offsets[b]: offsets[b + 1]] for b in pick]).astype(np.int64)
+    dp_s = np.concatenate([np.full(int(sizes[b]), b, dtype=np.int64) for b in pick])
+    scale = float(offsets[-1]) / float(rows_s.shape[0])
+    for name, thr in (("reference_structured_1core", 1), ("reference_structured_allcores", nthr)):
+        nav = pd.DataFrame(rows_s, index=labels_s, copy=False)
+        srch = pd.DataFrame(rows_s, index=labels_s, copy=False)   # a distinct frame object (SURVEY Q1)
+        torch.set_num_threads(thr)
+        with threadpool_limits(limits=thr):
+            t1 = time.perf_counter()
+            t_mlp = time.perf_counter()
+            cb.mlp_order_numpy(layers, qh_all[:nq_r], nb)
+            t_mlp = time.perf_counter() - t_mlp
+            rd, rn, parts = cb.reference_structured(nav, srch, qh_all[:nq_r], order_r, dp_s, k)
+            t_meas = time.perf_counter() - t1
+        est = t_mlp + (t_meas - t_mlp) * scale
+        variants[name] = {
+            "value": round(nq_r / est, 3), "unit": "queries/s", "cores": thr, "queries": nq_r, "estimated": True,
+            "measured_seconds": round(t_meas, 3), "sampled_buckets": int(pick.size), "sampled_rows": int(rows_s.shape[0]),
+            "scale_rows_total_over_sampled": round(scale, 3),
+            "seconds_by_part": {kk: round(v, 3) for kk, v in parts.items()},
+            "what": "the reference's loop (LearnedIndex.py:101-157, 328-373): per rank groupby materialising every "
+                    "group, label-based .loc gather copy of each visited bucket, BLAS sgemm + partial sort (faiss.knn "
+                    "stand-in), 1 - sim, stable merge; measured on whole sampled buckets, scaled by rows to the full index"}
+    best = variants["best_effort_torch"]
+    return {"value": best["value"], "unit": "queries/s", "cores": nthr, "kind": "port",
+            "sample": f"value = best-effort CPU variant: all {N} x {d} rows resident in host memory, first {nq_b} of {nq} queries, "
+                      f"all {nb} ranks, {nthr} threads (torch-CPU matmul + topk over the bucket-contiguous slab); "
+                      f"`variants` holds the reference-structured pandas/BLAS loop on 1 core and on {nthr} cores "
+                      f"(bounded bucket sample, scaled) and the bit-exact oracle used as the checker",
+            "host_cpu_count": host_cores, "index_copy_to_host_s": round(t_copy, 2), "variants": variants}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,10 +358,17 @@ def main():
     ap.add_argument("--train-rows", type=int, default=200_000)
     ap.add_argument("--epochs", type=int, default=200)
     ap.add_argument("--recall-queries", type=int, default=1000)
-    ap.add_argument("--cpu-queries", type=int, default=256)
-    ap.add_argument("--cpu-threads", type=int, default=0, help="oracle threads (0: min(16, host cores))")
+    ap.add_argument("--cpu-queries", type=int, default=256, help="queries re-computed by the bit-exact oracle (the checker)")
+    ap.add_argument("--cpu-best-queries", type=int, default=10_000, help="queries of the best-effort torch-CPU baseline")
+    ap.add_argument("--cpu-ref-queries", type=int, default=10_000, help="queries of the reference-structured pandas baseline")
+    ap.add_argument("--cpu-ref-buckets", type=int, default=6, help="whole buckets the reference-structured baseline is measured on")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="CPU baseline threads (0: min(16, host cores))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
+    ap.add_argument("--no-hard-leg", action="store_true", help="skip the second, harder workload (overlapping clusters)")
+    ap.add_argument("--hard-sigma", type=float, default=1.0)
+    ap.add_argument("--hard-centre-scale", type=float, default=0.26)
+    ap.add_argument("--hard-zipf", type=float, default=20.0)
     ap.add_argument("--chunk-rows", type=int, default=None)
     ap.add_argument("--timing-level", type=int, default=2, choices=(0, 1, 2),
                     help="lmi_set_timing: 2 (default) times every phase with hipEvents -- the roofline needs the dominant "
@@ -100,193 +408,64 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-
-    from learnedmetricindex_amd import _capi
-    from learnedmetricindex_amd.li.model import NeuralNetwork, linear_layers
-    from learnedmetricindex_amd.sharded import ShardedSearcher, assign_buckets, estimate_bucket_work
-
-    t_setup = time.time()
-    # ------------------------------------------------------------------ synthetic data
-    gcpu = torch.Generator().manual_seed(args.seed)
-    centres = torch.randn(L, d, generator=gcpu).to(dev)
-
-    def gen_rows(tag: int, piece: int, n: int):
-        g = torch.Generator(device=dev).manual_seed(args.seed * 1_000_003 + tag * 100_003 + piece)
-        a = torch.randint(0, L, (n,), generator=g, device=dev)
-        x = centres[a] + torch.randn(n, d, generator=g, device=dev)
-        return torch.nn.functional.normalize(x, dim=1).contiguous()
-
-    pieces = [(p, min(CHUNK, N - p * CHUNK)) for p in range((N + CHUNK - 1) // CHUNK)]
-    queries = gen_rows(7, 0, nq)  # fresh draws, not members of the set
-
-    # ------------------------------------------------------------------ MLP: k-means labels -> Adam/CE
-    net = NeuralNetwork(input_dim=d, output_dim=L, lr=0.01, model_type=cfg["model"])
-    if rank == 0:
-        torch.manual_seed(args.seed)
-        ntr = min(args.train_rows, N)
-        xtr = torch.cat([gen_rows(1, p, n) for p, n in pieces[: (ntr + CHUNK - 1) // CHUNK]])[:ntr]
-        cent = xtr[torch.randperm(ntr, device=dev)[:L]].clone()
-        for _ in range(10):  # Lloyd iterations (faiss/sklearn k-means stand-in; offline build step)
-            lab = (xtr @ cent.T).argmax(1)
-            cent = torch.zeros_like(cent).index_add_(0, lab, xtr)
-            cent = torch.nn.functional.normalize(cent, dim=1)
-        lab = (xtr @ cent.T).argmax(1)
-        net.train(xtr, lab, epochs=args.epochs)
-        del xtr, lab, cent
-    if world > 1:
-        for p_ in net.model.parameters():
-            dist.broadcast(p_.data, src=0)
-    layers = linear_layers(net.model)
-
-    # ------------------------------------------------------------------ placement: argmax MLP(x) over all N
-    eng = _capi.Index(local_rank, chunk_rows=args.chunk_rows, prefilter=not args.exact)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
-    eng.set_mlp(layers)
-    eng.set_timing(args.timing_level)
-    labels = torch.empty(N, dtype=torch.int32, device=dev)
-    for p, n in pieces:
-        x = gen_rows(1, p, n)
-        eng.mlp_topk_device(x, 1, labels[p * CHUNK: p * CHUNK + n])
-    torch.cuda.synchronize()
-    labels_h = labels.cpu().numpy().astype(np.int64)
-    sizes = np.bincount(labels_h, minlength=L)
-    # Expected scan work of a bucket = its rows x the queries it will receive.  The second factor is estimated
-    # at build time by routing a sample of the DATA through the MLP (top-nb, like a query): every rank computes
-    # the same estimate, no knowledge of the query batch is used.
-    work_w = estimate_bucket_work(eng, gen_rows(1, 0, pieces[0][1])[: min(20_000, N)], nb, sizes)
-    owner = assign_buckets(sizes, world, weights=work_w)
-    owned = (owner == rank).astype(np.uint8) if world > 1 else None
-    shard_world = world
     if args.emulate_shard:
         assert world == 1, "--emulate-shard is a single-GPU diagnostic"
-        er, ew = (int(v) for v in args.emulate_shard.split("/"))
-        shard_world = ew
-        owner = assign_buckets(sizes, ew, weights=work_w)
-        owner_all = owner.copy()
-        owned = (owner == er).astype(np.uint8)
-        owner = np.where(owner == er, 0, -1)
-        args.no_cpu_baseline = args.no_recall = True
-    eng.buckets_begin(labels_h, d, L, owned=owned)
-    for p, n in pieces:
-        eng.add_rows(gen_rows(1, p, n), p * CHUNK)
-        torch.cuda.synchronize()
-    eng.buckets_end()
-    del labels
-    torch.cuda.empty_cache()
-    if rank == 0:
-        log(f"[bench] index built in {time.time() - t_setup:.1f}s: N={N} d={d} L={L} bucket sizes "
-            f"min/median/max = {sizes.min()}/{int(np.median(sizes))}/{sizes.max()}, empty={int((sizes == 0).sum())}")
+        args.no_cpu_baseline = args.no_recall = args.no_hard_leg = True
 
-    # ------------------------------------------------------------------ the timed region
-    searcher = ShardedSearcher(eng, rank, world)
+    from learnedmetricindex_amd import _capi
 
-    def step():
-        return searcher.search(queries, queries, nb, k)
-
-    def sync_all():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    sync_all()
+    wl = Workload(args, cfg, dev, rank, world, local_rank)
+    res = wl.run(args.steps, args.warmup, shard_inference=True)
+    elapsed, phases, out_d, out_i, bo = res["elapsed"], res["phases"], res["out_d"], res["out_i"], res["bo"]
+    flops, pairs, items = res["scan_stats"]
+    pf_active, pf_survivors, pf_fallbacks = res["pf_stats"]
     dom_slot = _capi.T_SCAN if args.exact else _capi.T_PF_EMIT
-    eng.timings_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out_d, out_i, bo = step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    # hipEvents recorded on the kernels' own stream around every phase of every step; read once, after the
-    # timed region (the handle keeps the newest 128 sets), so the loop itself has no host synchronisation
-    phases, n_timed = eng.timings_mean()
-    phases = phases * searcher.calls_per_search  # a search with sharded inference is two C-ABI calls (MLP slice, scan)
-    tm = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-    elapsed = float(tm.item())
-    flops, pairs, items = eng.scan_stats()
-    if rank == 0 and shard_world > 1:  # how even the bucket assignment turned out for this batch
-        own = owner_all if args.emulate_shard else owner
-        bo_h = bo.cpu().numpy().ravel()
+    sizes, owner = wl.sizes, wl.owner
+    if rank == 0 and wl.shard_world > 1:  # how even the bucket assignment turned out for this batch
+        bo_h = bo.ravel()
         bo_h = bo_h[(bo_h >= 0) & (bo_h < L)]
-        per_rank = np.bincount(own[bo_h], weights=sizes[bo_h].astype(np.float64), minlength=shard_world)
+        per_rank = np.bincount(wl.owner_all[bo_h], weights=sizes[bo_h].astype(np.float64), minlength=wl.shard_world)
         log(f"[bench] scan work per rank (pairs, share of the mean): {np.round(per_rank / per_rank.mean(), 3).tolist()}")
-    pf_active, pf_survivors, pf_fallbacks = eng.prefilter_stats()
-    # ------------------------------------------------------------------ recall@10 vs exact brute force
-    recall = None
-    if not args.no_recall:
-        nr = min(args.recall_queries, nq)
-        gt_d, gt_i, _ = ShardedSearcher(eng, rank, world).search(queries[:nr].contiguous(), queries[:nr].contiguous(), L, k)
-        got = out_i[:nr].cpu().numpy().astype(np.int64)
-        gt = gt_i.cpu().numpy().astype(np.int64)
-        recall = float(np.mean([len(set(a) & set(b)) / float(k) for a, b in zip(got, gt)]))
+    # N > 1: the other collective layout (every rank routes the whole batch: ONE all-gather, as north_star words it)
+    alt = None
+    if world > 1:
+        r2 = wl.run(args.steps, args.warmup, shard_inference=False, measure_resident=False)
+        assert np.array_equal(r2["out_i"], out_i), "the two sharded modes disagree"
+        alt = {"mode": "replicated MLP on every rank, ONE all-gather (per-rank top-k)",
+               "value": round(nq * args.steps / r2["elapsed"], 2), "ms_per_step": round(r2["elapsed"] / args.steps * 1e3, 4)}
+    recall = None if args.no_recall else wl.recall(out_i, min(args.recall_queries, nq))
 
-    # ------------------------------------------------------------------ host boundary (PCIe inclusive), N=1
-    # host numpy in -> host numpy out through the C ABI with host pointers (pageable memory): reported
-    # beside the bench line, never as `value`
-    host_boundary = None
-    if rank == 0 and world == 1 and not args.emulate_shard:
-        qh_all = queries.cpu().numpy()
-        eng.search(qh_all, qh_all, nb, k)
-        t_h = time.perf_counter()
-        for _ in range(3):
-            hd, hi, _hb = eng.search(qh_all, qh_all, nb, k)
-        t_h = (time.perf_counter() - t_h) / 3
-        assert np.array_equal(hi.view(np.int32), out_i.cpu().numpy().view(np.int32)), "host-pointer path differs"
-        host_boundary = {"value": round(nq / t_h, 1), "unit": "queries/s", "ms_per_batch": round(t_h * 1e3, 3),
-                         "what": "lmi_search with host pointers: pageable query upload + search + result download"}
-
-    # ------------------------------------------------------------------ CPU baseline (oracle), rank 0, N=1
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import lmi_oracle
+        cpu = cpu_baselines(wl, res, args)
 
-        ns = min(args.cpu_queries, nq)
-        nthr = args.cpu_threads or min(16, os.cpu_count() or 1)
-        qh = queries[:ns].cpu().numpy()
-        t_cpu = time.perf_counter()
-        order_o = lmi_oracle.precompute_bucket_order(layers, qh, nb, nthreads=nthr)
-        t_cpu = time.perf_counter() - t_cpu
-        assert np.array_equal(order_o[:, :, 0], bo[:ns].cpu().numpy()), "oracle bucket order differs from the GPU's"
-        # reference structure (LearnedIndex.py:107-146, 350-371): for every visited bucket, per rank,
-        # knn over the bucket + 1 - sim + id mapping, then the stable merge; only that work is timed,
-        # not the device->host copy of the bucket.
-        rank_d = np.full((nb, ns, 10), np.inf)
-        rank_i = np.zeros((nb, ns, 10), dtype=np.uint32)
-        for b in np.unique(order_o[:, :, 0]):
-            rows, ids = eng.read_bucket(int(b))
-            if rows.shape[0] == 0:
-                continue
-            t1 = time.perf_counter()
-            for r in range(nb):
-                rel = np.flatnonzero(order_o[:, r, 0] == b)
-                if rel.size:
-                    sim, idx = lmi_oracle.knn_ip(qh[rel], rows, 10, nthreads=nthr)
-                    rank_d[r, rel] = np.float32(1) - sim
-                    rank_i[r, rel] = ids[idx]
-            t_cpu += time.perf_counter() - t1
-        t1 = time.perf_counter()
-        fd = fi = None
-        for r in range(nb):
-            fd, fi = lmi_oracle.merge_rank(fd, fi, rank_d[r], rank_i[r], k)
-        t_cpu += time.perf_counter() - t1
-        same = bool(np.array_equal(fi, out_i[:ns].cpu().numpy().view(np.uint32)) and
-                    np.array_equal(fd, out_d[:ns].cpu().numpy().astype(np.float64)))
-        assert same, "CPU oracle and GPU results differ on the sampled queries"
-        cpu = {"value": round(ns / t_cpu, 3), "unit": "queries/s", "cores": nthr, "kind": "port",
-               "sample": f"first {ns} of {nq} queries, all {nb} ranks, full {N}x{d} index, bucket by bucket like "
-                         f"LearnedIndex.py:107-146/350-371; oracle/lmi_oracle.c (canonical fmaf chain, OpenMP over "
-                         f"the bucket's rows, {nthr} threads); device->host copies of the buckets not timed; "
-                         f"ids and distances identical to the GPU's"}
+    # ---- second leg: a HARDER workload (overlapping clusters, heavy-tailed bucket sizes): what the prefilter's
+    # candidate logic and the throughput look like when recall@10 at top-4 is ~0.9 as on LAION (README.md:54-57)
+    hard = None
+    if world == 1 and not args.no_hard_leg and args.config == "c2" and not args.exact:
+        wl.eng.close()
+        del wl.eng
+        torch.cuda.empty_cache()
+        wh = Workload(args, cfg, dev, rank, world, local_rank, sigma=args.hard_sigma, zipf=args.hard_zipf,
+                      centre_scale=args.hard_centre_scale, tag="hard")
+        rh = wh.run(max(5, args.steps // 2), 2, measure_resident=True)
+        hs = wh.sizes
+        hard = {"generator": f"centres x{args.hard_centre_scale}, sigma {args.hard_sigma}, cluster weights ~ 1/(1 + c/{args.hard_zipf})",
+                "recall_at_10": round(wh.recall(rh["out_i"], min(args.recall_queries, nq)), 5),
+                "value": round(nq * max(5, args.steps // 2) / rh["elapsed"], 2), "unit": "queries/s",
+                "ms_per_step": round(rh["elapsed"] / max(5, args.steps // 2) * 1e3, 4),
+                "resident_ms_per_step": round(rh["resident_elapsed"] / max(5, args.steps // 2) * 1e3, 4),
+                "bucket_sizes_min_median_max": [int(hs.min()), int(np.median(hs)), int(hs.max())],
+                "survivors_per_slot": round(rh["pf_stats"][1] / max(1, nq * nb), 2), "fallback_slots": int(rh["pf_stats"][2]),
+                "scan_pairs": int(rh["scan_stats"][1]),
+                "phases_ms": {"pf_sample": round(float(rh["phases"][5]), 4), "pf_emit": round(float(rh["phases"][6]), 4),
+                              "rescore": round(float(rh["phases"][7]), 4), "fallback": round(float(rh["phases"][8]), 4)}}
 
     if rank == 0:
         scan_s = float(phases[_capi.T_SCAN]) * 1e-3
         dom_s = max(float(phases[dom_slot]) * 1e-3, 1e-12)  # 0 when --timing-level < 2: the roofline fields are meaningless then
         scan_s = max(scan_s, 1e-12)
-        visited = np.unique(bo.cpu().numpy())
+        visited = np.unique(bo)
         visited = visited[(visited >= 0) & (owner[np.clip(visited, 0, L - 1)] == rank)]
         rows_visited = float(sizes[visited].sum())
         # Dominant kernel and its roofline.  Algorithmic work per launch: flops = 2*d*sum over (query, rank)
@@ -304,19 +483,26 @@ def main():
         else:
             roof = {"bound": "hbm", "achieved": round(alg_bytes / dom_s / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(alg_bytes / dom_s / 1e9 / PEAK_HBM_GBS, 4)}
-        traffic = None
+        traffic = mfma_busy = None
         tj = args.traffic_json or os.path.join(ROOT, "profiles", f"scan_pmc_{args.config}{'_exact' if args.exact else ''}.json")
         overridden = any(getattr(args, key) is not None for key in ("n", "nq", "nb", "leaves", "emulate_shard"))
         if world == 1 and not overridden and os.path.exists(tj):
-            traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
+            pj = json.load(open(tj))
+            traffic, mfma_busy = pj.get("hbm_bytes_per_launch"), pj.get("mfma_pipe_busy_frac")
         roof.update({"traffic": traffic, "kernel": kernel, "flops_per_launch": flops, "bytes_per_launch": alg_bytes,
-                     "avg_launch_ms": round(dom_s * 1e3, 4), "launches_timed": int(n_timed) // searcher.calls_per_search,
+                     "avg_launch_ms": round(dom_s * 1e3, 4), "launches_timed": res["n_timed"],
+                     "mfma_pipe_busy_frac": mfma_busy,
                      "floors_ms": {"mfma": round(t_mfma * 1e3, 3), "hbm": round(t_hbm * 1e3, 3)},
                      # the whole scan phase (all its kernels) priced as SURVEY 8d does: algorithmic f32 flops
                      # against the f32 MFMA peak, whatever precision the prefilter used
                      "scan_phase_f32_equiv": {"achieved": round(flops / scan_s / 1e12, 3), "peak": PEAK_F32_MFMA_TFLOPS,
                                               "unit": "TFLOP/s", "frac": round(flops / scan_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                                               "avg_ms": round(scan_s * 1e3, 4)}})
+        resident = None
+        if "resident_elapsed" in res:
+            resident = {"value": round(nq * args.steps / res["resident_elapsed"], 2), "unit": "queries/s",
+                        "ms_per_step": round(res["resident_elapsed"] / args.steps * 1e3, 4),
+                        "what": "the same step with the query batch and the results already/left in HBM (no PCIe)"}
         result = {
             "metric": "queries/sec @ recall@10, 768-d 10M index, 10k query batch",
             "value": round(nq * args.steps / elapsed, 2),
@@ -330,19 +516,23 @@ def main():
             "vs_baseline": None,
             "dtype": "f32" if args.exact else "f16 prefilter (f32 accumulate) + f32 exact re-rank; outputs identical to the all-f32 path",
             "data": "synthetic",
+            "boundary": "host-in -> host-out: every step uploads its query batch from pinned host memory and downloads "
+                        "(dists, ids) to pinned host memory; transfers of neighbouring batches overlap the search",
             "recall_at_10": None if recall is None else round(recall, 5),
             "config": {"workload": f"{N}x{d} unit-norm gaussian-mixture vectors, 1-level LMI ({L} leaves, "
                                    f"{cfg['model']} {d}->512->{L} trained {args.epochs} epochs), top-{nb} buckets, "
                                    f"{nq}-query batch, k={k}",
                        "baseline_config": args.config, "parallelism": "single GPU" if world == 1 else
-                                      f"bucket-sharded x{world}: MLP on 1/{world} of the batch + all-gather of the bucket order, "
-                                      f"scan of the owned buckets + all-gather of the per-rank top-k",
+                                      f"bucket-sharded x{world} (owned-only ingest): MLP on 1/{world} of the batch + all-gather of "
+                                      f"the bucket order, scan of the owned buckets + all-gather of the per-rank top-k",
                        "scan_pairs": int(pairs), "scan_items": int(items)},
             "roofline": roof,
             "prefilter": None if args.exact else {"survivors_per_slot": round(pf_survivors / max(1, nq * nb), 2),
                                                    "fallback_slots": int(pf_fallbacks)},
             "cpu_baseline": cpu,
-            "host_boundary": host_boundary,
+            "resident": resident,
+            "sharded_alt_mode": alt,
+            "hard_leg": hard,
             **({"diagnostic": f"emulated shard {args.emulate_shard}: NOT a bench line"} if args.emulate_shard else {}),
             "phases_ms": {"inference": round(float(phases[0]), 4), "route_pack": round(float(phases[1]), 4),
                           "scan": round(float(phases[2]), 4), "merge": round(float(phases[3]), 4),

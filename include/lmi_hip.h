@@ -132,6 +132,13 @@ LMI_API int lmi_merge_gathered(lmi_index *h, const float *gathered_dists, const 
                        const uint32_t *gathered_keys, int world, int64_t world_stride, int nq,
                        int kout, float *dists, uint32_t *ids, int on_device);
 
+/* Copies `bytes` from device memory to any device-accessible destination -- in particular PINNED host memory
+ * (hipHostMalloc / torch pin_memory) -- by a kernel on the handle's stream: the result download of a pipelined
+ * caller (learnedmetricindex_amd/pipeline.py) without hipMemcpyAsync, whose D2H form was seen to block the
+ * submitting host thread for milliseconds behind queued kernels (ROCm 7.2).  Both pointers 16-byte aligned.
+ * Replaces the `.cpu().numpy()` of model.py:240-241 / the numpy results of LearnedIndex.py:340-341. */
+LMI_API int lmi_copy_out(lmi_index *h, void *dst, const void *src, int64_t bytes);
+
 /* faiss.knn(xq, xb, k, metric=METRIC_INNER_PRODUCT) on host pointers: D[nq][k] similarities in
  * descending order, I[nq][k] row numbers; nb < k pads with D = -FLT_MAX, I = -1.  k <= 10. */
 LMI_API int lmi_knn_ip(int device, const float *xq, int64_t nq, const float *xb, int64_t nb, int d, int k,

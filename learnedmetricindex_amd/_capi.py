@@ -49,6 +49,7 @@ SIGNATURES = {
     "lmi_merge_gathered": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
                                           ctypes.c_int, _vp, _vp, ctypes.c_int]),
     "lmi_bucket_read": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp]),
+    "lmi_copy_out": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64]),
     "lmi_knn_ip": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int64, _vp, ctypes.c_int64, ctypes.c_int,
                                   ctypes.c_int, _vp, _vp]),
     "lmi_timings": (ctypes.c_int, [_vp, _vp]),
@@ -291,11 +292,21 @@ class Index:
         _check(lib().lmi_merge_gathered(self._h, _ptr(gd), _ptr(gi), _ptr(gk), int(world), int(world_stride),
                                         int(nq), int(kout), _ptr(out_d), _ptr(out_i), on_device))
 
-    def read_bucket(self, b: int):
-        """(rows f32[n_b,d], ids u32[n_b]) of bucket b, in bucket order."""
+    def copy_out(self, dst_pinned_t, src_dev_t) -> None:
+        """src (device tensor) -> dst (pinned host tensor of the same byte size) by a kernel on the handle's stream."""
+        nbytes = src_dev_t.numel() * src_dev_t.element_size()
+        assert dst_pinned_t.is_pinned() and dst_pinned_t.numel() * dst_pinned_t.element_size() == nbytes
+        assert src_dev_t.is_contiguous() and dst_pinned_t.is_contiguous()
+        _check(lib().lmi_copy_out(self._h, _ptr(dst_pinned_t), _ptr(src_dev_t), nbytes))
+
+    def read_bucket(self, b: int, rows_out=None, ids_out=None):
+        """(rows f32[n_b,d], ids u32[n_b]) of bucket b, in bucket order; `rows_out` / `ids_out`: C-contiguous
+        numpy arrays of exactly that shape to fill instead of fresh ones (e.g. slices of one host slab)."""
         n = int(self.bucket_sizes()[b])
-        rows = np.empty((n, self.d), dtype=np.float32)
-        ids = np.empty(n, dtype=np.uint32)
+        rows = np.empty((n, self.d), dtype=np.float32) if rows_out is None else rows_out
+        ids = np.empty(n, dtype=np.uint32) if ids_out is None else ids_out
+        assert rows.shape == (n, self.d) and rows.dtype == np.float32 and rows.flags.c_contiguous
+        assert ids.shape == (n,) and ids.dtype == np.uint32 and ids.flags.c_contiguous
         _check(lib().lmi_bucket_read(self._h, int(b), _ptr(rows), _ptr(ids)))
         return rows, ids
 

@@ -1082,6 +1082,18 @@ extern "C" LMI_API int lmi_prefilter_stats(lmi_index* h, int* active, int64_t* s
     return 0;
 }
 
+extern "C" LMI_API int lmi_copy_out(lmi_index* h, void* dst, const void* src, int64_t bytes) {
+    if (!h) return fail("lmi_copy_out: NULL handle");
+    if (bytes < 0 || (bytes > 0 && (!dst || !src))) return fail("lmi_copy_out: bad arguments");
+    if ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) return fail("lmi_copy_out: pointers must be 16-byte aligned");
+    if (bytes == 0) return 0;
+    CHK(set_dev(h));
+    const int blocks = (int)std::min<long long>(h->num_cus * 2, cdiv(cdiv(bytes, 16), 256));
+    copy_bytes_kernel<<<std::max(1, blocks), 256, 0, h->stream>>>(static_cast<const unsigned char*>(src), static_cast<unsigned char*>(dst), bytes);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // ---- test hooks (tests/test_gpu_bound.py): the fp16 scores the pass-2 kernel really produced --------------
 extern "C" LMI_API int lmi_debug_emit_all(lmi_index* h, int on) {
     if (!h) return fail("lmi_debug_emit_all: NULL handle");

@@ -99,6 +99,17 @@ __global__ void unpack_kernel(const float4* __restrict__ src, int KG, long long 
         if (g * 8 + j < d) dst[i * d + g * 8 + j] = v[j];
 }
 
+// plain copy by a kernel (16 bytes per lane): results -> pinned host memory without a hipMemcpyAsync
+// (lmi_copy_out); dst/src 16-byte aligned, the tail is copied bytewise
+__global__ void copy_bytes_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, long long bytes) {
+    const long long n16 = bytes >> 4;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride)
+        reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+    const long long t = (n16 << 4) + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < bytes) dst[t] = src[t];
+}
+
 // ------------------------------------------------------------------------------------------------
 // MLP layer:  Y^T = W . X^T + b  (ReLU unless last).   model.py:45-49, 97-99, 232
 //   Wf   [n_rb][KG][64]  weights, rows = output features (padded with zero rows)

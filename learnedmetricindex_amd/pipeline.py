@@ -1,0 +1,116 @@
+"""Host-in -> host-out query pipeline (SURVEY.md section 8d defines QPS from host `queries_*` arrays in to host
+`(dists, nns)` out, LearnedIndex.py:87, 159).
+
+One batch needs 31 MB of queries over PCIe (10 000 x 768 f32: ~0.55 ms at Gen5 x16) and 0.8 MB of results
+back; the search itself is ~6 ms.  `HostPipeline` keeps `depth` batches in flight on two HIP streams so the
+upload of batch i+1 runs under the scan of batch i:
+
+    copy-in stream :  H2D(q[i+1]) ............
+    compute stream :  wait(H2D i) -> lmi_search(batch i, device pointers) -> D2H(dists, ids [, bucket order]) -> event
+
+The 1 MB result download is a KERNEL on the compute stream that stores into the pinned result buffers
+(`lmi_copy_out`, ~30 us): every `hipMemcpyAsync` D2H form tried (own stream behind an event wait; in the compute
+stream) blocked the submitting host thread for 15-20 ms every few batches behind the queued search kernels
+(ROCm 7.2, seen by timing the calls) and cost up to 8 % of the throughput.
+
+Host buffers are pinned (hipHostMalloc through torch): `submit` copies a pageable numpy batch into the
+slot's pinned staging buffer (a CPU memcpy that overlaps the GPU's work), or takes a pinned torch tensor as
+it is.  PyTorch is used for pinned memory, streams and events only; the search is the C ABI's `lmi_search`.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+
+
+class HostPipeline:
+    def __init__(self, index, nq: int, d_nav: int, d_search: int, nb: int, k: int = 10, depth: int = 2,
+                 device: Optional[int] = None, same_queries: bool = False, want_bucket_order: bool = False,
+                 search_fn=None):
+        """`search_fn(qn_dev, qs_dev) -> (dists_t, ids_t, bucket_order_t)`: optional replacement of the single-GPU
+        `lmi_search` call, run on the compute stream (the bucket-sharded searcher of sharded.py, whose collectives
+        then run on that stream too); its output tensors may be reused by its next call."""
+        import torch
+
+        self.index, self.nq, self.nb, self.k, self.depth = index, int(nq), int(nb), int(k), int(depth)
+        self.kout = index.kout(nb, k)
+        self.same = bool(same_queries) and d_nav == d_search   # navigation and scan vectors are one array
+        self.want_bo = bool(want_bucket_order)
+        self.search_fn = search_fn
+        dev = torch.device("cuda", index.device if device is None else device)
+        self.dev = dev
+        self.s_in, self.s_run = (torch.cuda.Stream(dev) for _ in range(2))
+        index.set_stream(self.s_run.cuda_stream)
+        f32, i32 = torch.float32, torch.int32
+        mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)   # noqa: E731
+        pin = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)   # noqa: E731
+        self.slots = []
+        for _ in range(self.depth):
+            s = dict(qn_h=pin((nq, d_nav), f32), qn_d=mk((nq, d_nav), f32),
+                     d_d=mk((nq, self.kout), f32), i_d=mk((nq, self.kout), i32), bo_d=mk((nq, nb), i32),
+                     d_h=pin((nq, self.kout), f32), i_h=pin((nq, self.kout), i32), bo_h=pin((nq, nb), i32),
+                     ev_in=torch.cuda.Event(), ev_out=torch.cuda.Event(), busy=False)
+            if not self.same:
+                s["qs_h"], s["qs_d"] = pin((nq, d_search), f32), mk((nq, d_search), f32)
+            self.slots.append(s)
+        self.t = 0
+
+    def submit(self, queries_nav, queries_search=None) -> int:
+        """Enqueues one batch (numpy arrays or pinned CPU torch tensors, [nq, d]); returns its ticket.
+        Blocks only if the slot's previous batch (`depth` submits ago) has not finished."""
+        import torch
+
+        s = self.slots[self.t % self.depth]
+        if s["busy"]:
+            s["ev_out"].synchronize()
+        s["busy"] = True
+
+        def stage(src, pinned):
+            if isinstance(src, torch.Tensor) and src.is_pinned():
+                return src                                   # already DMA-able: no staging copy
+            pinned.copy_(torch.from_numpy(np.ascontiguousarray(src, dtype=np.float32)) if isinstance(src, np.ndarray) else src)
+            return pinned
+
+        qn_src = stage(queries_nav, s["qn_h"])
+        with torch.cuda.stream(self.s_in):
+            s["qn_d"].copy_(qn_src, non_blocking=True)
+            if not self.same:
+                qs_src = stage(queries_nav if queries_search is None else queries_search, s["qs_h"])
+                s["qs_d"].copy_(qs_src, non_blocking=True)
+            s["ev_in"].record(self.s_in)
+        with torch.cuda.stream(self.s_run):
+            self.s_run.wait_event(s["ev_in"])
+            if self.search_fn is None:
+                self.index.search_device(s["qn_d"], s["qn_d"] if self.same else s["qs_d"], self.nb, self.k,
+                                         s["d_d"], s["i_d"], None, s["bo_d"])
+                d_t, i_t, bo_t = s["d_d"], s["i_d"], s["bo_d"]
+            else:
+                d_t, i_t, bo_t = self.search_fn(s["qn_d"], s["qn_d"] if self.same else s["qs_d"])
+            self.index.copy_out(s["d_h"], d_t)          # a kernel storing to the pinned buffers (see the module docstring)
+            self.index.copy_out(s["i_h"], i_t)
+            if self.want_bo:
+                self.index.copy_out(s["bo_h"], bo_t)
+            s["ev_out"].record(self.s_run)
+        self.t += 1
+        return self.t - 1
+
+    def result(self, ticket: int) -> Tuple[np.ndarray, np.ndarray]:
+        """(dists f32[nq,kout], ids u32[nq,kout]) of a batch, as views of its pinned output slot (valid until
+        the slot is reused `depth` submits later).  Waits for that batch only."""
+        assert self.t - self.depth <= ticket < self.t, "ticket no longer (or not yet) in the ring"
+        s = self.slots[ticket % self.depth]
+        s["ev_out"].synchronize()
+        return s["d_h"].numpy(), s["i_h"].numpy().view(np.uint32)
+
+    def bucket_order(self, ticket: int) -> np.ndarray:
+        assert self.want_bo
+        s = self.slots[ticket % self.depth]
+        s["ev_out"].synchronize()
+        return s["bo_h"].numpy()
+
+    def drain(self) -> None:
+        for s in self.slots:
+            if s["busy"]:
+                s["ev_out"].synchronize()
+                s["busy"] = False

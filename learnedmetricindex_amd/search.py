@@ -1,36 +1,43 @@
 #!/usr/bin/env python3
-"""Experiment driver with the reference's command line (reference: search/search.py:1-349).
+"""Experiment driver for the MI355X build: build an index, answer the query set at several bucket budgets,
+write one result file per budget.
+
+It accepts the reference driver's command line (SURVEY.md section 5 "Config / flags"; reference
+search/search.py:306-327) so that existing job scripts keep working:
 
     python learnedmetricindex_amd/search.py --dataset pca96v2 --emb pca96 --size 100K \\
         --n-categories 10 10 --epochs 100 --model-type MLP --lr 0.01 -bp 10 --clustering-algorithm scikit_kmeans
 
-Same flags, same flow (`run` -> `evaluate_learned_index` -> `li.search` per bucket count ->
-`store_results`), same log lines and result schema (`knns` uint32, `dists` float64, attrs `algo, data,
-buildtime, querytime, size, params`).  Differences, all forced by the MI355X image:
+and produces the reference's result schema (datasets `knns` uint32 / `dists` float64, attributes `algo, data,
+buildtime, querytime, size, params`; search/search.py:51-63) so the SISAP `eval` tooling reads it.  Everything
+else is this build's own structure:
 
-* the SISAP S3 download (`prepare`, search.py:38-48) needs the network; when the h5 files are not
-  already under `data/<kind>/<size>/` the driver generates a synthetic stand-in of the same shape
-  (unit-norm Gaussian mixture, seed 2023; lower-dimensional kinds are projections of the 768-d set, like
-  the challenge's PCA variants) -- pass `--no-synthetic` to insist on real files;
-* h5py is not installed: results are written as `.npz` with the same keys when it is missing;
-* `--eval` adds what the un-vendored `eval/` submodule did: recall@k against exact search on the GPU.
+    Experiment   the parsed command line (per-level lists expanded)
+    VectorSource where the vectors come from: local `data/<kind>/<size>/{dataset,query}.(h5|npy)` or, only
+                 when `--synthetic` is given, a generated stand-in whose results are stamped `synthetic-<kind>`
+    ResultSink   `.h5` when h5py is importable, `.npz` with the same keys otherwise
+    run()        build (LearnedIndexBuilder) -> one resident index in HBM -> `search_resident` per budget ->
+                 optional recall@k against the GPU brute-force `Baseline`
 
-Known quirks of the reference's CLI are kept: `-b/--n-buckets` is parsed and unused (search.py:316),
-`--preprocess/--save` are `type=bool` (any non-empty string is true)."""
+Flags the reference parses but ignores are accepted and ignored the same way (`-b/--n-buckets`); its
+`type=bool` flags (`--preprocess`, `--save`) keep "any non-empty string is true".  Downloading from the SISAP
+S3 bucket is not supported (no network on the target machines): place the files locally or use `--synthetic`.
+"""
+from __future__ import annotations
+
 import argparse
+import dataclasses
 import logging
 import os
 import sys
 import time
-from pathlib import Path
-from typing import Any, Dict, List
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
-import numpy.typing as npt
 import pandas as pd
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-if _HERE not in sys.path:  # reference style: `li` is importable from the directory of search.py
+if _HERE not in sys.path:  # `li` importable next to this file, as in the reference layout
     sys.path.insert(0, _HERE)
 
 from li.Baseline import Baseline  # noqa: E402
@@ -39,253 +46,226 @@ from li.clustering import algorithms  # noqa: E402
 from li.LearnedIndexBuilder import LearnedIndexBuilder  # noqa: E402
 from li.utils import save_as_pickle, serialize  # noqa: E402
 
-np.random.seed(2023)
-logging.basicConfig(level=logging.INFO, format="[%(asctime)s][%(levelname)-5.5s][%(name)-.20s] %(message)s")
-LOG = logging.getLogger(__name__)
+LOG = logging.getLogger("lmi.driver")
 
-MODELS_DIR_NAME = "models"
-SIZES = {"100K": 100_000, "300K": 300_000, "10M": 10_000_000, "30M": 30_000_000, "100M": 100_000_000}
-DIMS = {"clip768v2": 768, "pca96v2": 96, "pca32v2": 32}
-N_QUERIES = 10_000  # public-queries-10k
-SYNTHETIC = True
+SCAN_KIND, SCAN_KEY = "clip768v2", "emb"   # the scan always runs on the 768-d embeddings
+PER_LEVEL = ("clustering_algorithm", "model_type", "epochs", "lr")
+CARDINALITY = {"100K": 100_000, "300K": 300_000, "10M": 10_000_000, "30M": 30_000_000, "100M": 100_000_000}
+WIDTH = {"clip768v2": 768, "pca96v2": 96, "pca32v2": 32}
+QUERY_COUNT = 10_000
 
 
-def _l2n(x):
-    n = np.linalg.norm(x, axis=1, keepdims=True)
-    n[n == 0] = 1
-    return (x / n).astype(np.float32)
+# ------------------------------------------------------------------------------------------- command line
+@dataclasses.dataclass
+class Experiment:
+    dataset: str
+    emb: str
+    size: str
+    k: int
+    n_categories: List[int]
+    epochs: List[int]
+    model_type: List[str]
+    lr: List[float]
+    buckets_perc: List[int]
+    preprocess: bool
+    save: bool
+    clustering_algorithm: List[str]
+    synthetic: bool = False
+    evaluate: bool = False
+    job: str = "unknown"
+
+    @classmethod
+    def from_argv(cls, argv: Optional[Sequence[str]] = None) -> "Experiment":
+        p = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+        p.add_argument("--dataset", default="pca96v2")
+        p.add_argument("--emb", default="pca96")
+        p.add_argument("--size", default="100K", choices=sorted(CARDINALITY, key=CARDINALITY.get))
+        p.add_argument("--k", default=10, type=int)
+        p.add_argument("--n-categories", nargs="+", default=[10, 10], type=int)
+        p.add_argument("--epochs", nargs="+", default=[100], type=int)
+        p.add_argument("--model-type", nargs="+", default=["MLP"])
+        p.add_argument("--lr", nargs="+", default=[0.01], type=float)
+        p.add_argument("-b", "--n-buckets", nargs="+", default=[2, 3, 4], type=int, help="accepted, unused (as upstream)")
+        p.add_argument("-bp", "--buckets-perc", nargs="+", default=[10], type=int)
+        p.add_argument("--preprocess", default=True, type=bool)
+        p.add_argument("--save", default=True, type=bool)
+        p.add_argument("--clustering-algorithm", nargs="+", default=["faiss_kmeans"], choices=sorted(algorithms))
+        p.add_argument("--synthetic", action="store_true",
+                       help="generate stand-in vectors when the dataset files are missing (results are stamped synthetic)")
+        p.add_argument("--eval", dest="evaluate", action="store_true", help="report recall@k against GPU brute force")
+        a = vars(p.parse_args(argv))
+        a.pop("n_buckets")
+        levels = len(a["n_categories"])
+        for name in PER_LEVEL:  # one value for all levels, or one per level
+            if len(a[name]) == 1:
+                a[name] = a[name] * levels
+            elif len(a[name]) != levels:
+                p.error(f"--{name.replace('_', '-')} needs 1 or {levels} values, got {len(a[name])}")
+        return cls(job=os.environ.get("PBS_JOBID", "unknown"), **a)
+
+    def build_configuration(self) -> BuildConfiguration:
+        return BuildConfiguration([algorithms[c] for c in self.clustering_algorithm], self.epochs, self.model_type,
+                                  self.lr, self.n_categories)
+
+    def tag(self, prefix: str, **extra) -> str:
+        """File-name stem in the upstream format: <prefix>-ep=..-lr=..-cat=..-model=..[-k=v..]-<job>."""
+        parts = [prefix, f"ep={serialize(self.epochs)}", f"lr={serialize(self.lr)}", f"cat={serialize(self.n_categories)}",
+                 f"model={serialize(self.model_type)}"]
+        parts += [f"{k}={v}" for k, v in extra.items()]
+        parts += [f"clustering_algorithm={serialize(self.clustering_algorithm)}", self.job]
+        return "-".join(parts)
 
 
-def _synthetic(kind: str, size: str):
-    """(dataset f32[N,d], queries f32[10k,d]) for `kind`: a 768-d unit-norm mixture, or its random
-    projection to the kind's dimensionality (same seed -> the kinds describe the same objects)."""
-    n, d = SIZES[size], DIMS[kind]
-    rs = np.random.RandomState(2023)
-    centres = rs.randn(256, 768).astype(np.float32)
-    proj = None if d == 768 else (np.random.RandomState(d).randn(768, d) / np.sqrt(768)).astype(np.float32)
+# ------------------------------------------------------------------------------------------- vectors
+class VectorSource:
+    """`data/<kind>/<size>/{dataset,query}.h5|.npy`; synthetic stand-ins only on request."""
 
-    def draw(m, seed):
-        r = np.random.RandomState(seed)
-        out = np.empty((m, d), dtype=np.float32)
-        for s in range(0, m, 1 << 17):
-            e = min(m, s + (1 << 17))
-            x = _l2n(centres[r.randint(256, size=e - s)] + r.randn(e - s, 768).astype(np.float32))
-            out[s:e] = x if proj is None else x @ proj
+    def __init__(self, size: str, synthetic: bool, root: str = "data"):
+        self.size, self.synthetic, self.root = size, synthetic, root
+        self.generated = set()
+
+    def _path(self, kind: str, what: str, ext: str) -> str:
+        return os.path.join(self.root, kind, self.size, f"{what}.{ext}")
+
+    def load(self, kind: str, key: str) -> Tuple[np.ndarray, np.ndarray]:
+        """(objects f32[N,d], queries f32[nq,d]) of embedding `kind`."""
+        out = []
+        for what in ("dataset", "query"):
+            if os.path.exists(self._path(kind, what, "h5")):
+                import h5py
+
+                with h5py.File(self._path(kind, what, "h5"), "r") as fh:
+                    out.append(np.asarray(fh[key], dtype=np.float32))
+            elif os.path.exists(self._path(kind, what, "npy")):
+                out.append(np.load(self._path(kind, what, "npy")).astype(np.float32, copy=False))
+            elif self.synthetic:
+                self.generated.add(kind)
+                out.append(self._generate(kind, what))
+            else:
+                raise FileNotFoundError(
+                    f"{self._path(kind, what, 'h5')} (or .npy) not found; there is no network access to fetch the SISAP "
+                    f"files -- copy them there or pass --synthetic for a generated stand-in")
+        return out[0], out[1]
+
+    def _generate(self, kind: str, what: str) -> np.ndarray:
+        """Unit-norm mixture of 256 Gaussians in 768-d; the narrower kinds are one fixed random projection of the
+        same objects (so that `pca32v2` navigation and `clip768v2` scan describe the same set)."""
+        n = CARDINALITY[self.size] if what == "dataset" else QUERY_COUNT
+        d = WIDTH[kind]
+        centres = np.random.RandomState(2023).randn(256, 768).astype(np.float32)
+        proj = None if d == 768 else (np.random.RandomState(d).randn(768, d) / np.sqrt(768.0)).astype(np.float32)
+        rs = np.random.RandomState(11 if what == "dataset" else 12)
+        out = np.empty((n, d), dtype=np.float32)
+        step = 1 << 17
+        for lo in range(0, n, step):
+            hi = min(n, lo + step)
+            x = centres[rs.randint(256, size=hi - lo)] + rs.randn(hi - lo, 768).astype(np.float32)
+            x /= np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-30)
+            out[lo:hi] = x if proj is None else x @ proj
         return out
 
-    return draw(n, 11), draw(N_QUERIES, 12)
+    def stamp(self, kind: str) -> str:
+        return f"synthetic-{kind}" if kind in self.generated else kind
 
 
-def download(src, dst):
-    if not os.path.exists(dst):
-        from urllib.request import urlretrieve
-
-        os.makedirs(Path(dst).parent, exist_ok=True)
-        LOG.info("downloading %s -> %s..." % (src, dst))
-        urlretrieve(src, dst)
+def unit_rows(x: np.ndarray) -> np.ndarray:
+    """sklearn.preprocessing.normalize(x) (l2, zero rows untouched) without the dependency."""
+    n = np.linalg.norm(x, axis=1, keepdims=True)
+    return (x / np.where(n == 0, 1, n)).astype(np.float32)
 
 
-def prepare(kind, size):
-    """Makes data/<kind>/<size>/{dataset,query}.* available (search.py:38-48)."""
-    base = os.path.join("data", kind, size)
-    if all(os.path.exists(os.path.join(base, f"{v}.h5")) or os.path.exists(os.path.join(base, f"{v}.npy"))
-           for v in ("query", "dataset")):
-        return
-    if SYNTHETIC:
-        LOG.info(f"no local copy of {kind}/{size}: generating the synthetic stand-in")
-        os.makedirs(base, exist_ok=True)
-        data, queries = _synthetic(kind, size)
-        np.save(os.path.join(base, "dataset.npy"), data)
-        np.save(os.path.join(base, "query.npy"), queries)
-        return
-    url = "https://sisap-23-challenge.s3.amazonaws.com/SISAP23-Challenge"
-    for version, src in {"query": f"{url}/public-queries-10k-{kind}.h5",
-                         "dataset": f"{url}/laion2B-en-{kind}-n={size}.h5"}.items():
-        target = os.path.join(base, f"{version}.h5")
-        download(src, target)
-        assert os.path.exists(target), f"Failed to download {src}"
+# ------------------------------------------------------------------------------------------- results
+class ResultSink:
+    """One file per bucket budget under result/<kind>/<size>/ with the upstream schema."""
 
+    def __init__(self, root: str = "result"):
+        self.root = root
+        try:
+            import h5py  # noqa: F401
 
-def _load(kind, size, version, key):
-    base = os.path.join("data", kind, size)
-    if os.path.exists(os.path.join(base, f"{version}.h5")):
-        import h5py
+            self.h5 = True
+        except ImportError:
+            self.h5 = False
 
-        return np.array(h5py.File(os.path.join(base, f"{version}.h5"), "r")[key])
-    return np.load(os.path.join(base, f"{version}.npy"))
+    def write(self, folder_kind: str, folder_size: str, stem: str, dists: np.ndarray, knns: np.ndarray, **attrs) -> str:
+        folder = os.path.join(self.root, folder_kind, folder_size)
+        os.makedirs(folder, exist_ok=True)
+        path = os.path.join(folder, stem + (".h5" if self.h5 else ".npz"))
+        if self.h5:
+            import h5py
 
-
-def store_results(dst, algo, kind, dists, anns, buildtime, querytime, params, size):
-    """Result file with the reference's schema (search.py:51-63); `.npz` when h5py is absent."""
-    os.makedirs(Path(dst).parent, exist_ok=True)
-    try:
-        import h5py
-    except ImportError:
-        dst = os.path.splitext(dst)[0] + ".npz"
-        LOG.info(f"Storing results in {dst}")
-        np.savez(dst, knns=anns, dists=dists, algo=algo, data=kind, buildtime=buildtime, querytime=querytime,
-                 size=size, params=params)
-        return dst
-    LOG.info(f"Storing results in {dst}")
-    with h5py.File(dst, "w") as f:
-        for name, value in (("algo", algo), ("data", kind), ("buildtime", buildtime), ("querytime", querytime),
-                            ("size", size), ("params", params)):
-            f.attrs[name] = value
-        f.create_dataset("knns", anns.shape, dtype=anns.dtype)[:] = anns
-        f.create_dataset("dists", dists.shape, dtype=dists.dtype)[:] = dists
-    return dst
-
-
-def format_identifier(bucket: int, kind: str, config: BuildConfiguration, clustering_algorithms: List[str],
-                      short_identifier: str, size: str):
-    return (f"{short_identifier}-{kind}-{size}-ep={serialize(config.epochs)}-lr={serialize(config.lrs)}"
-            f"-cat={serialize(config.n_categories)}-model={serialize(config.model_types)}-buck={bucket}"
-            f"-clustering_algorithm={serialize(clustering_algorithms)}-{os.environ['PBS_JOBID']}")
-
-
-def format_models_filename(kind: str, config: BuildConfiguration, clustering_algorithms: List[str],
-                           preprocess: bool, size: str):
-    return (f"./{MODELS_DIR_NAME}/{kind}-{size}-ep={serialize(config.epochs)}-lr={serialize(config.lrs)}"
-            f"-cat={serialize(config.n_categories)}-model={serialize(config.model_types)}-prep={preprocess}"
-            f"-clustering_algorithm={serialize(clustering_algorithms)}-{os.environ['PBS_JOBID']}")
-
-
-def run(kind: str, key: str, size: str, k: int, index_type: str, n_buckets_perc: List[int],
-        n_categories: List[int], epochs: List[int], model_types: List[str], lr: List[float], preprocess: bool,
-        save: bool, clustering_algorithms: List[str], evaluate: bool = False):
-    assert index_type in {"baseline", "learned-index"}, f"Unknown index type: {index_type}"
-    LOG.info(f"Running with: kind={kind}, key={key}, size={size}, n_buckets_perc={n_buckets_perc},"
-             f" n_categories={n_categories}, clustering_algorithms={clustering_algorithms},"
-             f" epochs={epochs}, lr={lr}, model_types={model_types}, preprocess={preprocess}, save={save}")
-    prepare(kind, size)
-    data: npt.NDArray[np.float32] = _load(kind, size, "dataset", key)
-    queries: npt.NDArray[np.float32] = _load(kind, size, "query", key)
-    if preprocess:
-        from sklearn import preprocessing
-
-        data = preprocessing.normalize(data)
-        queries = preprocessing.normalize(queries)
-    n, d = data.shape
-    LOG.info(f"Loaded downloaded data, shape: n={n}, d={d}")
-    LOG.info(f"Loaded downloaded queries, shape: queries={queries.shape}")
-    if index_type == "baseline":
-        baseline = Baseline()
-        LOG.info(f"Build time: {baseline.build(data)}")
-        return baseline.search(queries=queries, data=data, k=k)
-    return evaluate_learned_index(data, clustering_algorithms, epochs, model_types, lr, k, kind, n_buckets_perc,
-                                  n_categories, preprocess, queries, save, size, evaluate)
-
-
-def evaluate_learned_index(data, clustering_algorithms: List[str], epochs: List[int], model_type: List[str],
-                           lr: List[float], k: int, kind: str, n_buckets_perc: List[int],
-                           n_categories: List[int], preprocess: bool, queries, save: bool, size: str,
-                           evaluate: bool = False):
-    s = time.time()
-    data_pd = pd.DataFrame(data)
-    data_pd.index += 1  # 1-based object ids (search.py:190-191)
-    kind_search, key_search = "clip768v2", "emb"
-    if kind != kind_search:  # navigate in `kind`, scan in clip768v2 (search.py:194-213)
-        LOG.info("Loading data to be used in search")
-        prepare(kind_search, size)
-        data_search = pd.DataFrame(_load(kind_search, size, "dataset", key_search))
-        data_search.index += 1
-        queries_search = _load(kind_search, size, "query", key_search)
-        LOG.info(f"Loaded downloaded data, shape: n={data_search.shape[0]}, d={data_search.shape[1]}")
-        LOG.info(f"Loaded downloaded queries, shape: queries={queries_search.shape}")
-    else:
-        data_search, queries_search = data_pd, queries
-    config = BuildConfiguration([algorithms[a] for a in clustering_algorithms], epochs, model_type, lr, n_categories)
-    li, data_prediction, n_buckets_in_index, build_t, cluster_t = LearnedIndexBuilder(data_pd, config).build()
-    LOG.info(f"Total number of buckets in the index: {n_buckets_in_index}")
-    LOG.info(f"Cluster time: {cluster_t}")
-    LOG.info(f"Pure build time: {build_t}")
-    LOG.info(f"Overall build time: {time.time() - s}")
-    if save:
-        os.makedirs(MODELS_DIR_NAME, exist_ok=True)
-        filename = format_models_filename(kind, config, clustering_algorithms, preprocess, size)
-        LOG.info(f"Saving as {filename}")
-        save_as_pickle(f"{filename}.pkl", li)
-    n_buckets = sorted({b for b in (int((p / 100) * n_buckets_in_index) for p in n_buckets_perc) if b > 0})
-    LOG.info(f"Number of buckets to search in: {n_buckets}")
-    outputs = {}
-    for bucket in n_buckets:
-        LOG.info(f"Searching with {bucket} buckets")
-        dists, nns, measured_time = li.search(
-            data_navigation=data_pd, queries_navigation=queries, data_search=data_search,
-            queries_search=queries_search, data_prediction=data_prediction, n_categories=n_categories,
-            n_buckets=bucket, k=k)
-        LOG.info(f"Inference time: {measured_time['inference']}")
-        LOG.info(f"Search time: {measured_time['search']}")
-        LOG.info(f"Search within buckets time: {measured_time['search_within_buckets']}")
-        LOG.info(f"Sequential search time: {measured_time['seq_search']}")
-        LOG.info(f"Sort time: {measured_time['sort']}")
-        if evaluate:
-            outputs[f"recall_{bucket}"] = recall = _recall(data_search, queries_search, nns, k)
-            LOG.info(f"Recall@{k} with {bucket} buckets: {recall:.5f}")
-        identifier = format_identifier(bucket, kind, config, clustering_algorithms, "learned-index", size)
-        store_results(os.path.join("result/", kind, size, f"{identifier}.h5"), "Learned-index", kind, dists, nns,
-                      build_t, measured_time["search"], identifier, size)
-        outputs[bucket] = (dists, nns, measured_time)
-    li.close()
-    return outputs
-
-
-def _recall(data_search: pd.DataFrame, queries_search, nns, k: int, sample: int = 1000) -> float:
-    """recall@k of the first `sample` queries against exact inner-product search on the GPU
-    (notebook cell 31: |I & gt| / (k * nq); ids 1-based in index order)."""
-    try:
-        from .. import _capi  # type: ignore
-    except ImportError:
-        import _capi  # type: ignore
-    m = min(sample, nns.shape[0])
-    cols = [c for c in data_search.columns if not (isinstance(c, str) and c.startswith("category_L"))]
-    _, gt = _capi.knn_ip(np.asarray(queries_search[:m], dtype=np.float32),
-                         data_search[cols].to_numpy(dtype=np.float32), min(k, 10))
-    labels = data_search.index.to_numpy()
-    hits = sum(len(set(labels[g[g >= 0]].tolist()) & set(a.tolist())) for g, a in zip(gt, nns[:m, :k]))
-    return hits / float(min(k, 10) * m)
-
-
-def expand(array: List[Any], size: int):
-    assert len(array) == 1
-    return [array[0]] * size
-
-
-def validate_and_expand_per_level_arguments(args: Dict[str, Any]):
-    """Per-level flags are given once or once per level (search.py:292-303)."""
-    for arg in ("clustering_algorithm", "model_type", "epochs", "lr", "n_categories"):
-        if len(args[arg]) == 1:
-            args[arg] = expand(args[arg], len(args["n_categories"]))
+            with h5py.File(path, "w") as fh:
+                fh.attrs.update(attrs)
+                fh.create_dataset("knns", data=knns)
+                fh.create_dataset("dists", data=dists)
         else:
-            assert len(args[arg]) == len(args["n_categories"])
+            np.savez(path, knns=knns, dists=dists, **attrs)
+        LOG.info("results -> %s", path)
+        return path
 
 
-def main(argv=None):
-    global SYNTHETIC
-    parser = argparse.ArgumentParser()
-    parser.add_argument("--dataset", default="pca96v2")
-    parser.add_argument("--emb", default="pca96")
-    parser.add_argument("--size", default="100K", choices=list(SIZES))
-    parser.add_argument("--k", default=10, type=int)
-    parser.add_argument("--n-categories", nargs="+", default=[10, 10], type=int)
-    parser.add_argument("--epochs", nargs="+", default=[100], type=int)
-    parser.add_argument("--model-type", nargs="+", default=["MLP"])
-    parser.add_argument("--lr", nargs="+", default=[0.01], type=float)
-    parser.add_argument("-b", "--n-buckets", nargs="+", default=[2, 3, 4], type=int)  # unused, as in the reference
-    parser.add_argument("-bp", "--buckets-perc", nargs="+", default=[10], type=int)
-    parser.add_argument("--preprocess", default=True, type=bool)
-    parser.add_argument("--save", default=True, type=bool)
-    parser.add_argument("--clustering-algorithm", nargs="+", default=["faiss_kmeans"], choices=algorithms.keys())
-    parser.add_argument("--no-synthetic", action="store_true", help="fail instead of generating stand-in data")
-    parser.add_argument("--eval", action="store_true", help="log recall@k against exact search")
-    args = parser.parse_args(argv)
-    SYNTHETIC = not args.no_synthetic
-    validate_and_expand_per_level_arguments(vars(args))
-    if "PBS_JOBID" not in os.environ:
-        os.environ["PBS_JOBID"] = "unknown"
-    return run(args.dataset, args.emb, args.size, args.k, "learned-index", args.buckets_perc, args.n_categories,
-               args.epochs, args.model_type, args.lr, args.preprocess, args.save, args.clustering_algorithm,
-               evaluate=args.eval)
+# ------------------------------------------------------------------------------------------- the run
+def bucket_budgets(percentages: Sequence[int], n_buckets_in_index: int) -> List[int]:
+    """`-bp`: per cent of the index's buckets -> bucket counts, int(p/100 * n) like upstream; zeros dropped."""
+    return sorted({b for b in (int(p / 100 * n_buckets_in_index) for p in percentages) if b > 0})
+
+
+def recall_against_bruteforce(queries: np.ndarray, objects: pd.DataFrame, knns: np.ndarray, k: int, sample: int = 1000):
+    """recall@k of the first `sample` queries (notebook cell 31: |found & true| / (k * nq)); ground truth from the
+    GPU brute-force Baseline over the scan vectors."""
+    m, kk = min(sample, knns.shape[0]), min(k, 10)
+    _, truth, _ = Baseline().search(queries[:m], objects.to_numpy(dtype=np.float32), k=kk)
+    labels = objects.index.to_numpy()
+    truth = labels[truth - 1]  # Baseline ids are 1-based positions
+    return float(np.mean([len(set(t) & set(f)) / kk for t, f in zip(truth.tolist(), knns[:m, :k].tolist())]))
+
+
+def run(exp: Experiment) -> Dict:
+    LOG.info("experiment: %s", dataclasses.asdict(exp))
+    src = VectorSource(exp.size, exp.synthetic)
+    nav_x, nav_q = src.load(exp.dataset, exp.emb)
+    if exp.preprocess:
+        nav_x, nav_q = unit_rows(nav_x), unit_rows(nav_q)
+    LOG.info("navigation vectors %s, queries %s", nav_x.shape, nav_q.shape)
+    nav = pd.DataFrame(nav_x)
+    nav.index += 1  # object ids are 1-based
+    if exp.dataset == SCAN_KIND:
+        scan, scan_q = nav, nav_q
+    else:  # navigate in the narrow embedding, scan in clip768v2 (not normalised by the driver, as upstream)
+        sx, scan_q = src.load(SCAN_KIND, SCAN_KEY)
+        scan = pd.DataFrame(sx)
+        scan.index += 1
+        LOG.info("scan vectors %s, queries %s", scan.shape, scan_q.shape)
+
+    t0 = time.time()
+    index, placement, n_buckets_in_index, build_s, cluster_s = LearnedIndexBuilder(nav, exp.build_configuration()).build()
+    LOG.info("index with %d buckets: clustering %.2fs, build %.2fs, total %.2fs", n_buckets_in_index, cluster_s, build_s,
+             time.time() - t0)
+    if exp.save:
+        os.makedirs("models", exist_ok=True)
+        save_as_pickle(os.path.join("models", exp.tag(f"{exp.dataset}-{exp.size}", prep=exp.preprocess) + ".pkl"), index)
+
+    index.prepare(nav, scan, placement, exp.n_categories)  # one upload; every budget below reuses the resident slab
+    sink, out = ResultSink(), {}
+    for budget in bucket_budgets(exp.buckets_perc, n_buckets_in_index):
+        dists, knns, clock = index.search_resident(nav_q, scan_q, exp.n_categories, n_buckets=budget, k=exp.k)
+        LOG.info("%d buckets: search %.4fs (inference %.4fs, within buckets %.4fs, scan %.4fs, merge %.4fs)", budget,
+                 clock["search"], clock["inference"], clock["search_within_buckets"], clock["seq_search"], clock["sort"])
+        if exp.evaluate:
+            out[f"recall_{budget}"] = recall_against_bruteforce(scan_q, scan, knns, exp.k)
+            LOG.info("%d buckets: recall@%d = %.5f", budget, exp.k, out[f"recall_{budget}"])
+        stem = exp.tag(f"learned-index-{exp.dataset}-{exp.size}", buck=budget)
+        sink.write(exp.dataset, exp.size, stem, dists, knns, algo="Learned-index", data=src.stamp(exp.dataset),
+                   buildtime=build_s, querytime=clock["search"], size=exp.size, params=stem)
+        out[budget] = (dists, knns, clock)
+    index.close()
+    return out
+
+
+def main(argv: Optional[Sequence[str]] = None) -> Dict:
+    logging.basicConfig(level=logging.INFO, format="[%(asctime)s][%(levelname)-5.5s][%(name)-.20s] %(message)s")
+    np.random.seed(2023)
+    return run(Experiment.from_argv(argv))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,54 @@
+"""GPU (`-m gpu`): the host-in -> host-out pipeline (learnedmetricindex_amd/pipeline.py) returns, batch by batch,
+exactly what one synchronous lmi_search on host pointers returns (which the other tests pin to the oracle), with
+several batches in flight, pageable and pinned inputs, distinct navigation / scan vectors (fixture G6)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import inputs_for, layers_from, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,depth", [("G3", 2), ("G6", 3), ("G4", 1)])
+def test_pipeline_equals_synchronous_search(oracle, name, depth):
+    from learnedmetricindex_amd import _capi
+    from learnedmetricindex_amd.pipeline import HostPipeline
+
+    g = load_golden(name)
+    Xn, Qn, Xs, Qs = inputs_for(name, g)
+    layers = layers_from(g)
+    nb, k = int(g["n_buckets"]), int(g["k"])
+    L = layers[-1][0].shape[0]
+    idx = _capi.Index(0)
+    idx.set_mlp(layers)
+    idx.set_buckets(Xs, g["data_prediction"][:, 0], L)
+    nq = 96
+    same = Xn.shape[1] == Xs.shape[1] and np.array_equal(Qn, Qs)
+    pipe = HostPipeline(idx, nq, Qn.shape[1], Qs.shape[1], nb, k, depth=depth, same_queries=same, want_bucket_order=True)
+    rs = np.random.RandomState(0)
+    batches = [np.sort(rs.choice(Qn.shape[0], nq, replace=False)) for _ in range(7)]
+    tickets, expect = [], []
+    for bi, sel in enumerate(batches):
+        qn, qs = np.ascontiguousarray(Qn[sel]), np.ascontiguousarray(Qs[sel])
+        if bi % 2:  # already pinned torch tensors: no staging copy
+            tickets.append(pipe.submit(torch.from_numpy(qn).pin_memory(), torch.from_numpy(qs).pin_memory()))
+        else:
+            tickets.append(pipe.submit(qn, qs))
+        if len(tickets) > depth:  # a ticket leaves the ring `depth` submits later: read it before that
+            t = tickets[-1 - depth]
+        # results of the newest ticket (waits for that batch only)
+        d, i = pipe.result(tickets[-1])
+        bo = pipe.bucket_order(tickets[-1])
+        expect.append((d.copy(), i.copy(), bo.copy()))
+    pipe.drain()
+    idx.set_stream(0)
+    for sel, (d, i, bo) in zip(batches, expect):
+        d0, i0, bo0 = idx.search(np.ascontiguousarray(Qn[sel]), np.ascontiguousarray(Qs[sel]), nb, k)
+        np.testing.assert_array_equal(i, i0)
+        np.testing.assert_array_equal(d, d0)
+        np.testing.assert_array_equal(bo, bo0)
+    do, io, _ = oracle.search(layers, Qn[batches[0]], Xs, Qs[batches[0]], g["data_prediction"], nb, k, nthreads=4)
+    np.testing.assert_array_equal(expect[0][1], io)
+    np.testing.assert_array_equal(expect[0][0].astype(np.float64), do)
+    idx.close()

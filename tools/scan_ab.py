@@ -73,12 +73,14 @@ def main():
         out_i = torch.empty((nq, 10), dtype=torch.int32, device=dev)
         variants.append((path, capi, idx, out_d, out_i, []))
     ref = None
+    emit = {}
     for r in range(args.rounds + 1):
         for path, capi, idx, out_d, out_i, times in variants:
             idx.scan_topk_device(q, bo, nb, 10, out_d, out_i)
             t = idx.timings()
             if r:
                 times.append(float(t[capi.T_SCAN]))
+                emit.setdefault(path, []).append(float(t[capi.T_PF_EMIT]))
             elif ref is None:
                 ref = out_i.clone()
             else:
@@ -86,7 +88,8 @@ def main():
     for path, capi, idx, out_d, out_i, times in variants:
         fl, pairs, items = idx.scan_stats()
         med, mn = float(np.median(times)), float(np.min(times))
-        print(f"{os.path.basename(path):28s} scan median {med:8.3f} ms  min {mn:8.3f} ms  "
+        e = emit.get(path, [0.0])
+        print(f"{os.path.basename(path):28s} pass2 median {float(np.median(e)):7.3f} min {float(np.min(e)):7.3f} ms | scan median {med:8.3f} ms  min {mn:8.3f} ms  "
               f"{fl / med / 1e9:7.2f} TFLOP/s (median)  items {items}  prefilter {idx.prefilter_stats()}  "
               f"rounds {[round(t, 1) for t in times]}  last phases {[round(float(v), 2) for v in idx.timings()]}", flush=True)
 
