@@ -78,6 +78,29 @@ LMI_API int lmi_set_stream(lmi_index *h, void *hip_stream);
 LMI_API int lmi_set_mlp(lmi_index *h, int n_layers, const int *dims, const float *const *W,
                 const float *const *b);
 
+/* Unfused fallback of the MLP (one kernel per layer + ranking kernels) instead of the one-launch kernel of
+ * lmi_mlp_fused.h; both produce bit-identical logits, orders and probabilities.  Default: fused. */
+LMI_API int lmi_set_fused_mlp(lmi_index *h, int on);
+
+/* Multi-level index (len(n_categories) > 1; LearnedIndex.py:216-325, PriorityQueue.py:18-94): the models of
+ * the internal nodes and the tree.  Model 0 is the root (lmi_set_mlp); lmi_nav_set_model sets model_id >= 1
+ * (arguments as lmi_set_mlp).  lmi_nav_set_tree: child e = child_offset[m] + c is class c of model m:
+ * child_model[e] >= 1 -> that internal node's model, -1 -> a leaf; child_bucket[e] >= 0 -> slab bucket id
+ * (the bucket ids of lmi_buckets_begin), -1 -> a bucket path that holds no object (LearnedIndex.bucket_paths
+ * lists it: it is recorded and its slot stays unvisited), -2 -> not a bucket (the popped path is dropped, as
+ * the reference's _visit_buckets does).
+ * lmi_nav_order: the batched priority-queue walk on the device -- every query pops its most probable entry
+ * (priority = the child's LOCAL softmax probability; ties: the entry pushed later), internal nodes
+ * are expanded by their model for all queries that popped them (one grouped launch per step), until nb
+ * buckets are recorded.  slab_ids[nq][nb], entries[nq][nb] (flat child index of each visited bucket; -1 where
+ * the queue ran out). */
+LMI_API int lmi_nav_set_model(lmi_index *h, int model_id, int n_layers, const int *dims, const float *const *W,
+                      const float *const *b);
+LMI_API int lmi_nav_set_tree(lmi_index *h, int n_models, const int32_t *child_offset, const int32_t *child_model,
+                     const int32_t *child_bucket);
+LMI_API int lmi_nav_order(lmi_index *h, const float *queries_nav, int nq, int nb, int32_t *slab_ids,
+                  int32_t *entries, int on_device);
+
 /* Bucket-contiguous index in HBM.
  * begin: labels[N] = data_prediction[:,0] (bucket of every object, 0 <= label < L), ids[N] = the
  *        DataFrame index labels (NULL -> 1..N, search.py:190-191), owned[L] = which buckets this

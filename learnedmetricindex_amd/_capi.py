@@ -35,6 +35,10 @@ SIGNATURES = {
     "lmi_destroy": (ctypes.c_int, [_vp]),
     "lmi_set_stream": (ctypes.c_int, [_vp, _vp]),
     "lmi_set_mlp": (ctypes.c_int, [_vp, ctypes.c_int, _i32p, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
+    "lmi_set_fused_mlp": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "lmi_nav_set_model": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _i32p, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
+    "lmi_nav_set_tree": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp]),
+    "lmi_nav_order": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int]),
     "lmi_buckets_begin": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
     "lmi_buckets_add_rows": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int]),
     "lmi_buckets_add_owned_rows": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int]),
@@ -182,6 +186,39 @@ class Index:
         bp = (_vp * n)(*[b.ctypes.data for b in bs])
         _check(lib().lmi_set_mlp(self._h, n, dims_c, Wp, bp))
         self.d_nav, self.n_classes = dims[0], dims[-1]
+
+    def set_fused_mlp(self, on: bool) -> None:
+        """One-launch MLP (default) or the per-layer kernels; identical outputs."""
+        _check(lib().lmi_set_fused_mlp(self._h, 1 if on else 0))
+
+    # ---- multi-level navigation ---------------------------------------------------------------
+    @staticmethod
+    def _pack_layers(layers):
+        Ws = [_np(W, np.float32) for W, _ in layers]
+        bs = [_np(b, np.float32) for _, b in layers]
+        dims = [Ws[0].shape[1]] + [W.shape[0] for W in Ws]
+        for i, (W, b) in enumerate(zip(Ws, bs)):
+            assert W.shape == (dims[i + 1], dims[i]) and b.shape == (dims[i + 1],)
+        n = len(Ws)
+        return Ws, bs, n, (ctypes.c_int32 * (n + 1))(*dims), (_vp * n)(*[W.ctypes.data for W in Ws]), (_vp * n)(*[b.ctypes.data for b in bs])
+
+    def nav_set_model(self, model_id: int, layers: Sequence) -> None:
+        """Model of an internal node (model_id >= 1; the root is set_mlp)."""
+        Ws, bs, n, dims_c, Wp, bp = self._pack_layers(layers)
+        _check(lib().lmi_nav_set_model(self._h, int(model_id), n, dims_c, Wp, bp))
+
+    def nav_set_tree(self, child_offset, child_model, child_bucket) -> None:
+        co, cm, cbk = _np(child_offset, np.int32), _np(child_model, np.int32), _np(child_bucket, np.int32)
+        assert cm.shape == cbk.shape == (int(co[-1]),)
+        _check(lib().lmi_nav_set_tree(self._h, co.shape[0] - 1, _ptr(co), _ptr(cm), _ptr(cbk)))
+
+    def nav_order(self, queries_nav, nb: int):
+        """(slab bucket ids i32[nq,nb], flat child indices i32[nq,nb]) of the multi-level walk."""
+        q = _np(queries_nav, np.float32)
+        slab = np.empty((q.shape[0], nb), dtype=np.int32)
+        ent = np.empty((q.shape[0], nb), dtype=np.int32)
+        _check(lib().lmi_nav_order(self._h, _ptr(q), q.shape[0], int(nb), _ptr(slab), _ptr(ent), 0))
+        return slab, ent
 
     # ---- buckets ---------------------------------------------------------------------------
     def buckets_begin(self, labels, d: int, L: int, ids=None, owned=None) -> None:

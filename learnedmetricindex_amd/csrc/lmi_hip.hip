@@ -3,6 +3,7 @@
 // weights and the per-call workspaces; enqueues the kernels of lmi_kernels.h on one HIP stream.
 #include "lmi_kernels.h"
 #include "lmi_prefilter.h"
+#include "lmi_mlp_fused.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -85,6 +86,24 @@ struct lmi_index {
     std::vector<int> KG;      // per layer: k-groups of the layer's input
     std::vector<DevBuf> Wf;   // packed weights
     std::vector<DevBuf> bias; // padded bias
+
+    // ---- fused MLP / multi-level navigation (lmi_mlp_fused.h) ----
+    struct NodeModel {            // an internal node's model (model id >= 1; the root is the fields above)
+        int n_layers = 0;
+        std::vector<int> dims, n_rb, KG;
+        std::vector<DevBuf> Wf, bias;
+    };
+    std::vector<NodeModel> node_models;   // index = model id - 1
+    bool fused_mlp = true;                // lmi_set_fused_mlp
+    bool desc_dirty = true;
+    DevBuf d_models;                      // ModelDesc[1 + node_models.size()]
+    int fm_s0 = 0, fm_s1 = 0, fm_act0 = 0, fm_lds = 0, fm_logits_lds = 0;  // LDS plan of the current model set
+    bool fm_ok = false;                   // every model fits the fused kernel
+    // the tree: flat child index = child_offset[model] + class
+    std::vector<int> h_child_offset, h_child_model, h_child_bucket;
+    DevBuf d_child_offset, d_child_model, d_child_bucket;
+    bool tree_set = false;
+    DevBuf pq_prob, pq_ent, pq_len, nav_len, nav_slab, nav_ent, nav_count, nav_colq, nav_active;
 
     // ---- buckets ----
     bool building = false, built = false;
@@ -189,6 +208,10 @@ extern "C" LMI_API int lmi_destroy(lmi_index* h) {
                       &h->slot_col, &h->colmap, &h->qfrag, &h->grp, &h->col_thr, &h->slab16, &h->rowmajor, &h->xscale, &h->xmaxbits, &h->bnorm, &h->bdelta, &h->qdelta, &h->qnorm, &h->qscale, &h->qfrag16, &h->eps2, &h->cand_cnt, &h->cand_row, &h->cand_s, &h->fallback, &h->pf_bound, &h->nkeep, &h->part_score, &h->part_row, &h->rank_d,
                       &h->rank_id, &h->out_d, &h->out_id, &h->out_key};
     for (DevBuf* b : bufs) b->release();
+    for (auto& m : h->node_models) { for (auto& b : m.Wf) b.release(); for (auto& b : m.bias) b.release(); }
+    DevBuf* nav[] = {&h->d_models, &h->d_child_offset, &h->d_child_model, &h->d_child_bucket, &h->pq_prob, &h->pq_ent, &h->pq_len,
+                     &h->nav_len, &h->nav_slab, &h->nav_ent, &h->nav_count, &h->nav_colq, &h->nav_active};
+    for (DevBuf* b : nav) b->release();
     for (int r = 0; r < lmi_index::EV_RING; ++r)
         for (int i = 0; i < 10; ++i)
             if (h->ev_ring[r][i]) (void)hipEventDestroy(h->ev_ring[r][i]);
@@ -233,32 +256,156 @@ static int pack_from_host(lmi_index* h, const float* src, int rows, int cols, in
     return 0;
 }
 
+// packs one Linear stack (torch layout W[out][in]) fragment-major: shared by lmi_set_mlp and lmi_nav_set_model
+static int pack_model(lmi_index* h, const char* who, int n_layers, const int* dims, const float* const* W, const float* const* b,
+                      std::vector<int>& o_dims, std::vector<int>& o_nrb, std::vector<int>& o_KG, std::vector<DevBuf>& o_W,
+                      std::vector<DevBuf>& o_b) {
+    if (n_layers < 1 || n_layers > LMI_MAX_LAYERS) return fail("%s: n_layers %d out of range", who, n_layers);
+    for (int i = 0; i <= n_layers; ++i)
+        if (dims[i] < 1) return fail("%s: dims[%d] = %d", who, i, dims[i]);
+    for (auto& x : o_W) x.release();
+    for (auto& x : o_b) x.release();
+    o_dims.assign(dims, dims + n_layers + 1);
+    o_nrb.assign(n_layers, 0);
+    o_KG.assign(n_layers, 0);
+    o_W.assign(n_layers, DevBuf());
+    o_b.assign(n_layers, DevBuf());
+    for (int i = 0; i < n_layers; ++i) {
+        o_nrb[i] = cdiv(dims[i + 1], 32);
+        o_KG[i] = (i == 0) ? cdiv(dims[0], 8) : o_nrb[i - 1] * 4;  // hidden K = padded features
+        if (!W[i] || !b[i]) return fail("%s: NULL weight/bias for layer %d", who, i);
+        CHK(pack_from_host(h, W[i], dims[i + 1], dims[i], o_nrb[i], o_KG[i], o_W[i]));
+        std::vector<float> bp((size_t)o_nrb[i] * 32, 0.0f);
+        std::copy(b[i], b[i] + dims[i + 1], bp.begin());
+        CHK(o_b[i].reserve(bp.size() * sizeof(float)));
+        HIPCHK(hipMemcpy(o_b[i].p, bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
 extern "C" LMI_API int lmi_set_mlp(lmi_index* h, int n_layers, const int* dims, const float* const* W,
                            const float* const* b) {
     if (!h) return fail("lmi_set_mlp: NULL handle");
-    if (n_layers < 1 || n_layers > LMI_MAX_LAYERS) return fail("lmi_set_mlp: n_layers %d out of range", n_layers);
     CHK(set_dev(h));
-    for (int i = 0; i <= n_layers; ++i)
-        if (dims[i] < 1) return fail("lmi_set_mlp: dims[%d] = %d", i, dims[i]);
-    for (auto& x : h->Wf) x.release();
-    for (auto& x : h->bias) x.release();
+    h->desc_dirty = true;
+    h->n_layers = 0;
+    CHK(pack_model(h, "lmi_set_mlp", n_layers, dims, W, b, h->dims, h->n_rb, h->KG, h->Wf, h->bias));
     h->n_layers = n_layers;
-    h->dims.assign(dims, dims + n_layers + 1);
-    h->n_rb.assign(n_layers, 0);
-    h->KG.assign(n_layers, 0);
-    h->Wf.assign(n_layers, DevBuf());
-    h->bias.assign(n_layers, DevBuf());
-    for (int i = 0; i < n_layers; ++i) {
-        h->n_rb[i] = cdiv(dims[i + 1], 32);
-        h->KG[i] = (i == 0) ? cdiv(dims[0], 8) : h->n_rb[i - 1] * 4;  // hidden K = padded features
-        if (!W[i] || !b[i]) return fail("lmi_set_mlp: NULL weight/bias for layer %d", i);
-        CHK(pack_from_host(h, W[i], dims[i + 1], dims[i], h->n_rb[i], h->KG[i], h->Wf[i]));
-        std::vector<float> bp((size_t)h->n_rb[i] * 32, 0.0f);
-        std::copy(b[i], b[i] + dims[i + 1], bp.begin());
-        CHK(h->bias[i].reserve(bp.size() * sizeof(float)));
-        HIPCHK(hipMemcpy(h->bias[i].p, bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice));
-    }
     return 0;
+}
+
+extern "C" LMI_API int lmi_set_fused_mlp(lmi_index* h, int on) {
+    if (!h) return fail("lmi_set_fused_mlp: NULL handle");
+    h->fused_mlp = on != 0;
+    return 0;
+}
+
+// ---- multi-level index: the internal nodes' models and the tree (lmi_mlp_fused.h) ----
+extern "C" LMI_API int lmi_nav_set_model(lmi_index* h, int model_id, int n_layers, const int* dims, const float* const* W,
+                                 const float* const* b) {
+    if (!h) return fail("lmi_nav_set_model: NULL handle");
+    if (model_id < 1 || model_id > 1 << 20) return fail("lmi_nav_set_model: model_id %d (the root, model 0, is lmi_set_mlp)", model_id);
+    CHK(set_dev(h));
+    if ((size_t)model_id > h->node_models.size()) h->node_models.resize(model_id);
+    auto& m = h->node_models[model_id - 1];
+    h->desc_dirty = true;
+    h->tree_set = false;
+    m.n_layers = 0;
+    CHK(pack_model(h, "lmi_nav_set_model", n_layers, dims, W, b, m.dims, m.n_rb, m.KG, m.Wf, m.bias));
+    m.n_layers = n_layers;
+    return 0;
+}
+
+extern "C" LMI_API int lmi_nav_set_tree(lmi_index* h, int n_models, const int32_t* child_offset, const int32_t* child_model,
+                                const int32_t* child_bucket) {
+    if (!h) return fail("lmi_nav_set_tree: NULL handle");
+    if (h->n_layers == 0) return fail("lmi_nav_set_tree: no root model (lmi_set_mlp)");
+    if (n_models != 1 + (int)h->node_models.size()) return fail("lmi_nav_set_tree: %d models, %d set (root + lmi_nav_set_model)", n_models, 1 + (int)h->node_models.size());
+    if (!child_offset || !child_model || !child_bucket || child_offset[0] != 0) return fail("lmi_nav_set_tree: bad arguments");
+    for (int m = 0; m < n_models; ++m) {
+        const int classes = m == 0 ? h->dims[h->n_layers] : (h->node_models[m - 1].n_layers ? h->node_models[m - 1].dims.back() : -1);
+        if (classes < 0) return fail("lmi_nav_set_tree: model %d has no weights (lmi_nav_set_model)", m);
+        if (child_offset[m + 1] - child_offset[m] != classes) return fail("lmi_nav_set_tree: model %d has %d classes, %d children listed", m, classes, child_offset[m + 1] - child_offset[m]);
+    }
+    const int total = child_offset[n_models];
+    for (int e = 0; e < total; ++e) {
+        if (child_model[e] < -1 || child_model[e] == 0 || child_model[e] >= n_models) return fail("lmi_nav_set_tree: child_model[%d] = %d", e, child_model[e]);
+        if (child_bucket[e] < -2) return fail("lmi_nav_set_tree: child_bucket[%d] = %d", e, child_bucket[e]);
+    }
+    CHK(set_dev(h));
+    h->h_child_offset.assign(child_offset, child_offset + n_models + 1);
+    h->h_child_model.assign(child_model, child_model + total);
+    h->h_child_bucket.assign(child_bucket, child_bucket + total);
+    CHK(h->d_child_offset.reserve((size_t)(n_models + 1) * 4));
+    CHK(h->d_child_model.reserve((size_t)std::max(total, 1) * 4));
+    CHK(h->d_child_bucket.reserve((size_t)std::max(total, 1) * 4));
+    HIPCHK(hipMemcpy(h->d_child_offset.p, child_offset, (size_t)(n_models + 1) * 4, hipMemcpyHostToDevice));
+    if (total) {
+        HIPCHK(hipMemcpy(h->d_child_model.p, child_model, (size_t)total * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_child_bucket.p, child_bucket, (size_t)total * 4, hipMemcpyHostToDevice));
+    }
+    h->tree_set = true;
+    return 0;
+}
+
+// device descriptors of every model + the LDS plan of mlp_fused_kernel for the current model set
+static int build_descs(lmi_index* h) {
+    if (!h->desc_dirty) return 0;
+    const int nm = 1 + (int)h->node_models.size();
+    std::vector<ModelDesc> D(nm);
+    bool ok = h->n_layers > 0, logits_lds = true;
+    int w0 = 0, w1 = 0;
+    auto add = [&](ModelDesc& d, int n_layers, const std::vector<int>& dims, const std::vector<int>& n_rb, const std::vector<int>& KG,
+                   const std::vector<DevBuf>& Wf, const std::vector<DevBuf>& bias) {
+        memset(&d, 0, sizeof(d));
+        d.n_layers = n_layers;
+        if (n_layers == 0) { ok = false; return; }
+        for (int i = 0; i <= n_layers; ++i) d.dims[i] = dims[i];
+        for (int i = 0; i < n_layers; ++i) {
+            d.KG[i] = KG[i];
+            d.W[i] = Wf[i].as<float4>();
+            d.b[i] = bias[i].as<float>();
+            const int padded = n_rb[i] * 32;
+            const bool last = i + 1 == n_layers;
+            if (padded > FM_MAXH) { if (last) logits_lds = false; else ok = false; continue; }
+            int& wref = (i & 1) ? w1 : w0;
+            wref = std::max(wref, padded);
+        }
+    };
+    add(D[0], h->n_layers, h->dims, h->n_rb, h->KG, h->Wf, h->bias);
+    for (int m = 1; m < nm; ++m) {
+        const auto& M = h->node_models[m - 1];
+        add(D[m], M.n_layers, M.dims, M.n_rb, M.KG, M.Wf, M.bias);
+    }
+    h->fm_s0 = w0 + 1;
+    h->fm_s1 = w1 + 1;
+    h->fm_act0 = FM_COLS * h->fm_s0;
+    h->fm_lds = (FM_COLS * FM_CHUNK_S + FM_COLS * h->fm_s0 + FM_COLS * h->fm_s1) * 4;
+    if (h->fm_lds > 160 * 1024 - 1024) ok = false;
+    h->fm_ok = ok;
+    h->fm_logits_lds = logits_lds ? 1 : 0;
+    CHK(h->d_models.reserve(sizeof(ModelDesc) * nm));
+    HIPCHK(hipMemcpy(h->d_models.p, D.data(), sizeof(ModelDesc) * nm, hipMemcpyHostToDevice));
+    if (ok) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<FM_TOPK>), hipFuncAttributeMaxDynamicSharedMemorySize, h->fm_lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<FM_PROBA>), hipFuncAttributeMaxDynamicSharedMemorySize, h->fm_lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<FM_NAV>), hipFuncAttributeMaxDynamicSharedMemorySize, h->fm_lds));
+    }
+    h->desc_dirty = false;
+    return 0;
+}
+
+static void fused_base(lmi_index* h, const float* d_q, int nq, FusedParams& P) {
+    memset(&P, 0, sizeof(P));
+    P.models = h->d_models.as<ModelDesc>();
+    P.n_models = 1 + (int)h->node_models.size();
+    P.x = d_q;
+    P.d = h->dims[0];
+    P.nq = nq;
+    P.s0 = h->fm_s0;
+    P.s1 = h->fm_s1;
+    P.act0_floats = h->fm_act0;
+    P.logits_in_lds = h->fm_logits_lds;
 }
 
 extern "C" LMI_API int lmi_buckets_begin(lmi_index* h, int64_t N, int d, int L, const int64_t* labels,
@@ -498,10 +645,40 @@ static int input_ptr(lmi_index* h, const void* src, size_t bytes, int on_device,
     return 0;
 }
 
-static int mlp_enqueue(lmi_index* h, const float* d_q, int nq, int nb, int* d_order, float* d_logits_out) {
+// MLP forward + class ranking (+ softmax when d_probs: then nb == L and d_order receives the full class order)
+static int mlp_enqueue(lmi_index* h, const float* d_q, int nq, int nb, int* d_order, float* d_logits_out, float* d_probs = nullptr) {
     if (h->n_layers == 0) return fail("lmi_mlp_topk: no MLP set (lmi_set_mlp)");
     const int L = h->dims[h->n_layers];
     if (nb < 1 || nb > L) return fail("lmi_mlp_topk: n_buckets %d outside [1,%d]", nb, L);
+    CHK(build_descs(h));
+    if (h->fused_mlp && h->fm_ok) {
+        // every layer, the ranking and the softmax in ONE launch (lmi_mlp_fused.h)
+        FusedParams P;
+        fused_base(h, d_q, nq, P);
+        float* d_logits = d_logits_out;
+        if (!h->fm_logits_lds && !d_logits) {  // wide output layer: logits through global memory, ranked below
+            CHK(h->logits.reserve((size_t)nq * L * 4));
+            d_logits = h->logits.as<float>();
+        }
+        P.logits_out = d_logits;
+        P.nb = nb;
+        P.order = d_order;
+        P.probs = d_probs;
+        P.classes = d_order;
+        const int grid = cdiv(nq, FM_COLS);
+        if (d_probs) mlp_fused_kernel<FM_PROBA><<<grid, 256, h->fm_lds, h->stream>>>(P);
+        else mlp_fused_kernel<FM_TOPK><<<grid, 256, h->fm_lds, h->stream>>>(P);
+        HIPCHK(hipGetLastError());
+        if (!h->fm_logits_lds) {
+            rank_classes_kernel<<<nq, 64, 0, h->stream>>>(d_logits, nq, L, nb, d_order);
+            HIPCHK(hipGetLastError());
+            if (d_probs) {
+                softmax_ranked_kernel<<<cdiv(nq, 64), 64, 0, h->stream>>>(d_logits, d_order, nq, L, d_probs);
+                HIPCHK(hipGetLastError());
+            }
+        }
+        return 0;
+    }
     const int ncb = cdiv(nq, 32);
     // pack the queries as the B operand of layer 0
     CHK(h->xfrag.reserve((size_t)ncb * h->KG[0] * 1024));
@@ -544,6 +721,10 @@ static int mlp_enqueue(lmi_index* h, const float* d_q, int nq, int nb, int* d_or
     }
     rank_classes_kernel<<<nq, 64, 0, h->stream>>>(d_logits, nq, L, nb, d_order);
     HIPCHK(hipGetLastError());
+    if (d_probs) {
+        softmax_ranked_kernel<<<cdiv(nq, 64), 64, 0, h->stream>>>(d_logits, d_order, nq, L, d_probs);
+        HIPCHK(hipGetLastError());
+    }
     return 0;
 }
 
@@ -596,9 +777,7 @@ extern "C" LMI_API int lmi_mlp_proba(lmi_index* h, const float* queries_nav, int
     }
     begin_call(h);
     CHK(record(h, 0));
-    CHK(mlp_enqueue(h, static_cast<const float*>(d_q), nq, L, d_order, nullptr));
-    softmax_ranked_kernel<<<cdiv(nq, 64), 64, 0, h->stream>>>(h->logits.as<float>(), d_order, nq, L, d_probs);
-    HIPCHK(hipGetLastError());
+    CHK(mlp_enqueue(h, static_cast<const float*>(d_q), nq, L, d_order, nullptr, d_probs));
     CHK(record(h, 1));
     if (!on_device) {
         HIPCHK(hipMemcpyAsync(classes, d_order, (size_t)nq * L * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1091,6 +1270,101 @@ extern "C" LMI_API int lmi_copy_out(lmi_index* h, void* dst, const void* src, in
     const int blocks = (int)std::min<long long>(h->num_cus * 2, cdiv(cdiv(bytes, 16), 256));
     copy_bytes_kernel<<<std::max(1, blocks), 256, 0, h->stream>>>(static_cast<const unsigned char*>(src), static_cast<unsigned char*>(dst), bytes);
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// Multi-level navigation on the device: LearnedIndex._precompute_bucket_order for len(n_categories) > 1
+// (LearnedIndex.py:216-252) -- the batched priority-queue walk.  slab_ids[nq][nb] <- slab bucket id of the
+// j-th visited bucket (-1: listed bucket without objects or queue exhausted), entries[nq][nb] <- its flat child
+// index (child_offset[parent model] + class; -1: none) from which the caller rebuilds the path.
+extern "C" LMI_API int lmi_nav_order(lmi_index* h, const float* queries_nav, int nq, int nb, int32_t* slab_ids, int32_t* entries,
+                             int on_device) {
+    if (!h) return fail("lmi_nav_order: NULL handle");
+    if (nq < 0 || nb < 1) return fail("lmi_nav_order: bad nq/n_buckets");
+    if (nq == 0) return 0;
+    if (!h->tree_set) return fail("lmi_nav_order: no tree (lmi_nav_set_model / lmi_nav_set_tree)");
+    CHK(set_dev(h));
+    CHK(build_descs(h));
+    if (!h->fm_ok || !h->fm_logits_lds)
+        return fail("lmi_nav_order: a model of the tree does not fit the fused kernel (layer outputs <= %d, LDS plan %d bytes)", FM_MAXH, h->fm_lds);
+    const int nm = 1 + (int)h->node_models.size();
+    const int cap = h->h_child_offset[nm];
+    if ((long long)nq * cap >= (1ll << 31) || (long long)nq * nb >= (1ll << 31)) return fail("lmi_nav_order: nq too large for this tree");
+    if (cap == 0) return fail("lmi_nav_order: empty tree");
+    const void* d_q = nullptr;
+    CHK(input_ptr(h, queries_nav, (size_t)nq * h->dims[0] * 4, on_device, h->q_nav, &d_q));
+    CHK(h->pq_prob.reserve((size_t)nq * cap * 4));
+    CHK(h->pq_ent.reserve((size_t)nq * cap * 4));
+    CHK(h->pq_len.reserve((size_t)nq * 4));
+    CHK(h->nav_len.reserve((size_t)nq * 4));
+    CHK(h->nav_slab.reserve((size_t)nq * nb * 4));
+    CHK(h->nav_ent.reserve((size_t)nq * nb * 4));
+    CHK(h->nav_count.reserve((size_t)2 * (nm + 1) * 4));  // [2][nm + 1]: per-model counters + the step's active-query count
+    CHK(h->nav_colq.reserve((size_t)nm * nq * 4));
+    int* d_slab = on_device ? slab_ids : h->nav_slab.as<int>();
+    int* d_ent = on_device ? entries : h->nav_ent.as<int>();
+    begin_call(h);
+    CHK(record(h, 0));
+    FillRanges Z;
+    Z.count = 0;
+    auto fill = [&](void* ptr, long long words, unsigned value) { Z.p[Z.count] = static_cast<unsigned*>(ptr); Z.n[Z.count] = words; Z.v[Z.count] = value; ++Z.count; };
+    fill(h->pq_len.p, nq, 0u);
+    fill(h->nav_len.p, nq, 0u);
+    fill(d_slab, (long long)nq * nb, 0xFFFFFFFFu);
+    fill(d_ent, (long long)nq * nb, 0xFFFFFFFFu);
+    fill(h->nav_count.p, 2 * (nm + 1), 0u);
+    fill_ranges_kernel<<<h->num_cus * 2, 256, 0, h->stream>>>(Z);
+    HIPCHK(hipGetLastError());
+    FusedParams P;
+    fused_base(h, static_cast<const float*>(d_q), nq, P);
+    P.pq_prob = h->pq_prob.as<float>();
+    P.pq_ent = h->pq_ent.as<int>();
+    P.pq_len = h->pq_len.as<int>();
+    P.cap = cap;
+    P.child_offset = h->d_child_offset.as<int>();
+    P.reverse = 1;  // root children: least probable first (LearnedIndex.py:220-227)
+    mlp_fused_kernel<FM_NAV><<<cdiv(nq, FM_COLS), 256, h->fm_lds, h->stream>>>(P);
+    HIPCHK(hipGetLastError());
+    P.reverse = 0;
+    P.col_query = h->nav_colq.as<int>();
+    NavParams N;
+    N.nq = nq; N.nb = nb; N.cap = cap;
+    N.pq_prob = P.pq_prob; N.pq_ent = P.pq_ent; N.pq_len = P.pq_len;
+    N.child_model = h->d_child_model.as<int>();
+    N.child_bucket = h->d_child_bucket.as<int>();
+    N.out_len = h->nav_len.as<int>();
+    N.out_slab = d_slab;
+    N.out_ent = d_ent;
+    N.col_query = h->nav_colq.as<int>();
+    int* counts = h->nav_count.as<int>();
+    // Every step pops one entry per unfinished query: at most cap pops in all.  The steps are enqueued in batches of
+    // 4 and the count of still-active queries is read back after each batch (one small synchronisation).
+    const int max_steps = cap + 1;
+    int h_active = 1;
+    for (int it = 0; it < max_steps && h_active > 0;) {
+        int last_par = 0;
+        for (int k4 = 0; k4 < 4 && it < max_steps; ++k4, ++it) {
+            const int par = it & 1;
+            N.node_count = counts + par * (nm + 1);
+            N.active = counts + par * (nm + 1) + nm;
+            nav_pop_kernel<<<cdiv(nq, 256), 256, 0, h->stream>>>(N);
+            HIPCHK(hipGetLastError());
+            P.node_count = N.node_count;
+            P.zero_counts = counts + (1 - par) * (nm + 1);
+            P.n_zero = nm + 1;
+            mlp_fused_kernel<FM_NAV><<<cdiv(nq, FM_COLS) + nm, 256, h->fm_lds, h->stream>>>(P);
+            HIPCHK(hipGetLastError());
+            last_par = par;
+        }
+        HIPCHK(hipMemcpyAsync(&h_active, counts + last_par * (nm + 1) + nm, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    CHK(record(h, 1));
+    if (!on_device) {
+        HIPCHK(hipMemcpyAsync(slab_ids, d_slab, (size_t)nq * nb * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(entries, d_ent, (size_t)nq * nb * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
     return 0;
 }
 

@@ -83,6 +83,7 @@ def load_index(path: str, device: int = 0) -> Tuple[LearnedIndex, List[int]]:
         eng.set_mlp(linear_layers(root.model))
     else:
         li._path_ids = {tuple(p): i for i, p in enumerate(meta["paths"])}
+        li._upload_tree(eng, len(meta["n_categories"]))  # the nodes' models + the tree for the device-side walk
     labels = np.repeat(np.arange(sizes.shape[0], dtype=np.int64), sizes)
     eng.buckets_begin(labels, int(meta["d"]), int(sizes.shape[0]), ids=ids)
     piece = max(1, (256 << 20) // (4 * int(meta["d"])))

@@ -9,10 +9,12 @@ values `(dists f64[nq,k], nns u32[nq,k], measured_time)`.  What changes undernea
   of every call, LearnedIndex.py:350-357);
 * one `lmi_search` call does MLP forward -> top-n_buckets -> routing -> bucket scan -> merge on the
   GPU (LearnedIndex.py:87-146 + 163-214 + 328-373);
-* multi-level indexes (`len(n_categories) > 1`): the priority-queue navigation keeps the
-  reference's host structure (LearnedIndex.py:216-325) with every model evaluated by the HIP MLP
-  kernels (`NeuralNetwork.predict_proba` -> lmi_mlp_proba), then ONE lmi_scan_topk call scans the
-  buckets of all ranks;
+* multi-level indexes (`len(n_categories) > 1`): the batched priority-queue walk of the reference
+  (LearnedIndex.py:216-325, PriorityQueue.py) runs on the device (`lmi_nav_order`): per step every
+  unfinished query pops its most probable node (priority = the child's local softmax probability), the
+  queries that popped the same internal node are evaluated by that node's model in one grouped launch of
+  the fused MLP kernel and its children are pushed; then ONE lmi_scan_topk call scans the buckets of
+  all ranks;
 * `data_navigation` is never mutated (the reference adds/drops `category_L*` columns,
   :101-104/:153-157), so passing the same frame for navigation and scan works.
 
@@ -32,8 +34,8 @@ import pandas as pd
 
 from .Logger import Logger
 from .model import NeuralNetwork, data_X_to_torch, linear_layers
-from .PriorityQueue import EMPTY_VALUE, PriorityQueue
-from .utils import filter_path_idxs, log_runtime
+from .PriorityQueue import EMPTY_VALUE
+from .utils import log_runtime
 
 try:
     from .. import _capi
@@ -59,12 +61,14 @@ class LearnedIndex(Logger):
         self._engine = None
         self._engine_key = None
         self._path_ids = None
+        self._entry_paths = None
 
     def __getstate__(self):  # picklable like the reference object (search.py:234-241)
         state = dict(self.__dict__)
         state["_engine"] = None
         state["_engine_key"] = None
         state["_path_ids"] = None
+        state["_entry_paths"] = None
         return state
 
     def __setstate__(self, state):
@@ -72,6 +76,7 @@ class LearnedIndex(Logger):
         self.__dict__.setdefault("_engine", None)
         self.__dict__.setdefault("_engine_key", None)
         self.__dict__.setdefault("_path_ids", None)
+        self.__dict__.setdefault("_entry_paths", None)
 
     # ------------------------------------------------------------------------------------------
     def close(self) -> None:
@@ -111,6 +116,7 @@ class LearnedIndex(Logger):
             bucket_of = np.asarray(bucket_of).reshape(-1)
             n_bucket_ids = paths.shape[0]
             self._path_ids = {tuple(int(v) for v in p): i for i, p in enumerate(paths)}
+            self._upload_tree(eng, n_levels)
         labels = data_navigation.index.to_numpy()
         assert labels.min(initial=0) >= 0 and labels.max(initial=0) < 2 ** 32, "ids must fit uint32"
         cols = _feature_columns(data_search)
@@ -172,9 +178,8 @@ class LearnedIndex(Logger):
             t = eng.timings() * 1e-3
             measured_time["inference"] = float(t[_capi.T_INFERENCE])
         else:
-            bucket_order, measured_time["inference"] = self._precompute_bucket_order(
-                queries_navigation=qn, n_buckets=n_buckets, n_categories=n_categories)
-            ids = self._bucket_ids(bucket_order)
+            ids, _ = eng.nav_order(qn, n_buckets)          # the priority-queue walk, on the device
+            measured_time["inference"] = float(eng.timings()[_capi.T_INFERENCE]) * 1e-3
             d32, nns = eng.scan_topk(qs, ids, k)
             t = eng.timings() * 1e-3
         measured_time["search_within_buckets"] = float(t[_capi.T_ROUTE] + t[_capi.T_SCAN] + t[_capi.T_MERGE])
@@ -186,79 +191,50 @@ class LearnedIndex(Logger):
         return dists, nns, measured_time
 
     # ------------------------------------------------------------------------------------------
-    def _bucket_ids(self, bucket_order: npt.NDArray[np.int32]) -> npt.NDArray[np.int32]:
-        """paths [nq, nb, n_levels] -> slab bucket ids [nq, nb]; a path that holds no object -> -1
-        (the reference's groupby never yields it, so the slot stays unvisited)."""
-        nq, nb, _ = bucket_order.shape
-        flat = bucket_order.reshape(nq * nb, -1)
-        uniq, inv = np.unique(flat, axis=0, return_inverse=True)
-        ids = np.array([self._path_ids.get(tuple(int(v) for v in p), -1) for p in uniq], dtype=np.int32)
-        return ids[np.asarray(inv).reshape(-1)].reshape(nq, nb)
+    def _upload_tree(self, eng, n_levels: int) -> None:
+        """Models of the internal nodes + the tree tables of lmi_nav_set_tree (include/lmi_hip.h).  Model 0 is the
+        root, model i+1 the i-th entry of `internal_models`; child (m, c) is the path of model m extended by class
+        c: an internal node, a listed bucket (slab id, or -1 when no object was placed there) or neither (-2)."""
+        eng.set_mlp(linear_layers(self.root_model.model))
+        prefixes = [()]
+        model_of = {}
+        for i, (path, net) in enumerate(self.internal_models.items()):
+            prefix = tuple(int(v) for v in path if v != EMPTY_VALUE)
+            eng.nav_set_model(i + 1, linear_layers(net.model))
+            model_of[prefix] = i + 1
+            prefixes.append(prefix)
+        buckets = {tuple(int(v) for v in p if v != EMPTY_VALUE) for p in self.bucket_paths}
+        classes = [linear_layers(self.root_model.model)[-1][0].shape[0]] + [
+            linear_layers(net.model)[-1][0].shape[0] for net in self.internal_models.values()]
+        offset, child_model, child_bucket, entry_path = [0], [], [], []
+        for prefix, n_cls in zip(prefixes, classes):
+            for c in range(n_cls):
+                child = prefix + (c,)
+                child_model.append(model_of.get(child, -1))
+                padded = child + (EMPTY_VALUE,) * (n_levels - len(child))
+                child_bucket.append(self._path_ids.get(padded, -1) if child in buckets else -2)
+                entry_path.append(padded[:n_levels])
+            offset.append(len(child_model))
+        eng.nav_set_tree(offset, child_model, child_bucket)
+        self._entry_paths = np.asarray(entry_path, dtype=np.int32).reshape(-1, n_levels)
 
     @log_runtime(INFO, "Precomputed bucket order time: {}")
     def _precompute_bucket_order(self, queries_navigation: npt.NDArray[np.float32], n_buckets: int,
                                  n_categories: List[int]) -> Tuple[npt.NDArray[np.int32], float]:
         """(bucket_order int32[nq, n_buckets, n_levels], inference seconds) -- LearnedIndex.py:163-252.
 
-        1 level: lmi_mlp_topk.  More levels: the reference's batched priority-queue walk; every
-        `predict_proba` is the HIP MLP (probabilities from the canonical softmax, so priorities
-        compare exactly like the oracle's)."""
+        1 level: lmi_mlp_topk on the root model.  More levels: lmi_nav_order on the resident index (`prepare`
+        uploaded the tree); the visited buckets' flat child indices are mapped back to their paths."""
         assert self.root_model is not None, "Model is not trained, call `build` first."
         qn = np.ascontiguousarray(queries_navigation, dtype=np.float32)
         n_queries, n_levels = qn.shape[0], len(n_categories)
+        bucket_order = np.full((n_queries, n_buckets, n_levels), EMPTY_VALUE, dtype=np.int32)
         if n_levels == 1:
             eng = self.root_model.engine()
-            order = eng.mlp_topk(qn, n_buckets)
-            t = float(eng.timings()[_capi.T_INFERENCE]) * 1e-3
-            bucket_order = np.full((n_queries, n_buckets, 1), EMPTY_VALUE, dtype=np.int32)
-            bucket_order[:, :, 0] = order
-            return bucket_order, t
-
-        total_inference_t = 0.0
-        s = time.time()
-        pred_l1_prob, pred_l1_paths = self.root_model.predict_proba(data_X_to_torch(qn))
-        total_inference_t += time.time() - s
-        pq = PriorityQueue(n_queries, int(np.prod(n_categories)), n_levels)
-        # root children pushed least probable first: the tail is the most probable (:220-227)
-        for l1_idx in reversed(range(n_categories[0])):
-            l1_paths = np.full((n_queries, n_levels), EMPTY_VALUE, dtype=np.int32)
-            l1_paths[:, 0] = pred_l1_paths[:, l1_idx]
-            pq.add(np.arange(n_queries), l1_paths, pred_l1_prob[:, l1_idx])
-        bucket_order = np.full((n_queries, n_buckets, n_levels), EMPTY_VALUE, dtype=np.int32)
-        bucket_order_length = np.zeros(n_queries, dtype=np.int32)
-        while not np.all(bucket_order_length == n_buckets):
-            query_idxs = np.where(bucket_order_length < n_buckets)[0]
-            path_to_visit = pq.pop(query_idxs)
-            total_inference_t += self._visit_internal_nodes(qn, query_idxs, pq, path_to_visit, n_levels)
-            self._visit_buckets(query_idxs, path_to_visit, bucket_order, bucket_order_length)
-            pq.sort()
-        return bucket_order, total_inference_t
-
-    def _visit_internal_nodes(self, queries_navigation, all_query_idxs, pq: PriorityQueue, path_to_visit,
-                              n_levels: int) -> float:
-        """Expands the popped internal nodes: every child enters the queue with its LOCAL softmax
-        probability (LearnedIndex.py:254-301).  Returns the inference seconds."""
-        inference_t = 0.0
-        for path, model in self.internal_models.items():
-            query_idxs = all_query_idxs[filter_path_idxs(path_to_visit, path)]
-            if query_idxs.shape[0] == 0:
-                continue
-            s = time.time()
-            probabilities, categories = model.predict_proba(data_X_to_torch(queries_navigation[query_idxs]))
-            inference_t += time.time() - s
-            level = len(path) - list(path).count(EMPTY_VALUE)
-            for child_idx in range(categories.shape[1]):
-                child_paths = np.full((query_idxs.shape[0], n_levels), EMPTY_VALUE, dtype=np.int32)
-                child_paths[:] = np.array(path)
-                child_paths[:, level] = categories[:, child_idx]
-                pq.add(query_idxs, child_paths, probabilities[:, child_idx])
-        return inference_t
-
-    def _visit_buckets(self, all_query_idxs, path_to_visit, bucket_order, bucket_order_length) -> None:
-        """Records the popped bucket paths in visiting order (LearnedIndex.py:303-325)."""
-        for path in self.bucket_paths:
-            query_idxs = all_query_idxs[filter_path_idxs(path_to_visit, path)]
-            if query_idxs.shape[0] == 0:
-                continue
-            bucket_order[query_idxs, bucket_order_length[query_idxs], :] = np.array(path)
-            bucket_order_length[query_idxs] += 1
+            bucket_order[:, :, 0] = eng.mlp_topk(qn, n_buckets)
+            return bucket_order, float(eng.timings()[_capi.T_INFERENCE]) * 1e-3
+        assert self._engine is not None, "multi-level navigation needs the resident index: call prepare() first"
+        _, entries = self._engine.nav_order(qn, n_buckets)
+        found = entries >= 0
+        bucket_order[found] = self._entry_paths[entries[found]]
+        return bucket_order, float(self._engine.timings()[_capi.T_INFERENCE]) * 1e-3

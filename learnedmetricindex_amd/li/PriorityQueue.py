@@ -1,10 +1,11 @@
-"""Batched per-query priority queue (reference: li/PriorityQueue.py:1-94).
+"""`li.PriorityQueue` of the reference API surface (reference: li/PriorityQueue.py).
 
-Three dense arrays hold, for every query, the probabilities and paths of the nodes still to
-visit; queues are kept sorted ASCENDING by probability so that `pop` takes from the tail.
-Used by multi-level navigation only (LearnedIndex.py:216-250)."""
+The per-query priority queues of the multi-level walk live on the device in this build (csrc/lmi_mlp_fused.h:
+`nav_pop_kernel` pops, `mlp_fused_kernel<FM_NAV>` pushes; entries are never moved, a popped entry is marked dead).
+This module keeps the names callers import -- `EMPTY_VALUE`, the padding of paths, and a small host-side
+`PriorityQueue` with the device queue's semantics (max probability first, the LATER push wins a tie: what the
+reference's ascending sort + pop-from-the-tail yields), used to cross-check the kernels in tests."""
 import numpy as np
-import numpy.typing as npt
 
 EMPTY_VALUE = -1
 
@@ -12,36 +13,31 @@ EMPTY_VALUE = -1
 class PriorityQueue:
     def __init__(self, n_queries: int, queue_length_upper_bound: int, n_levels: int):
         self.n_levels = n_levels
-        self.probability: npt.NDArray[np.float32] = np.full(
-            (n_queries, queue_length_upper_bound), EMPTY_VALUE, dtype=np.float32)
-        self.path: npt.NDArray[np.int32] = np.full(
-            (n_queries, queue_length_upper_bound, n_levels), EMPTY_VALUE, dtype=np.int32)
-        self.length: npt.NDArray[np.int32] = np.zeros(n_queries, dtype=np.int32)
-        self.should_sort: npt.NDArray[np.bool_] = np.zeros(n_queries, dtype=np.bool_)
+        self.probability = np.full((n_queries, queue_length_upper_bound), np.nan, dtype=np.float32)
+        self.path = np.full((n_queries, queue_length_upper_bound, n_levels), EMPTY_VALUE, dtype=np.int32)
+        self.alive = np.zeros((n_queries, queue_length_upper_bound), dtype=bool)
+        self.length = np.zeros(n_queries, dtype=np.int32)  # entries ever pushed
 
     def add(self, indices, path, probabilities) -> None:
-        """Appends one (path, probability) entry to the queues of `indices` (PriorityQueue.py:37-50)."""
-        slot = self.length[indices]
-        self.probability[indices, slot] = probabilities
-        self.path[indices, slot, :] = path
-        self.should_sort[indices] = True
-        self.length[indices] = slot + 1
+        at = self.length[indices]
+        self.probability[indices, at] = probabilities
+        self.path[indices, at] = path
+        self.alive[indices, at] = True
+        self.length[indices] = at + 1
 
     def pop(self, indices):
-        """Removes and returns the tail (most probable) path of each queue in `indices` (:52-56)."""
-        self.length[indices] -= 1
-        return self.path[indices, self.length[indices], :]
+        """Paths of the most probable live entry of each queue in `indices` (ties: the latest push); EMPTY rows
+        for exhausted queues."""
+        indices = np.asarray(indices)
+        out = np.full((indices.shape[0], self.n_levels), EMPTY_VALUE, dtype=np.int32)
+        for r, q in enumerate(indices):
+            live = np.flatnonzero(self.alive[q, : self.length[q]])
+            if live.size:
+                p = self.probability[q, live]
+                best = live[np.flatnonzero(p == p.max())[-1]]
+                self.alive[q, best] = False
+                out[r] = self.path[q, best]
+        return out
 
     def sort(self) -> None:
-        """Re-sorts (ascending probability) every queue flagged by `add` (:58-94); queues of equal
-        length are handled together, like the reference does."""
-        for qlen in np.unique(self.length):
-            if qlen < 2:
-                continue
-            rows = np.flatnonzero((self.length == qlen) & self.should_sort)
-            if rows.size == 0:
-                continue
-            order = self.probability[rows, :qlen].argsort()
-            self.probability[rows, :qlen] = np.take_along_axis(self.probability[rows, :qlen], order, axis=1)
-            self.path[rows, :qlen, :] = np.take_along_axis(self.path[rows, :qlen, :], order[:, :, None], axis=1)
-            self.should_sort[rows] = False
+        """Nothing to do: `pop` selects by priority (kept for callers written against the reference)."""
