@@ -380,7 +380,7 @@ static int build_descs(lmi_index* h) {
     h->fm_s0 = w0 + 1;
     h->fm_s1 = w1 + 1;
     h->fm_act0 = FM_COLS * h->fm_s0;
-    h->fm_lds = (FM_COLS * FM_CHUNK_S + FM_COLS * h->fm_s0 + FM_COLS * h->fm_s1) * 4;
+    h->fm_lds = (2 * FM_COLS * FM_CHUNK_S + FM_COLS * h->fm_s0 + FM_COLS * h->fm_s1) * 4;
     if (h->fm_lds > 160 * 1024 - 1024) ok = false;
     h->fm_ok = ok;
     h->fm_logits_lds = logits_lds ? 1 : 0;
@@ -1337,9 +1337,10 @@ extern "C" LMI_API int lmi_nav_order(lmi_index* h, const float* queries_nav, int
     N.out_ent = d_ent;
     N.col_query = h->nav_colq.as<int>();
     int* counts = h->nav_count.as<int>();
-    // Every step pops one entry per unfinished query: at most cap pops in all.  The steps are enqueued in batches of
-    // 4 and the count of still-active queries is read back after each batch (one small synchronisation).
-    const int max_steps = cap + 1;
+    // A step pops entries until the query hits an internal node; a query expands each node at most once, so there are
+    // at most (models) steps.  They are enqueued in batches of 4 and the number of queries still waiting for an
+    // expansion is read back after each batch (one small synchronisation).
+    const int max_steps = nm + 1;
     int h_active = 1;
     for (int it = 0; it < max_steps && h_active > 0;) {
         int last_par = 0;

@@ -5,7 +5,7 @@
 //   * a column is a query (1-level index, `lmi_mlp_topk` / `lmi_mlp_proba`) or a (query, internal node) pair of the
 //     multi-level walk (LearnedIndex.py:254-301: all queries that popped the same node are evaluated together, the
 //     block's model id selects the weight set);
-//   * layer 0 streams the input rows through LDS in chunks of 128 features (coalesced row segments, gathered by the
+//   * layer 0 streams the input rows through LDS in chunks of 96 features (coalesced row segments, gathered by the
 //     column -> query map), hidden activations never leave LDS (row-major [32][width + 1]: the odd stride makes both
 //     the B-operand reads and the accumulator write-back bank-conflict free), ReLU is applied in registers;
 //   * every inner product is the canonical chain: v_mfma_f32_32x32x2_f32 fed k in order, one accumulator per
@@ -25,7 +25,7 @@ namespace lmi {
 
 constexpr int FM_MAXL = 8;      // Linear layers per model (LMI_MAX_LAYERS)
 constexpr int FM_COLS = 32;     // columns per block = one MFMA column block
-constexpr int FM_CHUNK = 128;   // input features staged per step of layer 0
+constexpr int FM_CHUNK = 96;    // input features staged per step of layer 0 (12 k-groups: a multiple of the 3-deep weight prefetch)
 constexpr int FM_CHUNK_S = FM_CHUNK + 1;
 constexpr int FM_MAXH = 512;    // widest layer whose outputs stay in LDS
 enum { FM_TOPK = 0, FM_PROBA = 1, FM_NAV = 2 };
@@ -56,8 +56,8 @@ struct FusedParams {
     float* probs;                // FM_PROBA [nq][L]
     int* classes;                // FM_PROBA [nq][L]
     // FM_NAV: per-query priority queue (entries are never moved: a popped entry is marked dead)
-    float* pq_prob;              // [nq][cap]
-    int* pq_ent;                 // [nq][cap] flat child index = child_offset[model] + class; -1 = popped
+    float* pq_prob;              // [cap][nq]
+    int* pq_ent;                 // [cap][nq] flat child index = child_offset[model] + class; -1 = popped
     int* pq_len;                 // [nq] entries ever pushed
     int cap;
     const int* child_offset;     // [n_models + 1]
@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(FusedParams P) {
     __shared__ int s_hdr[4];
     __shared__ int s_q[FM_COLS];
     __shared__ float s_max[FM_COLS], s_sum[FM_COLS];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, c = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the row-block tests below are s_cbranch, not exec masks
     if (tid == 0) {
         int model = -1, ncols = 0, first = 0;
         if (!P.node_count) {
@@ -102,8 +103,9 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(FusedParams P) {
     __syncthreads();
     const ModelDesc& M = P.models[model];
     const int n_layers = M.n_layers;
-    float* chunk = fm_smem;
-    float* act0 = fm_smem + FM_COLS * FM_CHUNK_S;
+    float* chunk0 = fm_smem;                                   // two input chunks: one computes while the next lands
+    float* chunk1 = fm_smem + FM_COLS * FM_CHUNK_S;
+    float* act0 = fm_smem + 2 * FM_COLS * FM_CHUNK_S;
     float* act1 = act0 + P.act0_floats;
     const int L = M.dims[n_layers];
 
@@ -117,8 +119,14 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(FusedParams P) {
         const float* in = (li & 1) ? act0 : act1;   // li > 0: the previous layer's outputs
         const int Si = (li & 1) ? P.s0 : P.s1;
         const bool out_lds = !last || P.logits_in_lds;
-        const float4* Wl = M.W[li];
-        const float* bl = M.b[li];
+        // the descriptor's pointers come out of memory, so hipcc would use FLAT loads for them -- which count on
+        // lgkmcnt as well, so that every `s_waitcnt lgkmcnt(0)` for an LDS read also waited for the weight
+        // prefetch (measured: no prefetch depth helped until the loads were global_load)
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(1))) f4v* gf4;
+        typedef const __attribute__((address_space(1))) float* gf1;
+        const gf4 Wl = (gf4)M.W[li];
+        const gf1 bl = (gf1)M.b[li];
         for (int pass = 0; pass * 16 < n_rb; ++pass) {
             int rb[4];
             bool ok[4];
@@ -128,63 +136,110 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(FusedParams P) {
                 rb[j] = pass * 16 + 4 * j + w;
                 ok[j] = rb[j] < n_rb;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][r] = ok[j] ? bl[rb[j] * 32 + acc_row(r, h)] : 0.0f;
+                for (int r = 0; r < 16; ++r) acc[j][r] = bl[(ok[j] ? rb[j] : 0) * 32 + acc_row(r, h)];
             }
-            const float4* ap[4];
+            gf4 ap[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) ap[j] = Wl + (size_t)(ok[j] ? rb[j] : 0) * KG * 64 + lane;
-            float4 a[4];
+            // The weight fragments come straight from L2, three k-groups ahead of their use, in three NAMED register
+            // sets used in rotation (group g uses set g % 3 and refills it for group g + 3): with one wave per SIMD
+            // nothing else hides the load latency; rotating by register copies would make every copy wait for the
+            // newest load, and selecting the set by a run-time branch made hipcc shuffle the accumulators between the
+            // branches (880 v_accvgpr_mov, scratch): the loops below are unrolled by three instead.
+            f4v aq0[4], aq1[4], aq2[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a[j] = ok[j] ? ap[j][0] : make_float4(0.f, 0.f, 0.f, 0.f);
-            // one k-group: B from `bsrc` (this lane's column, k offset already applied), A one group ahead
-            auto group = [&](const float* bsrc, int g) {
-                const int gn = g + 1 < KG ? g + 1 : g;
-                float4 an[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) an[j] = ok[j] ? ap[j][(size_t)gn * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
-                const float b0 = bsrc[0 + h], b1 = bsrc[2 + h], b2 = bsrc[4 + h], b3 = bsrc[6 + h];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (ok[j]) {
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].x, b0, acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].y, b1, acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].z, b2, acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].w, b3, acc[j], 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) a[j] = an[j];
-            };
+            for (int j = 0; j < 4; ++j) {
+                aq0[j] = ap[j][0];
+                aq1[j] = ap[j][(size_t)min(1, KG - 1) * 64];
+                aq2[j] = ap[j][(size_t)min(2, KG - 1) * 64];
+            }
+            // one k-group G with weight set AQ and B from BSRC (this lane's column, k offset applied); row-blocks past
+            // the layer's last one are skipped by scalar branches (their loads are clamped)
+#define FM_STEP(AQ, BNEXT, G)                                                                              \
+            {                                                                                              \
+                const float* bs_ = (BNEXT);  /* the NEXT group's B values are requested before this group's MFMAs */ \
+                const float n0 = bs_[0 + h], n1 = bs_[2 + h], n2 = bs_[4 + h], n3 = bs_[6 + h];            \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                            \
+                    if (ok[j]) {                                                                           \
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AQ[j].x, bq0, acc[j], 0, 0, 0);      \
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AQ[j].y, bq1, acc[j], 0, 0, 0);      \
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AQ[j].z, bq2, acc[j], 0, 0, 0);      \
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AQ[j].w, bq3, acc[j], 0, 0, 0);      \
+                    }                                                                                      \
+                }                                                                                          \
+                const int gn_ = min((G) + 3, KG - 1);                                                      \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) AQ[j] = ap[j][(size_t)gn_ * 64];             \
+                bq0 = n0; bq1 = n1; bq2 = n2; bq3 = n3;                                                    \
+            }
+            // groups [G0, G1) (G0 a multiple of 3) with B at BASE + 8 * (g - G0); the look-ahead of the last group
+            // re-reads its own values
+#define FM_RANGE(BASE, G0, G1)                                                                             \
+            {                                                                                              \
+                int g_ = (G0);                                                                             \
+                const float* bb_ = (BASE);                                                                 \
+                const int last_ = ((G1) - (G0) - 1) * 8;                                                   \
+                float bq0 = bb_[0 + h], bq1 = bb_[2 + h], bq2 = bb_[4 + h], bq3 = bb_[6 + h];              \
+                int o_ = 0;                                                                                \
+                for (; g_ + 3 <= (G1); g_ += 3, o_ += 24) {                                                \
+                    FM_STEP(aq0, bb_ + min(o_ + 8, last_), g_)                                             \
+                    FM_STEP(aq1, bb_ + min(o_ + 16, last_), g_ + 1)                                        \
+                    FM_STEP(aq2, bb_ + min(o_ + 24, last_), g_ + 2)                                        \
+                }                                                                                          \
+                if (g_ < (G1)) FM_STEP(aq0, bb_ + min(o_ + 8, last_), g_)                                  \
+                if (g_ + 1 < (G1)) FM_STEP(aq1, bb_ + min(o_ + 16, last_), g_ + 1)                         \
+            }
             if (li == 0) {
+                // input features in chunks of 96 through two LDS buffers: thread -> (row, 12-float segment); the
+                // next chunk's rows are requested before this chunk's MFMAs and written to the other buffer after them
                 const int d = P.d;
                 const int nck = (KG * 8 + FM_CHUNK - 1) / FM_CHUNK;
-                for (int ck = 0; ck < nck; ++ck) {
-                    {   // stage features [128 ck, 128 ck + 128) of the block's 32 rows: thread -> (row, 16-float segment)
-                        const int row = tid >> 3, seg = tid & 7;
-                        const int qi = s_q[row];
-                        const int k0 = ck * FM_CHUNK + seg * 16;
-                        float* dst = chunk + row * FM_CHUNK_S + seg * 16;
-                        const float* src = P.x + (size_t)(qi < 0 ? 0 : qi) * d + k0;
-                        if (qi >= 0 && k0 + 16 <= d && (d & 3) == 0) {
+                const int row = tid >> 3, seg = tid & 7;
+                const int qi = s_q[row];
+                const float* src = P.x + (size_t)(qi < 0 ? 0 : qi) * d;
+                const bool vec_ok = (d & 3) == 0;
+                float4 st[3];
+                // loads are unconditional (clamped addresses) and masked afterwards: a load under a per-lane condition
+                // makes hipcc branch around it and wait vmcnt(0) per element
+                auto fetch = [&](int ck) {
+                    const int k0 = ck * FM_CHUNK + seg * 12;
+                    if (vec_ok && (ck + 1) * FM_CHUNK <= d) {  // block-uniform: the whole chunk lies inside the rows
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const float4 v = *reinterpret_cast<const float4*>(src + 4 * i);
-                                dst[4 * i + 0] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w;
-                            }
-                        } else {
+                        for (int i = 0; i < 3; ++i) st[i] = *reinterpret_cast<const float4*>(src + k0 + 4 * i);
+                    } else {
+                        float e[12];
 #pragma unroll
-                            for (int i = 0; i < 16; ++i) dst[i] = (qi >= 0 && k0 + i < d) ? src[i] : 0.0f;
-                        }
+                        for (int i = 0; i < 12; ++i) e[i] = src[min(k0 + i, d - 1)];
+#pragma unroll
+                        for (int i = 0; i < 12; ++i) e[i] = k0 + i < d ? e[i] : 0.0f;
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) st[i] = make_float4(e[4 * i], e[4 * i + 1], e[4 * i + 2], e[4 * i + 3]);
                     }
-                    __syncthreads();
+                    if (qi < 0) {
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) st[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                };
+                auto put = [&](float* buf) {
+                    float* dst = buf + row * FM_CHUNK_S + seg * 12;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { dst[4 * i + 0] = st[i].x; dst[4 * i + 1] = st[i].y; dst[4 * i + 2] = st[i].z; dst[4 * i + 3] = st[i].w; }
+                };
+                fetch(0);
+                put(chunk0);
+                __syncthreads();
+                for (int ck = 0; ck < nck; ++ck) {
+                    const float* cur = (ck & 1) ? chunk1 : chunk0;
+                    if (ck + 1 < nck) fetch(ck + 1);
                     const int g_end = min(KG, (ck + 1) * (FM_CHUNK / 8));
-                    for (int g = ck * (FM_CHUNK / 8); g < g_end; ++g)
-                        group(chunk + c * FM_CHUNK_S + (g - ck * (FM_CHUNK / 8)) * 8, g);
+                    FM_RANGE(cur + c * FM_CHUNK_S, ck * (FM_CHUNK / 8), g_end)
+                    if (ck + 1 < nck) put((ck & 1) ? chunk0 : chunk1);
                     __syncthreads();
                 }
             } else {
-                for (int g = 0; g < KG; ++g) group(in + c * Si + g * 8, g);
+                FM_RANGE(in + c * Si, 0, KG)
             }
+#undef FM_RANGE
+#undef FM_STEP
             // outputs: feature f = rb*32 + acc_row(r, h) of column c
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -217,56 +272,59 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(FusedParams P) {
         }
         __syncthreads();
     }
+    // Ranking: 8 lanes per column, all 8 columns of a wave side by side (a wave per column, one column after the
+    // other, took 27 us of a 106-us block: 32 sequential passes of 12 dependent shuffles each).  Selection pass t
+    // finds the t-th class of the descending order, ties -> lower class index (rank_classes_kernel's rule).
     const int T = MODE == FM_TOPK ? P.nb : L;
-    for (int col = w; col < ncols; col += 4) {
-        const int q = s_q[col];
-        const float* l = lg + col * SL;
-        int base = 0;
-        if (MODE == FM_NAV) base = P.pq_len[q];
-        float pv = INFINITY;
-        int pi = -1;
-        for (int t = 0; t < T; ++t) {
-            float bv = -INFINITY;
-            int bi = 0x7fffffff;
-            for (int j = lane; j < L; j += 64) {
-                const float v = l[j];
-                const bool after = (v < pv) || (v == pv && j > pi);
-                if (after && (v > bv || (v == bv && j < bi))) { bv = v; bi = j; }
-            }
+    const int col = w * 8 + (lane >> 3), sub = lane & 7;
+    const bool live = col < ncols;
+    const int q = s_q[live ? col : 0];
+    const float* l = lg + (live ? col : 0) * SL;
+    int base = 0;
+    if (MODE == FM_NAV) base = P.pq_len[q];
+    float pv = INFINITY;
+    int pi = -1;
+    for (int t = 0; t < T; ++t) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int j = sub; j < L; j += 8) {
+            const float v = l[j];
+            const bool after = (v < pv) || (v == pv && j > pi);
+            if (after && (v > bv || (v == bv && j < bi))) { bv = v; bi = j; }
+        }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float ov = __shfl_xor(bv, o);
-                const int oi = __shfl_xor(bi, o);
-                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-            }
-            if (lane == 0) {
-                const int cls = bi == 0x7fffffff ? -1 : bi;
-                if (MODE == FM_TOPK) {
-                    P.order[(size_t)q * P.nb + t] = cls;
+        for (int o = 4; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (sub == 0 && live) {
+            const int cls = bi == 0x7fffffff ? -1 : bi;
+            if (MODE == FM_TOPK) {
+                P.order[(size_t)q * P.nb + t] = cls;
+            } else {
+                const float pr = cls >= 0 ? lmi_expf(l[cls] - s_max[col]) / s_sum[col] : __builtin_nanf("");
+                if (MODE == FM_PROBA) {
+                    P.classes[(size_t)q * L + t] = cls;
+                    P.probs[(size_t)q * L + t] = pr;
                 } else {
-                    const float pr = cls >= 0 ? lmi_expf(l[cls] - s_max[col]) / s_sum[col] : __builtin_nanf("");
-                    if (MODE == FM_PROBA) {
-                        P.classes[(size_t)q * L + t] = cls;
-                        P.probs[(size_t)q * L + t] = pr;
-                    } else {
-                        const int pos = base + (P.reverse ? L - 1 - t : t);
-                        if (pos < P.cap) {
-                            P.pq_prob[(size_t)q * P.cap + pos] = pr;
-                            P.pq_ent[(size_t)q * P.cap + pos] = cls >= 0 ? P.child_offset[model] + cls : -1;
-                        }
+                    const int pos = base + (P.reverse ? L - 1 - t : t);
+                    if (pos < P.cap) {  // entry-major: the pop kernel's threads (one per query) read coalesced
+                        P.pq_prob[(size_t)pos * P.nq + q] = pr;
+                        P.pq_ent[(size_t)pos * P.nq + q] = cls >= 0 ? P.child_offset[model] + cls : -1;
                     }
                 }
             }
-            pv = bv;
-            pi = bi;
         }
-        if (MODE == FM_NAV && lane == 0) P.pq_len[q] = min(P.cap, base + L);
+        pv = bv;
+        pi = bi;
     }
+    if (MODE == FM_NAV && sub == 0 && live) P.pq_len[q] = min(P.cap, base + L);
 }
 
 // ------------------------------------------------------------------------------------------------
 // Multi-level walk, one step (LearnedIndex.py:234-250: `pq.pop` for every unfinished query, then
-// `_visit_internal_nodes` / `_visit_buckets`).  One thread per query pops the most probable entry of its
+// `_visit_internal_nodes` / `_visit_buckets`).  One thread per query pops the most probable entries of its
 // queue -- ties: the entry pushed LATER (what the reference's ascending stable sort + pop-from-the-tail does) --
 // and either records a bucket, or queues the query for its node's model (this step's mlp_fused_kernel<FM_NAV>),
 // or drops a path that is neither.  child_bucket: >= 0 slab bucket id, -1 a listed bucket without objects (the
@@ -284,7 +342,7 @@ struct NavParams {
     int* out_ent;             // [nq][nb] flat child index of the bucket (-> its path on the host)
     int* node_count;          // [n_models] this step's counters (zeroed by the previous step)
     int* col_query;           // [n_models][nq]
-    int* active;              // queries that popped something and are still short of nb buckets
+    int* active;              // queries waiting for an expansion after this step
 };
 
 __global__ __launch_bounds__(256) void nav_pop_kernel(NavParams P) {
@@ -292,29 +350,37 @@ __global__ __launch_bounds__(256) void nav_pop_kernel(NavParams P) {
     if (q >= P.nq) return;
     int have = P.out_len[q];
     if (have >= P.nb) return;
-    const float* pp = P.pq_prob + (size_t)q * P.cap;
-    int* pe = P.pq_ent + (size_t)q * P.cap;
+    const float* pp = P.pq_prob + q;   // entry i at [i * nq]
+    int* pe = P.pq_ent + q;
     const int len = P.pq_len[q];
-    float best = 0.0f;
-    int bi = -1;
-    for (int i = 0; i < len; ++i) {
-        if (pe[i] < 0) continue;
-        const float v = pp[i];
-        if (bi < 0 || v >= best) { best = v; bi = i; }  // >=: the later entry wins a tie
+    // Bucket pops change nothing but the queue, so they continue within this step; the walk pauses at the first
+    // internal node (its children's probabilities come from this step's grouped MLP launch) -- the same sequence
+    // of pops as the reference's one-pop-per-iteration loop, in fewer launches.
+    for (;;) {
+        float best = 0.0f;
+        int bi = -1;
+        for (int i = 0; i < len; ++i) {
+            if (pe[(size_t)i * P.nq] < 0) continue;
+            const float v = pp[(size_t)i * P.nq];
+            if (bi < 0 || v >= best) { best = v; bi = i; }  // >=: the later entry wins a tie
+        }
+        if (bi < 0) return;  // queue exhausted: the remaining slots stay EMPTY (the reference would fail here)
+        const int ent = pe[(size_t)bi * P.nq];
+        pe[(size_t)bi * P.nq] = -1;
+        const int cm = P.child_model[ent], cb = P.child_bucket[ent];
+        if (cm >= 0) {
+            const int pos = atomicAdd(&P.node_count[cm], 1);
+            P.col_query[(size_t)cm * P.nq + pos] = q;
+            atomicAdd(P.active, 1);
+            return;
+        }
+        if (cb >= -1) {
+            P.out_slab[(size_t)q * P.nb + have] = cb;
+            P.out_ent[(size_t)q * P.nb + have] = ent;
+            P.out_len[q] = ++have;
+            if (have >= P.nb) return;
+        }
     }
-    if (bi < 0) return;  // queue exhausted: the remaining slots stay EMPTY (the reference would fail here)
-    const int ent = pe[bi];
-    pe[bi] = -1;
-    const int cm = P.child_model[ent], cb = P.child_bucket[ent];
-    if (cm >= 0) {
-        const int pos = atomicAdd(&P.node_count[cm], 1);
-        P.col_query[(size_t)cm * P.nq + pos] = q;
-    } else if (cb >= -1) {
-        P.out_slab[(size_t)q * P.nb + have] = cb;
-        P.out_ent[(size_t)q * P.nb + have] = ent;
-        P.out_len[q] = ++have;
-    }
-    if (have < P.nb) atomicAdd(P.active, 1);  // (hipcc folds a wave's increments into one atomic)
 }
 
 }  // namespace lmi
