@@ -4,6 +4,7 @@
 #include "lmi_kernels.h"
 #include "lmi_prefilter.h"
 #include "lmi_mlp_fused.h"
+#include "lmi_rescore.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -123,7 +124,8 @@ struct lmi_index {
     bool have16 = false;     // slab16 built by lmi_buckets_end
     int KG16 = 0;
     DevBuf slab16, rowmajor, xscale, xmaxbits, bnorm, bdelta, qdelta;
-    DevBuf qnorm, qscale, qfrag16, eps2, cand_cnt, cand_row, cand_s, fallback, pf_bound, nkeep;
+    DevBuf qnorm, qscale, qfrag16, eps2, cand_cnt, cand_row, cand_s, fallback, pf_bound, nkeep, surv_row;
+    bool rescore_streamed = true;  // lmi_rescore.h (LMI_RESCORE_SIMPLE=1 in the environment: select_rescore_kernel)
     int last_nslots = 0, last_nb = 0;
     bool last_fast = false;
     bool debug_emit_all = false;  // lmi_debug_emit_all
@@ -192,6 +194,7 @@ extern "C" LMI_API int lmi_create(int device, lmi_index** out) {
         h->pf_hw_ok = cached == 1;
         if (!h->pf_hw_ok) h->prefilter = false;
     }
+    if (const char* e = getenv("LMI_RESCORE_SIMPLE")) h->rescore_streamed = !(e[0] && e[0] != '0');
     *out = h;
     return 0;
 }
@@ -209,7 +212,7 @@ extern "C" LMI_API int lmi_destroy(lmi_index* h) {
                       &h->rank_id, &h->out_d, &h->out_id, &h->out_key};
     for (DevBuf* b : bufs) b->release();
     for (auto& m : h->node_models) { for (auto& b : m.Wf) b.release(); for (auto& b : m.bias) b.release(); }
-    DevBuf* nav[] = {&h->d_models, &h->d_child_offset, &h->d_child_model, &h->d_child_bucket, &h->pq_prob, &h->pq_ent, &h->pq_len,
+    DevBuf* nav[] = {&h->d_models, &h->d_child_offset, &h->d_child_model, &h->d_child_bucket, &h->pq_prob, &h->pq_ent, &h->pq_len, &h->surv_row,
                      &h->nav_len, &h->nav_slab, &h->nav_ent, &h->nav_count, &h->nav_colq, &h->nav_active};
     for (DevBuf* b : nav) b->release();
     for (int r = 0; r < lmi_index::EV_RING; ++r)
@@ -981,8 +984,32 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         Q.fallback = h->fallback.as<int>();
         Q.nkeep = h->nkeep.as<int>();
 #ifndef LMI_ABL_NOEMIT  // timing-only ablation builds emit nothing: no re-rank, no fallback
-        select_rescore_kernel<<<cdiv(nslots, RS_WAVES), 64 * RS_WAVES, 0, h->stream>>>(Q);
-        HIPCHK(hipGetLastError());
+        if (h->rescore_streamed && h->d % 4 == 0 && h->d <= RS_MAXD) {
+            // selection at full occupancy, then the survivors' rows streamed through LDS in coalesced pieces (lmi_rescore.h)
+            CHK(h->surv_row.reserve((size_t)nslots * PF_KEEP * 4));
+            SelectOut O;
+            O.surv_row = h->surv_row.as<unsigned>();
+            select_kernel<<<cdiv(nslots, 4), 256, 0, h->stream>>>(Q, O);
+            HIPCHK(hipGetLastError());
+            const int G = nb % 4 == 0 ? 4 : nb % 3 == 0 ? 3 : nb % 2 == 0 ? 2 : 1;  // slots of one query per wave
+            const int blocks = cdiv(cdiv(nslots, G), RC_WAVES);
+            const int lds = RC_WAVES * rc_wave_lds(h->d, G);
+#define LMI_RC_LAUNCH(GV)                                                                                              \
+            {                                                                                                          \
+                static bool attr_set = false;                                                                          \
+                if (!attr_set) {                                                                                       \
+                    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<GV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+                    attr_set = true;                                                                                   \
+                }                                                                                                      \
+                rescore_kernel<GV><<<blocks, 64 * RC_WAVES, lds, h->stream>>>(Q, O);                                   \
+            }
+            if (G == 4) LMI_RC_LAUNCH(4) else if (G == 3) LMI_RC_LAUNCH(3) else if (G == 2) LMI_RC_LAUNCH(2) else LMI_RC_LAUNCH(1)
+#undef LMI_RC_LAUNCH
+            HIPCHK(hipGetLastError());
+        } else {
+            select_rescore_kernel<<<cdiv(nslots, RS_WAVES), 64 * RS_WAVES, 0, h->stream>>>(Q);
+            HIPCHK(hipGetLastError());
+        }
 #endif
         CHK(record(h, 7));
 #ifndef LMI_ABL_NOEMIT

@@ -1,0 +1,260 @@
+// lmi_rescore.h -- exact re-rank of the prefilter's survivors, memory-efficient form (gfx950).
+//
+// select_rescore_kernel (lmi_prefilter.h) lets every lane pull ITS survivor's row straight from global memory,
+// 128 bytes per step.  rocprofv3 (profiles/r02_rescore_pmc.txt): 25 M L2 requests of 64 bytes per launch for
+// 1.36 GB, 86 % misses -- the DRAM sees isolated 64-byte accesses to random 3-KiB rows and delivers 2.2 TB/s;
+// packing more chains into a wave changed nothing (the access shape, not the lane count, was the limit).
+// Here the work is split:
+//   select_kernel    one wave per (query, rank) slot: That by bisection on the candidates' keys, the survivor
+//                    rows -> surv_row[slot][..] (the first half of select_rescore_kernel, at full occupancy);
+//   rescore_kernel   one wave per G slots of ONE query (G | n_buckets, <= 4), one wave per SIMD.  The wave's
+//                    survivors are processed 32 rows at a time; their rows are STREAMED through LDS in chunks of
+//                    128 floats: one LDS-DMA piece moves 1 KiB = 512 contiguous bytes of two rows (lane -> (row,
+//                    16-byte segment), rows 528 bytes apart in LDS so that the 32 chains' ds_read_b128 hit distinct
+//                    banks), chunk c+1 is in flight while lane r runs the canonical chain acc = fmaf(q[k], x[k], acc)
+//                    over chunk c of row r (q broadcast from LDS).  The wave owns its buffers: no barriers, the
+//                    ring is ordered by the wave's own counted `s_waitcnt vmcnt`.  Then, per slot, the 10 best by
+//                    (score desc, row asc) become the slot's rank list exactly as before.
+// Used when d % 4 == 0 and d <= RS_MAXD; other shapes keep select_rescore_kernel.  Results are bit-identical
+// (same chain, same selection rule); tests/test_gpu_prefilter.py runs both.
+#pragma once
+#include "lmi_prefilter.h"
+
+namespace lmi {
+
+constexpr int RC_ROWS = 32;                       // chains per wave and batch
+constexpr int RC_CHUNK = 128;                     // floats of a row per chunk
+constexpr int RC_PITCH = RC_CHUNK * 4 + 16;       // bytes between rows in a chunk buffer (bank spread)
+constexpr int RC_PIECES = (RC_ROWS * RC_PITCH + 1023) / 1024;  // 17 LDS-DMA pieces per chunk (16 896 bytes of rows)
+constexpr int RC_BUF = RC_PIECES * 1024;          // a chunk buffer holds WHOLE pieces: the last one writes 512 bytes past the rows
+constexpr int RC_WAVES = 4;
+
+struct SelectOut {
+    unsigned* surv_row;  // [nslots][PF_KEEP]
+};
+
+// That + survivors of one slot; unvisited slots get their (inf, 0) rank list here.
+__global__ __launch_bounds__(256) void select_kernel(RescoreParams P, SelectOut O) {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + wv;
+    if (p >= P.nslots) return;
+    const float FMAXV = 3.402823466e+38f;
+    const int col = P.slot_col[p];
+    if (lane == 0) { P.fallback[p] = 0; P.nkeep[p] = 0; }
+    if (col < 0) {  // unvisited (LearnedIndex.py:340-341)
+        if (lane < KPB) {
+            P.rank_d[(size_t)p * KPB + lane] = P.raw ? -FMAXV : INFINITY;
+            P.rank_id[(size_t)p * KPB + lane] = P.raw ? NOROW : 0u;
+        }
+        return;
+    }
+    const float* cs = P.cand_s + (size_t)col * PF_CAP;
+    const unsigned* cr = P.cand_row + (size_t)col * PF_CAP;
+    constexpr int PER = PF_CAP / 64;
+    constexpr int SPEC = 4;  // the first 256 candidates (a slot emits ~160) are requested together with the count:
+                             // three dependent memory round trips (column -> count -> scores -> rows) become two
+    float s_spec[SPEC];
+    unsigned r_spec[SPEC];
+#pragma unroll
+    for (int i = 0; i < SPEC; ++i) { s_spec[i] = cs[lane + 64 * i]; r_spec[i] = cr[lane + 64 * i]; }
+    const unsigned cnt = P.cand_cnt[col];
+    if (cnt > (unsigned)PF_CAP) {
+        if (lane == 0) P.fallback[p] = 1;
+        return;
+    }
+    const int nper = (int)((cnt + 63u) >> 6);
+    unsigned key[PER];  // monotone image of shat; 0 = no candidate
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int e = lane + 64 * i;
+        key[i] = 0u;
+        if (i < nper && e < (int)cnt) {
+            const unsigned bits = __float_as_uint(i < SPEC ? s_spec[i < SPEC ? i : 0] : cs[e]);
+            key[i] = bits ^ ((bits >> 31) ? 0xffffffffu : 0x80000000u);
+        }
+    }
+    float pv = -INFINITY;  // fewer than 10 candidates: everything survives
+    if (cnt >= (unsigned)KPB) {
+        unsigned T = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned probe = T | (1u << bit);
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < PER; ++i)
+                if (i < nper) c += (int)__popcll(__ballot(key[i] >= probe));
+            if (c >= KPB) T = probe;
+        }
+        pv = __uint_as_float(T ^ ((T >> 31) ? 0x80000000u : 0xffffffffu));
+    }
+    const float cut = pv - P.eps2[col];
+    const unsigned cbits = __float_as_uint(cut);
+    const unsigned kcut = cut != cut ? 1u : cbits ^ ((cbits >> 31) ? 0xffffffffu : 0x80000000u);
+    unsigned* out = O.surv_row + (size_t)p * PF_KEEP;
+    unsigned nk = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        if (i < nper) {
+            const bool keep = key[i] != 0u && key[i] >= kcut;
+            const unsigned long long bal = __ballot(keep);
+            if (keep) {
+                const unsigned k = nk + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+                if (k < (unsigned)PF_KEEP) out[k] = i < SPEC ? r_spec[i < SPEC ? i : 0] : cr[lane + 64 * i];
+            }
+            nk += (unsigned)__popcll(bal);
+        }
+    }
+    if (lane == 0) {
+        if (nk > (unsigned)PF_KEEP) P.fallback[p] = 1;
+        else P.nkeep[p] = (int)nk;
+    }
+}
+
+// dynamic LDS per wave: 2 chunk buffers | q [d] | rows [G*PF_KEEP] | scores [G*PF_KEEP]
+__host__ __device__ inline int rc_wave_lds(int d, int G) { return 2 * RC_BUF + d * 4 + G * PF_KEEP * 8; }
+
+template <int G>
+__global__ __launch_bounds__(64 * RC_WAVES, 1) void rescore_kernel(RescoreParams P, SelectOut O) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rc_smem[];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int p0 = (blockIdx.x * RC_WAVES + wv) * G;
+    if (p0 >= P.nslots) return;
+    const int d = P.d;
+    unsigned char* mine = rc_smem + (size_t)wv * rc_wave_lds(d, G);
+    unsigned char* buf0 = mine;
+    unsigned char* buf1 = mine + RC_BUF;
+    float* qs = reinterpret_cast<float*>(mine + 2 * RC_BUF);
+    unsigned* krow = reinterpret_cast<unsigned*>(mine + 2 * RC_BUF + d * 4);
+    float* ksc = reinterpret_cast<float*>(krow + G * PF_KEEP);
+    const float FMAXV = 3.402823466e+38f;
+    // the wave's query (G divides nb: one query per wave) and the survivor lists of its slots, slot after slot
+    const float* qg = P.q + (size_t)(p0 / P.nb) * d;
+    for (int k = lane * 4; k < d; k += 256) *reinterpret_cast<float4*>(qs + k) = *reinterpret_cast<const float4*>(qg + k);
+    int off[G + 1];
+    off[0] = 0;
+#pragma unroll
+    for (int sl = 0; sl < G; ++sl) {
+        const int p = p0 + sl;
+        const int nk = (P.slot_col[p] >= 0 && !P.fallback[p]) ? P.nkeep[p] : 0;   // wave-uniform
+        if (lane < nk) krow[off[sl] + lane] = O.surv_row[(size_t)p * PF_KEEP + lane];
+        off[sl + 1] = off[sl] + nk;
+    }
+    const int total = off[G];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int nchunks = (d + RC_CHUNK - 1) / RC_CHUNK;
+    const unsigned qaddr = (unsigned)reinterpret_cast<uintptr_t>(qs);
+    for (int base = 0; base < total; base += RC_ROWS) {
+        const int nrows = min(RC_ROWS, total - base);
+        // DMA plan: piece pc, lane i writes LDS bytes [pc*1024 + 16 i, +16) of the chunk buffer = row r, byte col of the
+        // 528-byte pitch; its source is row r's chunk + col.  (r, col) do not depend on the chunk: one source
+        // pointer per piece, advanced by 512 bytes per chunk.  Lanes in the pad column or past the batch read the
+        // first row's segment again (an L2 hit nobody uses).
+        const float* src[RC_PIECES];
+        unsigned colb[RC_PIECES];
+#pragma unroll
+        for (int pc = 0; pc < RC_PIECES; ++pc) {
+            const int o = pc * 1024 + lane * 16;
+            const int r = o / RC_PITCH;
+            const int cb = o - r * RC_PITCH;
+            const bool okl = r < nrows && cb < RC_CHUNK * 4;
+            int sl = 0;
+            const int i = base + (okl ? r : 0);
+#pragma unroll
+            for (int t = 1; t < G; ++t) sl += i >= off[t] ? 1 : 0;
+            const int b = P.bucket_order[p0 + sl];
+            src[pc] = P.rows + ((size_t)P.rb_start[b] * 32 + krow[i]) * d + (okl ? cb / 4 : 0);
+            colb[pc] = okl ? (unsigned)cb : 0u;
+        }
+        auto issue = [&](int c, unsigned char* buf) {
+            const int cbytes = min(RC_CHUNK, d - c * RC_CHUNK) * 4;  // the last chunk of a row may be short
+#pragma unroll
+            for (int pc = 0; pc < RC_PIECES; ++pc) {
+                // a lane past the row's end re-reads the row's first bytes of this chunk (kept inside the row)
+                const float* s = src[pc] + c * RC_CHUNK - ((int)colb[pc] < cbytes ? 0 : (int)colb[pc] / 4);
+                glds16(reinterpret_cast<const float4*>(s), reinterpret_cast<float4*>(buf + pc * 1024));
+            }
+        };
+        float acc = 0.0f;
+        issue(0, buf0);
+        for (int c = 0; c < nchunks; ++c) {
+            unsigned char* cur = (c & 1) ? buf1 : buf0;
+            if (c + 1 < nchunks) {
+                issue(c + 1, (c & 1) ? buf0 : buf1);
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(RC_PIECES) : "memory");  // chunk c landed, c+1 may be out
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (lane < nrows) {
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                const unsigned xa = (unsigned)reinterpret_cast<uintptr_t>(cur) + (unsigned)lane * RC_PITCH;
+                const unsigned qa = qaddr + (unsigned)c * RC_CHUNK * 4u;
+                const int nsteps = (min(RC_CHUNK, d - c * RC_CHUNK) + 31) / 32;   // 32 floats per step
+                const int tail = min(RC_CHUNK, d - c * RC_CHUNK) - (nsteps - 1) * 32;  // floats of the last step (multiple of 4)
+                for (int st = 0; st < nsteps; ++st) {
+                    f32x4 xv[8], qq[8];
+                    const unsigned xo = xa + st * 128u, qo = qa + st * 128u;
+                    // asm reads: hipcc would order a visible ds_read behind every pending LDS-DMA (vmcnt(0))
+                    asm volatile("ds_read_b128 %0, %16\n\tds_read_b128 %1, %16 offset:16\n\tds_read_b128 %2, %16 offset:32\n\t"
+                                 "ds_read_b128 %3, %16 offset:48\n\tds_read_b128 %4, %16 offset:64\n\tds_read_b128 %5, %16 offset:80\n\t"
+                                 "ds_read_b128 %6, %16 offset:96\n\tds_read_b128 %7, %16 offset:112\n\t"
+                                 "ds_read_b128 %8, %17\n\tds_read_b128 %9, %17 offset:16\n\tds_read_b128 %10, %17 offset:32\n\t"
+                                 "ds_read_b128 %11, %17 offset:48\n\tds_read_b128 %12, %17 offset:64\n\tds_read_b128 %13, %17 offset:80\n\t"
+                                 "ds_read_b128 %14, %17 offset:96\n\tds_read_b128 %15, %17 offset:112\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(xv[0]), "=&v"(xv[1]), "=&v"(xv[2]), "=&v"(xv[3]), "=&v"(xv[4]), "=&v"(xv[5]), "=&v"(xv[6]), "=&v"(xv[7]),
+                                   "=&v"(qq[0]), "=&v"(qq[1]), "=&v"(qq[2]), "=&v"(qq[3]), "=&v"(qq[4]), "=&v"(qq[5]), "=&v"(qq[6]), "=&v"(qq[7])
+                                 : "v"(xo), "v"(qo) : "memory");
+                    const int nv = st + 1 < nsteps ? 8 : tail / 4;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        if (t < nv) {
+                            acc = __builtin_fmaf(qq[t].x, xv[t].x, acc); acc = __builtin_fmaf(qq[t].y, xv[t].y, acc);
+                            acc = __builtin_fmaf(qq[t].z, xv[t].z, acc); acc = __builtin_fmaf(qq[t].w, xv[t].w, acc);
+                        }
+                    }
+                }
+            }
+        }
+        if (lane < nrows) ksc[base + lane] = acc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // rank lists: a survivor's position = the number of survivors of ITS slot that beat it by (score desc, row asc)
+    for (int base = 0; base < total; base += 64) {
+        const int i = base + lane;
+        if (i < total) {
+            int sl = 0;
+#pragma unroll
+            for (int t = 1; t < G; ++t) sl += i >= off[t] ? 1 : 0;
+            int lo = off[0], hi = off[1];
+#pragma unroll
+            for (int t = 1; t < G; ++t) { lo = sl == t ? off[t] : lo; hi = sl == t ? off[t + 1] : hi; }
+            const float sc = ksc[i];
+            const unsigned row = krow[i];
+            int pos = 0;
+            for (int j = lo; j < hi; ++j) pos += better(ksc[j], krow[j], sc, row) ? 1 : 0;
+            if (pos < KPB) {
+                const int p = p0 + sl;
+                const int b = P.bucket_order[p];
+                P.rank_d[(size_t)p * KPB + pos] = P.raw ? sc : 1.0f - sc;
+                P.rank_id[(size_t)p * KPB + pos] = P.raw ? row : P.ids_slab[(size_t)P.rb_start[b] * 32 + row];
+            }
+        }
+    }
+    // faiss padding (Q4) of short lists: -FLT_MAX similarity, last id of the bucket
+    if (lane < KPB) {
+#pragma unroll
+        for (int sl = 0; sl < G; ++sl) {
+            const int p = p0 + sl;
+            if (P.slot_col[p] < 0 || P.fallback[p]) continue;  // written by select_kernel / recomputed by fallback_kernel
+            const int b = P.bucket_order[p];
+            const int rb0 = P.rb_start[b], n_b = P.nb_rows[b];
+            const int nreal = min(min(off[sl + 1] - off[sl], KPB), n_b);
+            if (lane >= nreal) {
+                P.rank_d[(size_t)p * KPB + lane] = P.raw ? -FMAXV : 1.0f - (-FMAXV);
+                P.rank_id[(size_t)p * KPB + lane] = P.raw ? NOROW : P.ids_slab[(size_t)rb0 * 32 + (n_b - 1)];
+            }
+        }
+    }
+}
+
+}  // namespace lmi
