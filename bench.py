@@ -159,7 +159,14 @@ class Workload:
 
         eng, world, rank, dev = self.eng, self.world, self.rank, self.dev
         nb, nq, d, k = self.cfg["nb"], self.cfg["nq"], self.cfg["d"], self.args.k
-        searcher = ShardedSearcher(eng, rank, world, shard_inference=shard_inference)
+        lib_comm = None
+        if world > 1 and os.environ.get("LMI_BENCH_LIBCOMM"):  # result exchange by lmi_allgather_merge (RCCL inside the library)
+            if getattr(self, "_lib_comm", None) is None:
+                ids = [self.eng.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                self._lib_comm = eng.comm_init(rank, world, ids[0])
+            lib_comm = self._lib_comm
+        searcher = ShardedSearcher(eng, rank, world, shard_inference=shard_inference, lib_comm=lib_comm)
 
         def sync_all():
             torch.cuda.synchronize()

@@ -162,6 +162,22 @@ LMI_API int lmi_merge_gathered(lmi_index *h, const float *gathered_dists, const 
  * Replaces the `.cpu().numpy()` of model.py:240-241 / the numpy results of LearnedIndex.py:340-341. */
 LMI_API int lmi_copy_out(lmi_index *h, void *dst, const void *src, int64_t bytes);
 
+/* The same exchange through RCCL inside the library (no reference counterpart; SURVEY 8b `lmi_allgather_merge(h,
+ * ncclComm_t, ...)`): a C/C++ caller runs the bucket-sharded mode without torch.distributed.
+ *   lmi_comm_unique_id   rank 0: 128 bytes (ncclUniqueId) to hand to every rank by any side channel
+ *   lmi_comm_init        every rank: *comm <- ncclComm_t over `world` ranks on the handle's device (collective call)
+ *   lmi_allgather_merge  every rank: its lmi_scan_topk / lmi_search outputs (DEVICE pointers [nq][kout], keys
+ *                        included) -> ONE ncclAllGather of the packed [dists|ids|keys] block on the handle's stream
+ *                        -> merge kernel -> dists/ids [nq][kout] (device), identical on every rank.  `comm` may be
+ *                        any ncclComm_t of the process (e.g. PyTorch's).
+ * RCCL is resolved at run time (the process image, else librccl.so); the calls fail cleanly when it is absent. */
+LMI_API int lmi_comm_unique_id(void *id128);
+LMI_API int lmi_comm_init(lmi_index *h, int rank, int world, const void *id128, void **comm);
+LMI_API int lmi_comm_destroy(void *comm);
+LMI_API int lmi_allgather_merge(lmi_index *h, void *comm, int rank, int world, const float *local_dists,
+                        const uint32_t *local_ids, const uint32_t *local_keys, int nq, int kout, float *dists,
+                        uint32_t *ids);
+
 /* faiss.knn(xq, xb, k, metric=METRIC_INNER_PRODUCT) on host pointers: D[nq][k] similarities in
  * descending order, I[nq][k] row numbers; nb < k pads with D = -FLT_MAX, I = -1.  k <= 10. */
 LMI_API int lmi_knn_ip(int device, const float *xq, int64_t nq, const float *xb, int64_t nb, int d, int k,

@@ -52,6 +52,11 @@ SIGNATURES = {
                                   ctypes.c_int]),
     "lmi_merge_gathered": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
                                           ctypes.c_int, _vp, _vp, ctypes.c_int]),
+    "lmi_comm_unique_id": (ctypes.c_int, [_vp]),
+    "lmi_comm_init": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.POINTER(_vp)]),
+    "lmi_comm_destroy": (ctypes.c_int, [_vp]),
+    "lmi_allgather_merge": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int,
+                                           _vp, _vp]),
     "lmi_bucket_read": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp]),
     "lmi_copy_out": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64]),
     "lmi_knn_ip": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int64, _vp, ctypes.c_int64, ctypes.c_int,
@@ -335,6 +340,29 @@ class Index:
         assert dst_pinned_t.is_pinned() and dst_pinned_t.numel() * dst_pinned_t.element_size() == nbytes
         assert src_dev_t.is_contiguous() and dst_pinned_t.is_contiguous()
         _check(lib().lmi_copy_out(self._h, _ptr(dst_pinned_t), _ptr(src_dev_t), nbytes))
+
+    # ---- RCCL inside the library (the sharded exchange without torch.distributed) ----------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(128)
+        _check(lib().lmi_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, rank: int, world: int, unique_id: bytes):
+        """ncclComm_t (opaque pointer) over `world` ranks; collective: every rank calls it with rank 0's id."""
+        comm = _vp()
+        _check(lib().lmi_comm_init(self._h, int(rank), int(world), ctypes.c_char_p(unique_id), ctypes.byref(comm)))
+        return comm
+
+    @staticmethod
+    def comm_destroy(comm) -> None:
+        _check(lib().lmi_comm_destroy(comm))
+
+    def allgather_merge(self, comm, rank: int, world: int, d_t, i_t, k_t, out_d_t, out_i_t) -> None:
+        """This rank's [nq, kout] device tensors (dists, ids, keys) -> merged (dists, ids) on every rank."""
+        nq, kout = int(d_t.shape[0]), int(d_t.shape[1])
+        _check(lib().lmi_allgather_merge(self._h, comm, int(rank), int(world), _ptr(d_t), _ptr(i_t), _ptr(k_t), nq, kout,
+                                         _ptr(out_d_t), _ptr(out_i_t)))
 
     def read_bucket(self, b: int, rows_out=None, ids_out=None):
         """(rows f32[n_b,d], ids u32[n_b]) of bucket b, in bucket order; `rows_out` / `ids_out`: C-contiguous

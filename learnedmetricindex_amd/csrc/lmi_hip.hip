@@ -11,11 +11,13 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
 #include <mutex>
 #include <string>
 #include <vector>
 
 #include "lmi_hip.h"
+#include <rccl/rccl.h>  // types only: the functions are resolved at run time (lmi_comm_*), the library does not link RCCL
 
 using namespace lmi;
 
@@ -104,6 +106,7 @@ struct lmi_index {
     std::vector<int> h_child_offset, h_child_model, h_child_bucket;
     DevBuf d_child_offset, d_child_model, d_child_bucket;
     bool tree_set = false;
+    DevBuf gather_send, gather_recv;      // lmi_allgather_merge
     DevBuf pq_prob, pq_ent, pq_len, nav_len, nav_slab, nav_ent, nav_count, nav_colq, nav_active;
 
     // ---- buckets ----
@@ -212,7 +215,7 @@ extern "C" LMI_API int lmi_destroy(lmi_index* h) {
                       &h->rank_id, &h->out_d, &h->out_id, &h->out_key};
     for (DevBuf* b : bufs) b->release();
     for (auto& m : h->node_models) { for (auto& b : m.Wf) b.release(); for (auto& b : m.bias) b.release(); }
-    DevBuf* nav[] = {&h->d_models, &h->d_child_offset, &h->d_child_model, &h->d_child_bucket, &h->pq_prob, &h->pq_ent, &h->pq_len, &h->surv_row,
+    DevBuf* nav[] = {&h->d_models, &h->d_child_offset, &h->d_child_model, &h->d_child_bucket, &h->pq_prob, &h->pq_ent, &h->pq_len, &h->surv_row, &h->gather_send, &h->gather_recv,
                      &h->nav_len, &h->nav_slab, &h->nav_ent, &h->nav_count, &h->nav_colq, &h->nav_active};
     for (DevBuf* b : nav) b->release();
     for (int r = 0; r < lmi_index::EV_RING; ++r)
@@ -1167,6 +1170,101 @@ extern "C" LMI_API int lmi_merge_gathered(lmi_index* h, const float* gd, const u
     HIPCHK(hipStreamSynchronize(h->stream));
     in.release();
     out.release();
+    return 0;
+}
+
+// ---- RCCL (resolved from the process image -- PyTorch-ROCm has it loaded -- or from librccl.so) ----------------
+namespace {
+struct Rccl {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+Rccl* rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void* lib = RTLD_DEFAULT;
+        if (!dlsym(lib, "ncclAllGather")) {
+            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"})
+                if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+            if (!lib) return;
+        }
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(lib, "ncclAllGather"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+        r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather;
+    });
+    return &r;
+}
+int rccl_fail(const char* what, ncclResult_t e) {
+    Rccl* r = rccl();
+    return fail("%s failed: %s", what, r->GetErrorString ? r->GetErrorString(e) : "RCCL error");
+}
+}  // namespace
+
+extern "C" LMI_API int lmi_comm_unique_id(void* id128) {
+    if (!id128) return fail("lmi_comm_unique_id: NULL buffer");
+    if (!rccl()->ok) return fail("lmi_comm_unique_id: RCCL (librccl.so) is not available in this process");
+    ncclUniqueId id;
+    ncclResult_t e = rccl()->GetUniqueId(&id);
+    if (e != ncclSuccess) return rccl_fail("ncclGetUniqueId", e);
+    memcpy(id128, &id, sizeof(id));
+    return 0;
+}
+
+extern "C" LMI_API int lmi_comm_init(lmi_index* h, int rank, int world, const void* id128, void** comm) {
+    if (!h || !id128 || !comm) return fail("lmi_comm_init: NULL argument");
+    if (world < 1 || world > 64 || rank < 0 || rank >= world) return fail("lmi_comm_init: rank %d of %d", rank, world);
+    if (!rccl()->ok) return fail("lmi_comm_init: RCCL (librccl.so) is not available in this process");
+    CHK(set_dev(h));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclComm_t c = nullptr;
+    ncclResult_t e = rccl()->CommInitRank(&c, world, id, rank);
+    if (e != ncclSuccess) return rccl_fail("ncclCommInitRank", e);
+    *comm = c;
+    return 0;
+}
+
+extern "C" LMI_API int lmi_comm_destroy(void* comm) {
+    if (!comm) return 0;
+    if (!rccl()->ok) return fail("lmi_comm_destroy: RCCL is not available");
+    ncclResult_t e = rccl()->CommDestroy(static_cast<ncclComm_t>(comm));
+    return e == ncclSuccess ? 0 : rccl_fail("ncclCommDestroy", e);
+}
+
+// The exchange step of the bucket-sharded mode through the C ABI alone: this rank's lmi_scan_topk /
+// lmi_search outputs (device pointers, [nq][kout] each) -> ONE ncclAllGather of the packed [dists | ids | keys] block
+// over `comm` on the handle's stream -> merge_gathered_kernel -> dists / ids [nq][kout] (device), identical on
+// every rank and to the single-GPU result.
+extern "C" LMI_API int lmi_allgather_merge(lmi_index* h, void* comm, int rank, int world, const float* local_dists,
+                                   const uint32_t* local_ids, const uint32_t* local_keys, int nq, int kout, float* dists,
+                                   uint32_t* ids) {
+    if (!h || !comm) return fail("lmi_allgather_merge: NULL handle/communicator");
+    if (world < 1 || world > 64 || rank < 0 || rank >= world) return fail("lmi_allgather_merge: rank %d of %d", rank, world);
+    if (nq <= 0 || kout < 1) return nq == 0 ? 0 : fail("lmi_allgather_merge: bad nq/kout");
+    if (!rccl()->ok) return fail("lmi_allgather_merge: RCCL (librccl.so) is not available in this process");
+    CHK(set_dev(h));
+    const size_t plane = (size_t)nq * kout;
+    CHK(h->gather_send.reserve(3 * plane * 4));
+    CHK(h->gather_recv.reserve((size_t)world * 3 * plane * 4));
+    char* snd = h->gather_send.as<char>();
+    HIPCHK(hipMemcpyAsync(snd, local_dists, plane * 4, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(snd + plane * 4, local_ids, plane * 4, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(snd + 2 * plane * 4, local_keys, plane * 4, hipMemcpyDeviceToDevice, h->stream));
+    ncclResult_t e = rccl()->AllGather(snd, h->gather_recv.p, 3 * plane, ncclInt32, static_cast<ncclComm_t>(comm), h->stream);
+    if (e != ncclSuccess) return rccl_fail("ncclAllGather", e);
+    const char* rcv = h->gather_recv.as<char>();
+    merge_gathered_kernel<<<nq, 64, 0, h->stream>>>(reinterpret_cast<const float*>(rcv), reinterpret_cast<const unsigned*>(rcv + plane * 4),
+                                                   reinterpret_cast<const unsigned*>(rcv + 2 * plane * 4), world, (long long)(3 * plane),
+                                                   nq, kout, dists, ids);
+    HIPCHK(hipGetLastError());
     return 0;
 }
 

@@ -1,11 +1,14 @@
 """Bucket-sharded multi-GPU search (no counterpart in the reference).
 
 One process per GPU.  Bucket b lives on rank owner[b]; the MLP weights and the query batch are
-replicated, every rank runs the (cheap) MLP itself and scans only the (query, rank) pairs whose
-bucket it owns, then ONE all-gather (RCCL over xGMI; `gloo` in the CPU tests) moves every rank's
-`[dists | ids | keys]` block of nq*k*12 bytes and a merge kernel orders the union by
-(distance, bucket rank, position) -- the same total order the single-GPU merge uses, so results
-are byte-identical for every world size.
+replicated; every rank scans only the (query, rank) pairs whose bucket it owns, then an all-gather
+(RCCL over xGMI; `gloo` in the CPU tests) moves every rank's `[dists | ids | keys]` block of nq*k*12
+bytes and a merge kernel orders the union by (distance, bucket rank, position) -- the same total
+order the single-GPU merge uses, so results are byte-identical for every world size.
+Two layouts of the routing step (`ShardedSearcher(shard_inference=...)`):
+  * False: every rank runs the MLP on the whole batch -- ONE collective per search (the all-gather above);
+  * True (default for world > 1): every rank routes its 1/world slice of the batch and the bucket order
+    (nq*nb*4 bytes) is all-gathered first -- TWO small collectives, 1/world of the MLP work per rank.
 """
 from __future__ import annotations
 
@@ -120,8 +123,11 @@ class ShardedSearcher:
     (at 8 ranks the replicated MLP was a sixth of a rank's step).  `calls_per_search` tells a caller that
     averages `Index.timings_mean()` how many C-ABI calls one search makes."""
 
-    def __init__(self, index, rank: int, world: int, group=None, shard_inference: bool = True):
+    def __init__(self, index, rank: int, world: int, group=None, shard_inference: bool = True, lib_comm=None):
+        """`lib_comm`: an ncclComm_t from `Index.comm_init` -- the result exchange then runs inside the library
+        (`lmi_allgather_merge`: ncclAllGather + merge kernel on the handle's stream) instead of torch.distributed."""
         self.index, self.rank, self.world, self.group = index, rank, world, group
+        self.lib_comm = lib_comm
         self.shard_inference = bool(shard_inference) and world > 1
         self.calls_per_search = 2 if self.shard_inference else 1
         self._buf = None
@@ -150,8 +156,11 @@ class ShardedSearcher:
             self.index.scan_topk_device(qs_t, bo, nb, k, blk[0], blk[1], blk[2])
         else:
             self.index.search_device(qn_t, qs_t, nb, k, blk[0], blk[1], blk[2], bo)
-        if self.world == 1:
+        if self.world == 1 and self.lib_comm is None:
             return blk[0].view(torch.float32), blk[1], bo
+        if self.lib_comm is not None:
+            self.index.allgather_merge(self.lib_comm, self.rank, self.world, blk[0], blk[1], blk[2], out_d, out_i)
+            return out_d, out_i, bo
         g = all_gather_blocks(blk, self.world, self.group)  # [world, 3, nq, kout]
         plane = nq * kout
         self.index.merge_gathered(g[0, 0], g[0, 1], g[0, 2], self.world, nq, kout, out_d, out_i,

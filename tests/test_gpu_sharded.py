@@ -89,3 +89,30 @@ def test_sharded_equals_single(oracle, name, nb, k, world):
     np.testing.assert_array_equal(hi, io)
     for h in handles + [single]:
         h.close()
+
+
+def test_library_rccl_exchange_world1(oracle):
+    """lmi_comm_* / lmi_allgather_merge: the exchange step through RCCL inside the library, exercised on the one test
+    GPU with a single-rank communicator (a real ncclCommInitRank + ncclAllGather on the handle's stream)."""
+    from learnedmetricindex_amd import _capi
+    from learnedmetricindex_amd.sharded import ShardedSearcher
+
+    g = load_golden("G3")
+    Xn, Qn, Xs, Qs = inputs_for("G3", g)
+    layers = layers_from(g)
+    dp = g["data_prediction"]
+    L = layers[-1][0].shape[0]
+    dev = torch.device("cuda", 0)
+    idx = _capi.Index(0)
+    idx.set_stream(torch.cuda.current_stream().cuda_stream)
+    idx.set_mlp(layers)
+    idx.set_buckets(Xs, dp[:, 0], L)
+    comm = idx.comm_init(0, 1, _capi.Index.comm_unique_id())
+    qn, qs = torch.from_numpy(Qn).to(dev), torch.from_numpy(Qs).to(dev)
+    d, i, bo = ShardedSearcher(idx, 0, 1, lib_comm=comm).search(qn, qs, 4, 10)
+    torch.cuda.synchronize()
+    do, io, _ = oracle.search(layers, Qn, Xs, Qs, dp, 4, 10, nthreads=4)
+    np.testing.assert_array_equal(i.cpu().numpy().view(np.uint32), io)
+    np.testing.assert_array_equal(d.cpu().numpy().astype(np.float64), do)
+    _capi.Index.comm_destroy(comm)
+    idx.close()
