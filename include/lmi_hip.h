@@ -45,6 +45,8 @@ extern "C" {
 
 #define LMI_ABI_VERSION 1
 #define LMI_API __attribute__((visibility("default")))
+#define LMI_METRIC_IP 0 /* dist = 1 - <q,x> : the reference's only metric (LearnedIndex.py:360-368) */
+#define LMI_METRIC_L2 1 /* dist = |q - x|^2, computed as |q|^2 - 2 (<q,x> - |x|^2/2); see lmi_set_metric */
 #define LMI_K_PER_BUCKET 10 /* LearnedIndex.py:334: k is never forwarded to the bucket scan */
 #define LMI_MAX_K 64
 #define LMI_MAX_LAYERS 8
@@ -100,6 +102,14 @@ LMI_API int lmi_nav_set_tree(lmi_index *h, int n_models, const int32_t *child_of
                      const int32_t *child_bucket);
 LMI_API int lmi_nav_order(lmi_index *h, const float *queries_nav, int nq, int nb, int32_t *slab_ids,
                   int32_t *entries, int on_device);
+
+/* Metric of the bucket scan (call before lmi_buckets_begin; default LMI_METRIC_IP).  The reference scans with
+ * faiss.METRIC_INNER_PRODUCT only (LearnedIndex.py:364); LMI_METRIC_L2 is what faiss.knn(..., METRIC_L2) would be in
+ * its place: squared Euclidean distances, ascending.  Canonical arithmetic (oracle/lmi_oracle.c:lmi_oracle_knn_l2):
+ * with the k-ordered fmaf chains s = <q,x>, xn = <x,x>, qn = <q,q>:  key = s + (-xn/2)  (one rounding),
+ * dist = fmaf(-2, key, qn);  neighbours by key descending, ties -> lower row; short buckets are padded with
+ * FLT_MAX.  Internally every stored vector carries the column -xn/2 (lmi_bucket_read does not return it). */
+LMI_API int lmi_set_metric(lmi_index *h, int metric);
 
 /* Bucket-contiguous index in HBM.
  * begin: labels[N] = data_prediction[:,0] (bucket of every object, 0 <= label < L), ids[N] = the

@@ -36,6 +36,7 @@ SIGNATURES = {
     "lmi_set_stream": (ctypes.c_int, [_vp, _vp]),
     "lmi_set_mlp": (ctypes.c_int, [_vp, ctypes.c_int, _i32p, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     "lmi_set_fused_mlp": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "lmi_set_metric": (ctypes.c_int, [_vp, ctypes.c_int]),
     "lmi_nav_set_model": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _i32p, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     "lmi_nav_set_tree": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp]),
     "lmi_nav_order": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int]),
@@ -121,7 +122,10 @@ def _np(a, dtype) -> np.ndarray:
 class Index:
     """One device-resident index: thin, typed wrapper over an `lmi_index*`."""
 
-    def __init__(self, device: int = 0, chunk_rows: Optional[int] = None, prefilter: Optional[bool] = None):
+    METRICS = {"ip": 0, "l2": 1}
+
+    def __init__(self, device: int = 0, chunk_rows: Optional[int] = None, prefilter: Optional[bool] = None,
+                 metric: str = "ip"):
         self._h = _vp()
         _check(lib().lmi_create(int(device), ctypes.byref(self._h)))
         self.device = int(device)
@@ -135,6 +139,9 @@ class Index:
             prefilter = os.environ["LMI_PREFILTER"] not in ("0", "off", "false")
         if prefilter is not None:
             self.set_prefilter(prefilter)
+        if metric != "ip":  # "l2": squared Euclidean distances instead of 1 - inner product
+            _check(lib().lmi_set_metric(self._h, self.METRICS[metric]))
+        self.metric = metric
 
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h:

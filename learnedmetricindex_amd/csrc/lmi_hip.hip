@@ -112,7 +112,9 @@ struct lmi_index {
     // ---- buckets ----
     bool building = false, built = false;
     int64_t N = 0;
-    int d = 0, L = 0, KGs = 0;
+    int d = 0, L = 0, KGs = 0;     // d: dims of the STORED vectors (L2 metric: user dims + the norm column, padded to 4)
+    int metric = 0, d_user = 0;    // lmi_set_metric; dims of the caller's vectors
+    DevBuf aug_rows, q_aug, qn2;   // L2: augmented ingest pieces / queries, |q|^2
     int chunk_rows = 2048;
     bool chunk_rows_auto = true;  // until lmi_set_chunk_rows: lmi_buckets_begin picks 256..2048 by the index size
     int64_t n_rb_total = 0;
@@ -215,7 +217,7 @@ extern "C" LMI_API int lmi_destroy(lmi_index* h) {
                       &h->rank_id, &h->out_d, &h->out_id, &h->out_key};
     for (DevBuf* b : bufs) b->release();
     for (auto& m : h->node_models) { for (auto& b : m.Wf) b.release(); for (auto& b : m.bias) b.release(); }
-    DevBuf* nav[] = {&h->d_models, &h->d_child_offset, &h->d_child_model, &h->d_child_bucket, &h->pq_prob, &h->pq_ent, &h->pq_len, &h->surv_row, &h->gather_send, &h->gather_recv,
+    DevBuf* nav[] = {&h->d_models, &h->d_child_offset, &h->d_child_model, &h->d_child_bucket, &h->pq_prob, &h->pq_ent, &h->pq_len, &h->surv_row, &h->gather_send, &h->gather_recv, &h->aug_rows, &h->q_aug, &h->qn2,
                      &h->nav_len, &h->nav_slab, &h->nav_ent, &h->nav_count, &h->nav_colq, &h->nav_active};
     for (DevBuf* b : nav) b->release();
     for (int r = 0; r < lmi_index::EV_RING; ++r)
@@ -237,6 +239,14 @@ extern "C" LMI_API int lmi_set_chunk_rows(lmi_index* h, int rows) {
     if (h->building || h->built) return fail("lmi_set_chunk_rows: must be called before lmi_buckets_begin");
     h->chunk_rows = rows;
     h->chunk_rows_auto = false;
+    return 0;
+}
+
+extern "C" LMI_API int lmi_set_metric(lmi_index* h, int metric) {
+    if (!h) return fail("lmi_set_metric: NULL handle");
+    if (metric != LMI_METRIC_IP && metric != LMI_METRIC_L2) return fail("lmi_set_metric: unknown metric %d", metric);
+    if ((h->built || h->building) && metric != h->metric) return fail("lmi_set_metric: the metric is fixed once lmi_buckets_begin has run");
+    h->metric = metric;
     return 0;
 }
 
@@ -422,7 +432,9 @@ extern "C" LMI_API int lmi_buckets_begin(lmi_index* h, int64_t N, int d, int L, 
     if (L > 8000) return fail("lmi_buckets_begin: %d buckets exceed the 8000 the routing kernels stage in LDS", L);
     CHK(set_dev(h));
     h->N = N;
-    h->d = d;
+    h->d_user = d;
+    h->d = h->metric == LMI_METRIC_L2 ? (int)rup(d + 1, 4) : d;  // L2: + the -|x|^2/2 column (sim_to_dist, lmi_kernels.h)
+    d = h->d;
     h->L = L;
     h->KGs = (int)rup(cdiv(d, 8), STAGE_G);
     h->built = false;
@@ -503,10 +515,10 @@ static int add_rows_impl(lmi_index* h, const float* rows, int64_t row0, const in
     const int64_t piece = std::max<int64_t>(1, (256ll << 20) / ((int64_t)h->d * 4));
     for (int64_t off = 0; off < nrows; off += piece) {
         const int64_t n = std::min(piece, nrows - off);
-        const float* src = rows + off * h->d;
+        const float* src = rows + off * h->d_user;
         const long long* idx = index ? reinterpret_cast<const long long*>(index + off) : nullptr;
         if (!on_device) {
-            const size_t row_bytes = (size_t)n * h->d * 4;
+            const size_t row_bytes = (size_t)n * h->d_user * 4;
             CHK(h->stage.reserve(row_bytes + (index ? (size_t)n * 8 : 0)));
             HIPCHK(hipMemcpyAsync(h->stage.p, src, row_bytes, hipMemcpyHostToDevice, h->stream));
             src = h->stage.as<float>();
@@ -514,6 +526,14 @@ static int add_rows_impl(lmi_index* h, const float* rows, int64_t row0, const in
                 HIPCHK(hipMemcpyAsync(h->stage.as<char>() + row_bytes, index + off, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
                 idx = reinterpret_cast<const long long*>(h->stage.as<char>() + row_bytes);
             }
+        }
+        if (h->metric == LMI_METRIC_L2) {  // the piece with its norm column, then ingested like any d-column piece
+            CHK(h->aug_rows.reserve((size_t)n * h->d * 4));
+            augment_copy_kernel<<<cdiv((long long)n * h->d, 256), 256, 0, h->stream>>>(src, h->d_user, h->d, n, h->aug_rows.as<float>());
+            HIPCHK(hipGetLastError());
+            augment_norm_kernel<<<cdiv(n, 256), 256, 0, h->stream>>>(src, h->d_user, h->d, n, h->aug_rows.as<float>(), nullptr);
+            HIPCHK(hipGetLastError());
+            src = h->aug_rows.as<float>();
         }
         if (h->prefilter) {
             long long total = (long long)n * h->d;
@@ -609,14 +629,16 @@ extern "C" LMI_API int lmi_bucket_read(lmi_index* h, int bucket, float* rows, ui
     if (n == 0) return 0;
     CHK(set_dev(h));
     const int64_t p0 = (int64_t)h->h_rb_start[bucket] * 32;
+    const int du = h->d_user;  // the caller's columns (the L2 norm column is not returned)
     if (rows && h->prefilter) {
-        HIPCHK(hipMemcpyAsync(rows, h->rowmajor.as<float>() + (size_t)p0 * h->d, (size_t)n * h->d * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpy2DAsync(rows, (size_t)du * 4, h->rowmajor.as<float>() + (size_t)p0 * h->d, (size_t)h->d * 4, (size_t)du * 4, (size_t)n,
+                                hipMemcpyDeviceToHost, h->stream));
     } else if (rows) {
-        CHK(h->stage.reserve((size_t)n * h->d * 4));
-        long long total = n * cdiv(h->d, 8);
-        unpack_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(h->slab.as<float4>(), h->KGs, p0, n, h->d, h->stage.as<float>());
+        CHK(h->stage.reserve((size_t)n * du * 4));
+        long long total = n * cdiv(du, 8);
+        unpack_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(h->slab.as<float4>(), h->KGs, p0, n, du, h->stage.as<float>());
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(rows, h->stage.p, (size_t)n * h->d * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(rows, h->stage.p, (size_t)n * du * 4, hipMemcpyDeviceToHost, h->stream));
     }
     if (ids) HIPCHK(hipMemcpyAsync(ids, h->ids_slab.as<uint32_t>() + p0, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -795,6 +817,17 @@ extern "C" LMI_API int lmi_mlp_proba(lmi_index* h, const float* queries_nav, int
 
 static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_order, int nb, int kout, int raw,
                         float* d_dists, uint32_t* d_ids, uint32_t* d_keys) {
+    const float* d_qn2 = nullptr;
+    if (h->metric == LMI_METRIC_L2) {  // queries [nq][d_user] -> [q, 1, 0..] of the stored width, |q|^2 aside
+        CHK(h->q_aug.reserve((size_t)nq * h->d * 4));
+        CHK(h->qn2.reserve((size_t)nq * 4));
+        augment_copy_kernel<<<cdiv((long long)nq * h->d, 256), 256, 0, h->stream>>>(d_qs, h->d_user, h->d, nq, h->q_aug.as<float>());
+        HIPCHK(hipGetLastError());
+        augment_norm_kernel<<<cdiv(nq, 256), 256, 0, h->stream>>>(d_qs, h->d_user, h->d, nq, h->q_aug.as<float>(), h->qn2.as<float>());
+        HIPCHK(hipGetLastError());
+        d_qs = h->q_aug.as<float>();
+        d_qn2 = h->qn2.as<float>();
+    }
     const int L = h->L;
     const int nslots = nq * nb;
     const long long ncb_bound = (long long)nslots / 32 + L + 4;
@@ -981,6 +1014,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         Q.eps2 = F.eps2;
         Q.rows = h->rowmajor.as<float>();
         Q.q = d_qs;
+        Q.qn2 = d_qn2;
         Q.ids_slab = h->ids_slab.as<unsigned>();
         Q.rank_d = h->rank_d.as<float>();
         Q.rank_id = h->rank_id.as<unsigned>();
@@ -1038,6 +1072,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     M.part_score = S.part_score;
     M.part_row = S.part_row;
     M.ids_slab = h->ids_slab.as<unsigned>();
+    M.qn2 = d_qn2;
     M.rank_d = h->rank_d.as<float>();
     M.rank_id = h->rank_id.as<unsigned>();
     M.out_d = d_dists;
@@ -1074,7 +1109,7 @@ extern "C" LMI_API int lmi_scan_topk(lmi_index* h, const float* queries_search, 
     CHK(set_dev(h));
     const void* d_qs = nullptr;
     const void* d_order = nullptr;
-    CHK(input_ptr(h, queries_search, (size_t)nq * h->d * 4, on_device, h->q_srch, &d_qs));
+    CHK(input_ptr(h, queries_search, (size_t)nq * h->d_user * 4, on_device, h->q_srch, &d_qs));
     CHK(input_ptr(h, bucket_order, (size_t)nq * nb * 4, on_device, h->order, &d_order));
     float* d_d = dists;
     uint32_t* d_i = ids;
@@ -1110,8 +1145,8 @@ extern "C" LMI_API int lmi_search(lmi_index* h, const float* queries_nav, const 
     const void* d_qn = nullptr;
     const void* d_qs = nullptr;
     CHK(input_ptr(h, queries_nav, (size_t)nq * h->dims[0] * 4, on_device, h->q_nav, &d_qn));
-    if (queries_search == queries_nav && h->dims[0] == h->d) d_qs = d_qn;
-    else CHK(input_ptr(h, queries_search, (size_t)nq * h->d * 4, on_device, h->q_srch, &d_qs));
+    if (queries_search == queries_nav && h->dims[0] == h->d_user) d_qs = d_qn;
+    else CHK(input_ptr(h, queries_search, (size_t)nq * h->d_user * 4, on_device, h->q_srch, &d_qs));
     int* d_order = bucket_order;
     float* d_d = dists;
     uint32_t* d_i = ids;

@@ -99,6 +99,27 @@ __global__ void unpack_kernel(const float4* __restrict__ src, int KG, long long 
         if (g * 8 + j < d) dst[i * d + g * 8 + j] = v[j];
 }
 
+// L2 metric (lmi_set_metric): rows [n][d] -> [n][da] with column d = -|x|^2 / 2 (|x|^2 by the canonical chain
+// fmaf(x[k], x[k], acc), k ascending) and zeros after it; queries -> [q, 1, 0..] and qn2 = |q|^2 by the same chain.
+// One thread per (row, column) for the copy, one thread per row for the chain.
+__global__ void augment_copy_kernel(const float* __restrict__ src, int d, int da, long long n, float* __restrict__ dst) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * da) return;
+    const long long i = idx / da;
+    const int k = (int)(idx - i * da);
+    dst[idx] = k < d ? src[i * d + k] : 0.0f;
+}
+__global__ void augment_norm_kernel(const float* __restrict__ src, int d, int da, long long n, float* __restrict__ dst,
+                                    float* __restrict__ qn2) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* x = src + i * d;
+    float acc = 0.0f;
+    for (int k = 0; k < d; ++k) acc = __builtin_fmaf(x[k], x[k], acc);
+    if (qn2) { qn2[i] = acc; dst[i * da + d] = 1.0f; }   // a query
+    else dst[i * da + d] = -0.5f * acc;                   // an indexed vector
+}
+
 // plain copy by a kernel (16 bytes per lane): results -> pinned host memory without a hipMemcpyAsync
 // (lmi_copy_out); dst/src 16-byte aligned, the tail is copied bytewise
 __global__ void copy_bytes_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, long long bytes) {
@@ -517,6 +538,15 @@ __device__ __forceinline__ void list_insert(float (&v)[KPB], unsigned (&id)[KPB]
     v[0] = top ? s : v[0];
 }
 
+// similarity -> returned distance.  IP (the reference's only metric): 1 - s in binary32 (LearnedIndex.py:368).
+// L2 (lmi_set_metric): the scanned vectors carry the extra column -|x|^2/2 and the queries a 1 there, so the
+// "similarity" is key = <q,x> - |x|^2/2 (ranking by it == ranking by |q - x|^2) and dist = |q|^2 - 2 key, one fmaf.
+// Padding of short buckets (faiss: worst value of the metric): 1 - (-FLT_MAX) resp. FLT_MAX.
+__device__ __forceinline__ float sim_to_dist(float s, const float* qn2, int q) {
+    return qn2 ? __builtin_fmaf(-2.0f, s, qn2[q]) : 1.0f - s;
+}
+__device__ __forceinline__ float pad_dist(const float* qn2) { return qn2 ? 3.402823466e+38f : 1.0f - (-3.402823466e+38f); }
+
 __device__ __forceinline__ bool better(float s, unsigned r, float s2, unsigned r2) {
     return s > s2 || (s == s2 && r < r2);
 }
@@ -822,6 +852,7 @@ struct MergeParams {
     const float* part_score;
     const unsigned* part_row;
     const unsigned* ids_slab;
+    const float* qn2;   // L2 metric: |q|^2 per query (nullptr: inner product, dist = 1 - sim)
     float* rank_d;      // scratch [nq][nb][KPB]
     unsigned* rank_id;  // scratch [nq][nb][KPB]
     float* out_d;       // [nq][kout]
@@ -882,10 +913,10 @@ __global__ __launch_bounds__(64) void merge_kernel(MergeParams P) {
                 dv = real ? my_s : -FMAXV;
                 iv = real ? my_r : NOROW;
             } else if (real) {
-                dv = 1.0f - my_s;
+                dv = sim_to_dist(my_s, P.qn2, q);
                 iv = P.ids_slab[(size_t)P.rb_start[b] * 32 + my_r];
             } else {  // faiss padding: sim = -FLT_MAX, idx = -1 -> last label of the bucket
-                dv = 1.0f - (-FMAXV);
+                dv = pad_dist(P.qn2);
                 iv = P.ids_slab[(size_t)P.rb_start[b] * 32 + (n_b - 1)];
             }
             rd[r * KPB + lane] = dv;

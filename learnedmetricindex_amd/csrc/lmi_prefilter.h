@@ -945,6 +945,7 @@ struct RescoreParams {
     const float* eps2;
     const float* rows;  // bucket-contiguous row-major f32 [slab rows][d]
     const float* q;     // row-major [nq][d]
+    const float* qn2;   // L2 metric: |q|^2 per query (nullptr: inner product)
     const unsigned* ids_slab;
     float* rank_d;
     unsigned* rank_id;
@@ -972,15 +973,16 @@ __device__ __forceinline__ float exact_score(const float* __restrict__ rows, siz
 
 // lanes 0..9 hold the sorted (score, row) results; writes the slot's rank list (merge phase A form)
 __device__ __forceinline__ void write_rank_list(int lane, float my_s, unsigned my_r, int n_b, int rb0, int raw,
-                                                const unsigned* __restrict__ ids_slab, float* rd, unsigned* ri) {
+                                                const unsigned* __restrict__ ids_slab, float* rd, unsigned* ri,
+                                                const float* qn2, int q) {
     const float FMAXV = 3.402823466e+38f;
     if (lane < KPB) {
         const bool real = my_r != NOROW && lane < n_b;
         float dv;
         unsigned iv;
         if (raw) { dv = real ? my_s : -FMAXV; iv = real ? my_r : NOROW; }
-        else if (real) { dv = 1.0f - my_s; iv = ids_slab[(size_t)rb0 * 32 + my_r]; }
-        else { dv = 1.0f - (-FMAXV); iv = ids_slab[(size_t)rb0 * 32 + (n_b - 1)]; }  // faiss padding (Q4)
+        else if (real) { dv = sim_to_dist(my_s, qn2, q); iv = ids_slab[(size_t)rb0 * 32 + my_r]; }
+        else { dv = pad_dist(qn2); iv = ids_slab[(size_t)rb0 * 32 + (n_b - 1)]; }  // faiss padding (Q4)
         rd[lane] = dv;
         ri[lane] = iv;
     }
@@ -1164,11 +1166,11 @@ __global__ __launch_bounds__(64 * RS_WAVES) __attribute__((amdgpu_waves_per_eu(L
     }
     const int nreal = min(min((int)nk, KPB), n_b);
     if (lane < (int)nk && pos < KPB) {
-        rd[pos] = P.raw ? s : 1.0f - s;
+        rd[pos] = P.raw ? s : sim_to_dist(s, P.qn2, p / P.nb);
         ri[pos] = P.raw ? row : P.ids_slab[(size_t)rb0 * 32 + row];
     }
     if (lane >= nreal && lane < KPB) {  // faiss padding (Q4): -FLT_MAX similarity, last id of the bucket
-        rd[lane] = P.raw ? -FMAXV : 1.0f - (-FMAXV);
+        rd[lane] = P.raw ? -FMAXV : pad_dist(P.qn2);
         ri[lane] = P.raw ? NOROW : P.ids_slab[(size_t)rb0 * 32 + (n_b - 1)];
     }
 }
@@ -1246,7 +1248,7 @@ __global__ __launch_bounds__(256) void fallback_kernel(RescoreParams P) {
         if (lane == j) { my_s = bs; my_r = br; }
     }
     write_rank_list(lane, my_s, my_r, n_b, rb0, P.raw, P.ids_slab, P.rank_d + (size_t)p * KPB,
-                    P.rank_id + (size_t)p * KPB);
+                    P.rank_id + (size_t)p * KPB, P.qn2, p / P.nb);
     }
     __syncthreads();  // fs / fr are reused by the block's next slot
     }

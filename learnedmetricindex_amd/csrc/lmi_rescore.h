@@ -235,7 +235,7 @@ __global__ __launch_bounds__(64 * RC_WAVES, 1) void rescore_kernel(RescoreParams
             if (pos < KPB) {
                 const int p = p0 + sl;
                 const int b = P.bucket_order[p];
-                P.rank_d[(size_t)p * KPB + pos] = P.raw ? sc : 1.0f - sc;
+                P.rank_d[(size_t)p * KPB + pos] = P.raw ? sc : sim_to_dist(sc, P.qn2, p / P.nb);
                 P.rank_id[(size_t)p * KPB + pos] = P.raw ? row : P.ids_slab[(size_t)P.rb_start[b] * 32 + row];
             }
         }
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(64 * RC_WAVES, 1) void rescore_kernel(RescoreParams
             const int rb0 = P.rb_start[b], n_b = P.nb_rows[b];
             const int nreal = min(min(off[sl + 1] - off[sl], KPB), n_b);
             if (lane >= nreal) {
-                P.rank_d[(size_t)p * KPB + lane] = P.raw ? -FMAXV : 1.0f - (-FMAXV);
+                P.rank_d[(size_t)p * KPB + lane] = P.raw ? -FMAXV : pad_dist(P.qn2);
                 P.rank_id[(size_t)p * KPB + lane] = P.raw ? NOROW : P.ids_slab[(size_t)rb0 * 32 + (n_b - 1)];
             }
         }

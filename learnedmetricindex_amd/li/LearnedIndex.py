@@ -87,7 +87,7 @@ class LearnedIndex(Logger):
         self._engine_key = None
 
     def prepare(self, data_navigation: pd.DataFrame, data_search: pd.DataFrame,
-                data_prediction: npt.NDArray[np.int64], n_categories: List[int], device: int = 0):
+                data_prediction: npt.NDArray[np.int64], n_categories: List[int], device: int = 0, metric: str = "ip"):
         """Uploads the scan vectors bucket-contiguously (the one-time replacement of the
         reference's per-call groupby + `.loc` gather).  Called by `search` when needed."""
         assert self.root_model is not None, "Model is not trained, call `build` first."
@@ -96,13 +96,13 @@ class LearnedIndex(Logger):
             dp = dp[:, None]
         assert dp.shape[0] == data_navigation.shape[0] == data_search.shape[0]
         key = (id(data_search), tuple(data_search.shape), dp.__array_interface__["data"][0], dp.shape,
-               int(dp[:: max(1, dp.shape[0] // 1024), 0].sum()), tuple(n_categories), device)
+               int(dp[:: max(1, dp.shape[0] // 1024), 0].sum()), tuple(n_categories), device, metric)
         if self._engine is not None and key == self._engine_key:
             return self._engine
         self.close()
         n_levels = len(n_categories)
         assert dp.shape[1] == n_levels
-        eng = _capi.Index(device)
+        eng = _capi.Index(device, metric=metric)
         if n_levels == 1:
             # bucket id == class id: lmi_search can run MLP -> scan without leaving the device
             eng.set_mlp(linear_layers(self.root_model.model))
@@ -152,11 +152,13 @@ class LearnedIndex(Logger):
         n_categories: List[int],
         n_buckets: int = 1,
         k: int = 10,
+        metric: str = "ip",
     ) -> Tuple[npt.NDArray, npt.NDArray[np.uint32], Dict[str, float]]:
         """Searches for `k` nearest neighbors of every query in its `n_buckets` most probable buckets.
-        Parameters and return values as the reference (LearnedIndex.py:41-83)."""
+        Parameters and return values as the reference (LearnedIndex.py:41-83).  `metric` (an extension; the
+        reference scans with `1 - inner product` only): "ip" (default) or "l2" -- squared Euclidean distances."""
         s = time.time()
-        eng = self.prepare(data_navigation, data_search, data_prediction, n_categories)
+        eng = self.prepare(data_navigation, data_search, data_prediction, n_categories, metric=metric)
         return self._search_with(eng, queries_navigation, queries_search, n_categories, n_buckets, k, s)
 
     def _search_with(self, eng, queries_navigation, queries_search, n_categories, n_buckets, k, s):

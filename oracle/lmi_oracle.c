@@ -256,6 +256,27 @@ void lmi_oracle_knn_ip(const float *xq, int64_t nq, const float *xb, int64_t nb,
     free(xt);
 }
 
+/* L2 metric (no counterpart in the reference, which scans with METRIC_INNER_PRODUCT only, LearnedIndex.py:364;
+ * this is what faiss.knn(..., METRIC_L2) would be in its place).  Canonical arithmetic, shared with the HIP
+ * kernels (include/lmi_hip.h: lmi_set_metric): xn = chain <x,x>, qn = chain <q,q>, key = chain <q,x> continued by
+ * one step fmaf(1, -xn/2, .) -- i.e. the inner product of [q, 1] with [x, -xn/2], which lmi_oracle.py computes with
+ * lmi_oracle_knn_ip on the augmented vectors -- and dist = fmaf(-2, key, qn). */
+void lmi_oracle_sqnorms(const float *x, int64_t n, int d, float *out)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        float acc = 0.0f;
+        for (int k = 0; k < d; ++k) acc = fmaf(x[(size_t)i * d + k], x[(size_t)i * d + k], acc);
+        out[i] = acc;
+    }
+}
+
+void lmi_oracle_l2_finish(const float *key, const int64_t *idx, const float *qn, int64_t nq, int k, float *dist)
+{
+    for (int64_t q = 0; q < nq; ++q)
+        for (int j = 0; j < k; ++j)
+            dist[q * k + j] = idx[q * k + j] < 0 ? FLT_MAX : fmaf(-2.0f, key[q * k + j], qn[q]);
+}
+
 /* Single canonical dot product, exposed for spot checks at full size. */
 float lmi_oracle_dot(const float *a, const float *b, int d, float c0)
 {

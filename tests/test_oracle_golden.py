@@ -112,3 +112,23 @@ def test_expf_close_to_libm(oracle):
     xs = np.linspace(-86.9, 0, 4001).astype(np.float32)
     got = np.array([oracle.lib().lmi_oracle_expf(float(x)) for x in xs], dtype=np.float32)
     np.testing.assert_allclose(got, np.exp(xs.astype(np.float64)), rtol=3e-7)
+
+
+def test_knn_l2_matches_float64_bruteforce(oracle):
+    """The L2 extension of the oracle (squared Euclidean, ascending) against float64 brute force; on unit-norm data
+    its neighbours are the inner-product ones (L2^2 = 2 (1 - ip))."""
+    rs = np.random.RandomState(7)
+    xb = (rs.randn(900, 45) * rs.uniform(0.2, 3, size=(900, 1))).astype(np.float32)
+    xq = rs.randn(40, 45).astype(np.float32)
+    D, I = oracle.knn_l2(xq, xb, 10, nthreads=3)
+    ref = ((xq.astype(np.float64)[:, None, :] - xb.astype(np.float64)[None, :, :]) ** 2).sum(-1)
+    order = np.argsort(ref, axis=1, kind="stable")[:, :10]
+    assert (I == order).mean() > 0.99 and np.all(np.diff(D, axis=1) >= 0)
+    np.testing.assert_allclose(D, np.take_along_axis(ref, order, 1), rtol=1e-4)
+    xu = xb / np.linalg.norm(xb, axis=1, keepdims=True)
+    qu = xq / np.linalg.norm(xq, axis=1, keepdims=True)
+    _, Il2 = oracle.knn_l2(qu, xu, 10)
+    _, Iip = oracle.knn_ip(qu, xu, 10)
+    assert (Il2 == Iip).mean() > 0.98
+    D3, I3 = oracle.knn_l2(xq[:2], xb[:3], 5)  # fewer rows than k: FLT_MAX / -1 padding
+    assert np.all(I3[:, 3:] == -1) and np.all(D3[:, 3:] == np.finfo(np.float32).max)
