@@ -50,6 +50,8 @@ def _feature_columns(df: pd.DataFrame) -> list:
 
 
 class LearnedIndex(Logger):
+    _WORKSPACE_BYTES = 6 << 30  # per-call device workspace budget of one search chunk
+
     def __init__(self, root_model: NeuralNetwork, internal_models: Dict[Tuple, NeuralNetwork],
                  bucket_paths: List[Tuple]):
         self.root_model = root_model
@@ -79,6 +81,11 @@ class LearnedIndex(Logger):
         self.__dict__.setdefault("_entry_paths", None)
 
     # ------------------------------------------------------------------------------------------
+    def invalidate(self) -> None:
+        """Drops the HBM-resident copy: the next `search`/`prepare` uploads the frames again (call after editing
+        the vectors in place beyond what the sampled fingerprint can see)."""
+        self.close()
+
     def close(self) -> None:
         """Frees the HBM-resident index."""
         if self._engine is not None:
@@ -95,8 +102,19 @@ class LearnedIndex(Logger):
         if dp.ndim == 1:
             dp = dp[:, None]
         assert dp.shape[0] == data_navigation.shape[0] == data_search.shape[0]
-        key = (id(data_search), tuple(data_search.shape), dp.__array_interface__["data"][0], dp.shape,
-               int(dp[:: max(1, dp.shape[0] // 1024), 0].sum()), tuple(n_categories), device, metric)
+        # What the resident copy was built from.  The reference re-reads the frames on every call; here a cheap
+        # content fingerprint (strided samples of the vectors, the labels, the placement and the root weights) makes
+        # an in-place edit, a re-labelled or re-trained index miss the cache instead of answering from a stale slab,
+        # and an equal-content copy of `data_prediction` hit it.  `invalidate()` forces a rebuild.
+        def _sample(a, n=4096):
+            a = np.asarray(a).reshape(-1)
+            return float(np.asarray(a[:: max(1, a.shape[0] // n)], dtype=np.float64).sum()) if a.size else 0.0
+
+        rows = np.linspace(0, max(0, data_search.shape[0] - 1), num=min(64, max(1, data_search.shape[0])), dtype=np.int64)
+        first = linear_layers(self.root_model.model)[0][0]
+        key = (tuple(data_search.shape), _sample(data_search.iloc[rows].to_numpy(dtype=np.float32)) if data_search.shape[0] else 0.0,
+               _sample(data_navigation.index.to_numpy()), dp.shape, _sample(dp), _sample(first), len(self.internal_models),
+               tuple(n_categories), device, metric)
         if self._engine is not None and key == self._engine_key:
             return self._engine
         self.close()
@@ -175,18 +193,31 @@ class LearnedIndex(Logger):
         if nq == 0:
             kout = _capi.Index.kout(n_buckets, k)
             return np.empty((0, kout)), np.empty((0, kout), dtype=np.uint32), measured_time
-        if len(n_categories) == 1:
-            d32, nns, _ = eng.search(qn, qs, n_buckets, k)
-            t = eng.timings() * 1e-3
-            measured_time["inference"] = float(t[_capi.T_INFERENCE])
-        else:
-            ids, _ = eng.nav_order(qn, n_buckets)          # the priority-queue walk, on the device
-            measured_time["inference"] = float(eng.timings()[_capi.T_INFERENCE]) * 1e-3
-            d32, nns = eng.scan_topk(qs, ids, k)
-            t = eng.timings() * 1e-3
-        measured_time["search_within_buckets"] = float(t[_capi.T_ROUTE] + t[_capi.T_SCAN] + t[_capi.T_MERGE])
-        measured_time["seq_search"] = float(t[_capi.T_SCAN])
-        measured_time["sort"] = float(t[_capi.T_MERGE])
+        # The prefilter's per-call workspace is ~8.7 KiB per (query, bucket) slot (candidate buffers): large
+        # batches x many buckets are answered in query chunks that keep it under _WORKSPACE_BYTES.
+        step = max(1, min(nq, self._WORKSPACE_BYTES // (8900 * max(1, n_buckets))))
+        parts_d, parts_n = [], []
+        for lo in range(0, nq, step):
+            hi = min(nq, lo + step)
+            whole = lo == 0 and hi == nq
+            qn_c = qn if whole else qn[lo:hi]
+            qs_c = qs if whole else (qn_c if qs is qn else qs[lo:hi])
+            if len(n_categories) == 1:
+                d32, nn, _ = eng.search(qn_c, qs_c, n_buckets, k)
+                t = eng.timings() * 1e-3
+                measured_time["inference"] += float(t[_capi.T_INFERENCE])
+            else:
+                ids, _ = eng.nav_order(qn_c, n_buckets)        # the priority-queue walk, on the device
+                measured_time["inference"] += float(eng.timings()[_capi.T_INFERENCE]) * 1e-3
+                d32, nn = eng.scan_topk(qs_c, ids, k)
+                t = eng.timings() * 1e-3
+            measured_time["search_within_buckets"] += float(t[_capi.T_ROUTE] + t[_capi.T_SCAN] + t[_capi.T_MERGE])
+            measured_time["seq_search"] += float(t[_capi.T_SCAN])
+            measured_time["sort"] += float(t[_capi.T_MERGE])
+            parts_d.append(d32)
+            parts_n.append(nn)
+        d32 = parts_d[0] if len(parts_d) == 1 else np.concatenate(parts_d)
+        nns = parts_n[0] if len(parts_n) == 1 else np.concatenate(parts_n)
         dists = d32.astype(np.float64)  # float32 values in a float64 array, like the reference (Q6)
         assert dists.shape == nns.shape
         measured_time["search"] = time.time() - s

@@ -175,3 +175,38 @@ def test_two_level_index_G2(oracle):
     compare_modulo_near_ties(g["ref_dists"][same], g["ref_nns"][same], dists[same], nns[same])
     assert mt["inference"] > 0 and mt["seq_search"] > 0
     li.close()
+
+
+def test_resident_cache_key_and_query_chunks(oracle):
+    """The HBM-resident copy is keyed by a content fingerprint: an in-place edit of a sampled row, new labels or
+    `invalidate()` rebuild it, an equal-content copy of `data_prediction` does not; and a search answered in
+    several query chunks (small workspace budget) equals the one-call answer."""
+    g = load_golden("G1")
+    Xn, Qn, Xs, Qs = inputs_for("G1", g)
+    li, _ = make_index("G1", g)
+    dp = g["data_prediction"].astype(np.int64)
+    df = frame(Xs.copy())
+    d, n, _ = li.search(df, Qn, df, Qs, dp, [12], 3, 10)
+    eng = li._engine
+    d1, n1, _ = li.search(df, Qn, df, Qs, dp.copy(), [12], 3, 10)      # same contents, another array: cache hit
+    assert li._engine is eng
+    np.testing.assert_array_equal(n1, n)
+    li._WORKSPACE_BYTES = 8900 * 3 * 37                                   # 37 queries per chunk
+    d2, n2, mt = li.search(df, Qn, df, Qs, dp, [12], 3, 10)
+    np.testing.assert_array_equal(n2, n)
+    np.testing.assert_array_equal(d2, d)
+    assert mt["seq_search"] > 0 and mt["inference"] > 0
+    df.iloc[0, :] = Qs[0]                                                  # in-place edit of a sampled row
+    d3, n3, _ = li.search(df, Qn, df, Qs, dp, [12], 3, 10)
+    assert li._engine is not eng
+    X2 = Xs.copy()
+    X2[0] = Qs[0]
+    do, no, _ = oracle.search(layers_from(g), Qn, X2, Qs, dp, 3, 10, nthreads=4)
+    np.testing.assert_array_equal(n3, no)
+    np.testing.assert_array_equal(d3, do)
+    eng = li._engine
+    li.invalidate()
+    assert li._engine is None
+    d4, n4, _ = li.search(df, Qn, df, Qs, dp, [12], 3, 10)
+    np.testing.assert_array_equal(n4, no)
+    li.close()
