@@ -80,9 +80,11 @@ LMI_API int lmi_set_stream(lmi_index *h, void *hip_stream);
 LMI_API int lmi_set_mlp(lmi_index *h, int n_layers, const int *dims, const float *const *W,
                 const float *const *b);
 
-/* Unfused fallback of the MLP (one kernel per layer + ranking kernels) instead of the one-launch kernel of
- * lmi_mlp_fused.h; both produce bit-identical logits, orders and probabilities.  Default: fused. */
-LMI_API int lmi_set_fused_mlp(lmi_index *h, int on);
+/* Which kernels run the navigation MLP: 2 = always the one-launch kernel of lmi_mlp_fused.h, 0 = always one kernel
+ * per layer + ranking kernels, 1 (default) = the fused kernel when the batch has enough 32-query blocks to fill the
+ * chip (and for predict_proba), the per-layer kernels for small batches.  All produce bit-identical logits, orders
+ * and probabilities. */
+LMI_API int lmi_set_fused_mlp(lmi_index *h, int mode);
 
 /* Multi-level index (len(n_categories) > 1; LearnedIndex.py:216-325, PriorityQueue.py:18-94): the models of
  * the internal nodes and the tree.  Model 0 is the root (lmi_set_mlp); lmi_nav_set_model sets model_id >= 1

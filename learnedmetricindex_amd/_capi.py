@@ -199,9 +199,9 @@ class Index:
         _check(lib().lmi_set_mlp(self._h, n, dims_c, Wp, bp))
         self.d_nav, self.n_classes = dims[0], dims[-1]
 
-    def set_fused_mlp(self, on: bool) -> None:
-        """One-launch MLP (default) or the per-layer kernels; identical outputs."""
-        _check(lib().lmi_set_fused_mlp(self._h, 1 if on else 0))
+    def set_fused_mlp(self, mode: int) -> None:
+        """2: always the one-launch MLP kernel, 0: always the per-layer kernels, 1 (default): by batch size; identical outputs."""
+        _check(lib().lmi_set_fused_mlp(self._h, int(mode)))
 
     # ---- multi-level navigation ---------------------------------------------------------------
     @staticmethod

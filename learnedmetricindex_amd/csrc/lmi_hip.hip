@@ -97,7 +97,7 @@ struct lmi_index {
         std::vector<DevBuf> Wf, bias;
     };
     std::vector<NodeModel> node_models;   // index = model id - 1
-    bool fused_mlp = true;                // lmi_set_fused_mlp
+    int fused_mlp = 1;                    // lmi_set_fused_mlp: 0 never, 1 when the batch fills the chip, 2 always
     bool desc_dirty = true;
     DevBuf d_models;                      // ModelDesc[1 + node_models.size()]
     int fm_s0 = 0, fm_s1 = 0, fm_act0 = 0, fm_lds = 0, fm_logits_lds = 0;  // LDS plan of the current model set
@@ -129,7 +129,7 @@ struct lmi_index {
     bool have16 = false;     // slab16 built by lmi_buckets_end
     int KG16 = 0;
     DevBuf slab16, rowmajor, xscale, xmaxbits, bnorm, bdelta, qdelta;
-    DevBuf qnorm, qscale, qfrag16, eps2, cand_cnt, cand_row, cand_s, fallback, pf_bound, nkeep, surv_row;
+    DevBuf qnorm, qscale, qfrag16, eps2, cand_cnt, cand_row, cand_s, fallback, pf_bound, nkeep, surv_row, rs_flag, rs_active;
     bool rescore_streamed = true;  // lmi_rescore.h (LMI_RESCORE_SIMPLE=1 in the environment: select_rescore_kernel)
     int last_nslots = 0, last_nb = 0;
     bool last_fast = false;
@@ -217,7 +217,7 @@ extern "C" LMI_API int lmi_destroy(lmi_index* h) {
                       &h->rank_id, &h->out_d, &h->out_id, &h->out_key};
     for (DevBuf* b : bufs) b->release();
     for (auto& m : h->node_models) { for (auto& b : m.Wf) b.release(); for (auto& b : m.bias) b.release(); }
-    DevBuf* nav[] = {&h->d_models, &h->d_child_offset, &h->d_child_model, &h->d_child_bucket, &h->pq_prob, &h->pq_ent, &h->pq_len, &h->surv_row, &h->gather_send, &h->gather_recv, &h->aug_rows, &h->q_aug, &h->qn2,
+    DevBuf* nav[] = {&h->d_models, &h->d_child_offset, &h->d_child_model, &h->d_child_bucket, &h->pq_prob, &h->pq_ent, &h->pq_len, &h->surv_row, &h->rs_flag, &h->rs_active, &h->gather_send, &h->gather_recv, &h->aug_rows, &h->q_aug, &h->qn2,
                      &h->nav_len, &h->nav_slab, &h->nav_ent, &h->nav_count, &h->nav_colq, &h->nav_active};
     for (DevBuf* b : nav) b->release();
     for (int r = 0; r < lmi_index::EV_RING; ++r)
@@ -312,7 +312,8 @@ extern "C" LMI_API int lmi_set_mlp(lmi_index* h, int n_layers, const int* dims, 
 
 extern "C" LMI_API int lmi_set_fused_mlp(lmi_index* h, int on) {
     if (!h) return fail("lmi_set_fused_mlp: NULL handle");
-    h->fused_mlp = on != 0;
+    if (on < 0 || on > 2) return fail("lmi_set_fused_mlp: mode %d outside 0..2", on);
+    h->fused_mlp = on;
     return 0;
 }
 
@@ -679,7 +680,12 @@ static int mlp_enqueue(lmi_index* h, const float* d_q, int nq, int nb, int* d_or
     const int L = h->dims[h->n_layers];
     if (nb < 1 || nb > L) return fail("lmi_mlp_topk: n_buckets %d outside [1,%d]", nb, L);
     CHK(build_descs(h));
-    if (h->fused_mlp && h->fm_ok) {
+    // One launch for every layer + ranking when the batch fills the chip (a block = 32 queries, one per CU for the wide
+    // models: 8 192 queries 100 us against 138 us for the per-layer kernels); small batches (a rank's slice of a
+    // sharded batch, single queries) have too few 32-query blocks for that and take the per-layer kernels, whose grids
+    // also split the features (2 048 queries: 79 us against 88 us).  predict_proba always takes the fused kernel.
+    const bool fill = cdiv(nq, FM_COLS) * 2 >= h->num_cus || d_probs != nullptr || h->fused_mlp == 2;
+    if (h->fused_mlp && h->fm_ok && fill) {
         // every layer, the ranking and the softmax in ONE launch (lmi_mlp_fused.h)
         FusedParams P;
         fused_base(h, d_q, nq, P);
@@ -1023,13 +1029,27 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
 #ifndef LMI_ABL_NOEMIT  // timing-only ablation builds emit nothing: no re-rank, no fallback
         if (h->rescore_streamed && h->d % 4 == 0 && h->d <= RS_MAXD) {
             // selection at full occupancy, then the survivors' rows streamed through LDS in coalesced pieces (lmi_rescore.h)
+            const int G = nb % 4 == 0 ? 4 : nb % 3 == 0 ? 3 : nb % 2 == 0 ? 2 : 1;  // slots of one query per wave
+            const int groups = nslots / G;
             CHK(h->surv_row.reserve((size_t)nslots * PF_KEEP * 4));
+            CHK(h->rs_flag.reserve((size_t)groups * 4));
+            CHK(h->rs_active.reserve((size_t)(groups + 1) * 4));
             SelectOut O;
             O.surv_row = h->surv_row.as<unsigned>();
+            O.G = G;
+            O.grp_flag = h->rs_flag.as<int>();
+            O.active = h->rs_active.as<int>();
+            {
+                FillRanges Zr;
+                Zr.count = 2;
+                Zr.p[0] = reinterpret_cast<unsigned*>(O.grp_flag); Zr.n[0] = groups; Zr.v[0] = 0u;
+                Zr.p[1] = reinterpret_cast<unsigned*>(O.active); Zr.n[1] = 1; Zr.v[1] = 0u;
+                fill_ranges_kernel<<<cdiv(groups, 1024), 256, 0, h->stream>>>(Zr);
+                HIPCHK(hipGetLastError());
+            }
             select_kernel<<<cdiv(nslots, 4), 256, 0, h->stream>>>(Q, O);
             HIPCHK(hipGetLastError());
-            const int G = nb % 4 == 0 ? 4 : nb % 3 == 0 ? 3 : nb % 2 == 0 ? 2 : 1;  // slots of one query per wave
-            const int blocks = cdiv(cdiv(nslots, G), RC_WAVES);
+            const int blocks = cdiv(groups, RC_WAVES);
             const int lds = RC_WAVES * rc_wave_lds(h->d, G);
 #define LMI_RC_LAUNCH(GV)                                                                                              \
             {                                                                                                          \

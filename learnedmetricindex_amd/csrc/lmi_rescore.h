@@ -30,7 +30,11 @@ constexpr int RC_BUF = RC_PIECES * 1024;          // a chunk buffer holds WHOLE 
 constexpr int RC_WAVES = 4;
 
 struct SelectOut {
-    unsigned* surv_row;  // [nslots][PF_KEEP]
+    unsigned* surv_row;   // [nslots][PF_KEEP]
+    int G;                // slots per rescore wave
+    int* grp_flag;        // [groups] zeroed per call: the group has a slot with survivors
+    int* active;          // [1 + groups]: count, then the groups to re-score (any order; a rank of a sharded index
+                          // owns 1/world of the slots: its rescore waves are packed into the first blocks)
 };
 
 // That + survivors of one slot; unvisited slots get their (inf, 0) rank list here.
@@ -105,7 +109,10 @@ __global__ __launch_bounds__(256) void select_kernel(RescoreParams P, SelectOut 
     }
     if (lane == 0) {
         if (nk > (unsigned)PF_KEEP) P.fallback[p] = 1;
-        else P.nkeep[p] = (int)nk;
+        else {
+            P.nkeep[p] = (int)nk;
+            if (nk > 0 && atomicExch(&O.grp_flag[p / O.G], 1) == 0) O.active[1 + atomicAdd(&O.active[0], 1)] = p / O.G;
+        }
     }
 }
 
@@ -116,8 +123,9 @@ template <int G>
 __global__ __launch_bounds__(64 * RC_WAVES, 1) void rescore_kernel(RescoreParams P, SelectOut O) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rc_smem[];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int p0 = (blockIdx.x * RC_WAVES + wv) * G;
-    if (p0 >= P.nslots) return;
+    const int wid = blockIdx.x * RC_WAVES + wv;
+    if (wid >= O.active[0]) return;
+    const int p0 = O.active[1 + wid] * G;
     const int d = P.d;
     unsigned char* mine = rc_smem + (size_t)wv * rc_wave_lds(d, G);
     unsigned char* buf0 = mine;
@@ -126,9 +134,7 @@ __global__ __launch_bounds__(64 * RC_WAVES, 1) void rescore_kernel(RescoreParams
     unsigned* krow = reinterpret_cast<unsigned*>(mine + 2 * RC_BUF + d * 4);
     float* ksc = reinterpret_cast<float*>(krow + G * PF_KEEP);
     const float FMAXV = 3.402823466e+38f;
-    // the wave's query (G divides nb: one query per wave) and the survivor lists of its slots, slot after slot
-    const float* qg = P.q + (size_t)(p0 / P.nb) * d;
-    for (int k = lane * 4; k < d; k += 256) *reinterpret_cast<float4*>(qs + k) = *reinterpret_cast<const float4*>(qg + k);
+    // the survivor lists of the wave's slots, slot after slot, and the wave's query (G divides nb: one query per wave)
     int off[G + 1];
     off[0] = 0;
 #pragma unroll
@@ -139,6 +145,8 @@ __global__ __launch_bounds__(64 * RC_WAVES, 1) void rescore_kernel(RescoreParams
         off[sl + 1] = off[sl] + nk;
     }
     const int total = off[G];
+    const float* qg = P.q + (size_t)(p0 / P.nb) * d;
+    for (int k = lane * 4; k < d; k += 256) *reinterpret_cast<float4*>(qs + k) = *reinterpret_cast<const float4*>(qg + k);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int nchunks = (d + RC_CHUNK - 1) / RC_CHUNK;

@@ -14,7 +14,7 @@ def both_modes(layers):
     from learnedmetricindex_amd import _capi
 
     out = []
-    for fused in (True, False):
+    for fused in (2, 0):   # 2: the fused kernel whatever the batch size, 0: the per-layer kernels
         idx = _capi.Index(0)
         idx.set_fused_mlp(fused)
         idx.set_mlp(layers)
