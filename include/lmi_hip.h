@@ -211,8 +211,12 @@ LMI_API int lmi_scan_stats(lmi_index *h, double *flops, int64_t *pairs, int64_t 
  * re-ranking of the survivors (lmi_prefilter.h); off: every similarity by f32 MFMA.  Both modes
  * return bit-identical results; call before lmi_buckets_begin (the index is stored differently:
  * row-major f32 + fp16 fragments vs f32 fragments).  lmi_prefilter_stats: whether the last scan used the prefilter, how many candidates were
- * re-scored exactly and how many (query, rank) slots fell back to the exact brute-force kernel. */
+ * re-scored exactly and how many (query, rank) slots fell back to the exact brute-force kernel.
+ * on = 2: the prefilter with the query-resident form of its pass 2 (lmi_pass2_qr.h; d <= 768, else as 1) instead of the
+ * streamed one; 1 <-> 2 may be switched at any time, results are identical (the streamed form is the faster one). */
 LMI_API int lmi_set_prefilter(lmi_index *h, int on);
+/* Developer aid: copies the first `bytes` of a named internal device buffer to host memory ("pf_bound"). */
+LMI_API int lmi_debug_peek(lmi_index *h, const char *name, void *dst, int64_t bytes);
 LMI_API int lmi_prefilter_stats(lmi_index *h, int *active, int64_t *survivors, int64_t *fallbacks);
 /* Tuning: rows per scan chunk (multiple of the 256-row block tile).  Not called: lmi_buckets_begin picks
  * 256..2048 by the size of the index (this rank's rows / 4096), and more for buckets beyond 1024 chunks. */

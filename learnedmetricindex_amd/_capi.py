@@ -69,6 +69,7 @@ SIGNATURES = {
     "lmi_scan_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double), _i64p, _i64p]),
     "lmi_set_chunk_rows": (ctypes.c_int, [_vp, ctypes.c_int]),
     "lmi_set_prefilter": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "lmi_debug_peek": (ctypes.c_int, [_vp, ctypes.c_char_p, _vp, ctypes.c_int64]),
     "lmi_prefilter_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), _i64p, _i64p]),
     "lmi_debug_emit_all": (ctypes.c_int, [_vp, ctypes.c_int]),
     "lmi_debug_read_candidates": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, _vp, _vp,
@@ -154,9 +155,16 @@ class Index:
         except Exception:  # noqa: BLE001
             pass
 
-    def set_prefilter(self, on: bool) -> None:
-        """fp16 prefilter + exact re-rank (default) or f32 MFMA for every similarity; same results."""
-        _check(lib().lmi_set_prefilter(self._h, 1 if on else 0))
+    def set_prefilter(self, on) -> None:
+        """fp16 prefilter + exact re-rank (default) or f32 MFMA for every similarity; same results.
+        2: the prefilter with the query-resident pass 2 (1 <-> 2 can be switched on a built index)."""
+        _check(lib().lmi_set_prefilter(self._h, int(on)))
+
+    def debug_peek(self, name: str, nbytes: int) -> np.ndarray:
+        """Developer aid: the first `nbytes` of a named internal device buffer as uint8."""
+        out = np.empty(nbytes, np.uint8)
+        _check(lib().lmi_debug_peek(self._h, name.encode(), out.ctypes.data_as(_vp), nbytes))
+        return out
 
     def prefilter_stats(self):
         """(active, survivors re-scored exactly, slots that fell back to exact brute force)."""

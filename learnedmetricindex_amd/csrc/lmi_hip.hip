@@ -3,6 +3,7 @@
 // weights and the per-call workspaces; enqueues the kernels of lmi_kernels.h on one HIP stream.
 #include "lmi_kernels.h"
 #include "lmi_prefilter.h"
+#include "lmi_pass2_qr.h"
 #include "lmi_mlp_fused.h"
 #include "lmi_rescore.h"
 
@@ -130,6 +131,10 @@ struct lmi_index {
     int KG16 = 0;
     DevBuf slab16, rowmajor, xscale, xmaxbits, bnorm, bdelta, qdelta;
     DevBuf qnorm, qscale, qfrag16, eps2, cand_cnt, cand_row, cand_s, fallback, pf_bound, nkeep, surv_row, rs_flag, rs_active;
+#ifndef LMI_PASS2_QR_DEFAULT
+#define LMI_PASS2_QR_DEFAULT false
+#endif
+    bool pass2_qr = LMI_PASS2_QR_DEFAULT;   // lmi_set_prefilter(h, 2) / LMI_PASS2_QR=1: pass2_qr_kernel (lmi_pass2_qr.h) instead of prefilter_kernel<false, 2>
     bool rescore_streamed = true;  // lmi_rescore.h (LMI_RESCORE_SIMPLE=1 in the environment: select_rescore_kernel)
     int last_nslots = 0, last_nb = 0;
     bool last_fast = false;
@@ -200,6 +205,11 @@ extern "C" LMI_API int lmi_create(int device, lmi_index** out) {
         if (!h->pf_hw_ok) h->prefilter = false;
     }
     if (const char* e = getenv("LMI_RESCORE_SIMPLE")) h->rescore_streamed = !(e[0] && e[0] != '0');
+    if (const char* e = getenv("LMI_PASS2_QR")) h->pass2_qr = e[0] && e[0] != '0';
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pass2_qr_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)QR_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pass2_qr_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)QR_LDS));
     *out = h;
     return 0;
 }
@@ -256,6 +266,7 @@ extern "C" LMI_API int lmi_set_prefilter(lmi_index* h, int on) {
         return fail("lmi_set_prefilter: the mode is fixed once lmi_buckets_begin has run (the index is stored differently)");
     if (on && !h->pf_hw_ok) return fail("lmi_set_prefilter: fp16 subnormal self-test failed on this device; the prefilter's error bound does not hold");
     h->prefilter = on != 0;
+    if (on) h->pass2_qr = on == 2;
     return 0;
 }
 
@@ -1002,7 +1013,17 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
             HIPCHK(hipGetLastError());
         }
         CHK(record(h, 5));
-        prefilter_kernel<false, PF_NG><<<h->num_cus * PF_BLOCKS_PER_CU, 256 * PF_NG, 0, h->stream>>>(F);  // pass 2: candidates
+#ifdef LMI_QR_STAMPS
+        HIPCHK(hipMemsetAsync(F.bound, 0, 2 * 8 * 12 * 8, h->stream));
+#endif
+        // pass 2: candidates.  The query-resident form (opt-in: measured slower) needs a col-block's
+        // fragments to fit a wave's registers (d <= 768)
+        if (h->pass2_qr && PF_NG == 2 && h->KG16 <= QR_KMAX) {
+            if (h->KG16 == QR_KMAX) pass2_qr_kernel<true><<<h->num_cus, 64 * QR_WAVES, QR_LDS, h->stream>>>(F);
+            else pass2_qr_kernel<false><<<h->num_cus, 64 * QR_WAVES, QR_LDS, h->stream>>>(F);
+        } else {
+            prefilter_kernel<false, PF_NG><<<h->num_cus * PF_BLOCKS_PER_CU, 256 * PF_NG, 0, h->stream>>>(F);
+        }
         HIPCHK(hipGetLastError());
         CHK(record(h, 6));
         RescoreParams Q;
@@ -1580,6 +1601,19 @@ extern "C" LMI_API int lmi_debug_read_candidates(lmi_index* h, int64_t slot, int
     if (eps2) *eps2 = e2;
     if (qscale) *qscale = qs;
     if (xscale) *xscale = xs[0];
+    return 0;
+}
+
+// developer aid: the first `bytes` of a named internal device buffer ("pf_bound": LMI_QR_STAMPS builds keep phase timings there)
+extern "C" LMI_API int lmi_debug_peek(lmi_index* h, const char* name, void* dst, int64_t bytes) {
+    if (!h || !name || !dst) return fail("lmi_debug_peek: NULL argument");
+    CHK(set_dev(h));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    DevBuf* b = nullptr;
+    if (!strcmp(name, "pf_bound")) b = &h->pf_bound;
+    if (!b) return fail("lmi_debug_peek: unknown buffer '%s'", name);
+    if (bytes < 0 || (size_t)bytes > b->cap) return fail("lmi_debug_peek: %lld bytes asked of a %zu-byte buffer", (long long)bytes, b->cap);
+    if (bytes) HIPCHK(hipMemcpy(dst, b->p, (size_t)bytes, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -20,6 +20,12 @@ def both_modes(capi, X, labels, L, Q, order, k=10, chunk_rows=256):
         active, survivors, fallbacks = idx.prefilter_stats()
         assert active == pf
         out.append((d, i, survivors, fallbacks))
+        if pf:  # the query-resident form of pass 2 (lmi_pass2_qr.h) on the same index: same candidates, same answers
+            idx.set_prefilter(2)
+            d2, i2 = idx.scan_topk(Q, order, k)
+            assert idx.prefilter_stats() == (1, survivors, fallbacks)
+            np.testing.assert_array_equal(i2, i)
+            np.testing.assert_array_equal(d2, d)
         idx.close()
     return out
 
