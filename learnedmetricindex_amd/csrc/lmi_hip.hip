@@ -1013,7 +1013,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
             HIPCHK(hipGetLastError());
         }
         CHK(record(h, 5));
-#ifdef LMI_QR_STAMPS
+#if defined(LMI_QR_STAMPS) || defined(LMI_PF_STAMPS)
         HIPCHK(hipMemsetAsync(F.bound, 0, 2 * 8 * 12 * 8, h->stream));
 #endif
         // pass 2: candidates.  The query-resident form (opt-in: measured slower) needs a col-block's

@@ -351,6 +351,10 @@ struct PrefilterParams {
 // subset of the bucket's scores: the union of the 8 (row-wave, half) lists x parts of a column holds the
 // sample's ten best unless five of them fall into one list; a shorter list is a cheaper insert (the
 // epilogue of pass 1 is VALU-bound) and a higher entry threshold.
+#ifndef LMI_PF_EPI_G
+#define LMI_PF_EPI_G 1  // pass 2: score registers tested per branch of the epilogue (A/B on MI355X: 1: -2.7 %, 2: -1.6 %, 4: +11 % -- its 4-entry reservations overflow the 64-entry list)
+#endif
+constexpr int PF_LIST = 64 + LMI_PF_EPI_G;  // compaction-list entries per wave (+ slack for the group that overflows it)
 #ifndef LMI_PF_LK
 #define LMI_PF_LK 4
 #endif
@@ -365,6 +369,16 @@ __device__ __forceinline__ void vlist_insert(float (&v)[PF_LK], float s) {  // v
 // 256 vectors x 256 queries, one block per CU: group g (waves 4g..4g+3) owns its share of the tile's
 // col-blocks and both groups read the SAME staged vector fragments, so a CU fetches every vector stage
 // once instead of twice and a bucket has half as many query tiles re-reading its chunks.
+// In-kernel phase timing of pass 2 (developer builds, -DLMI_PF_STAMPS): shader-clock cycles per wave and phase summed into
+// P.bound (free once bound_merge_kernel has run) as u64 [8 waves][12 phases]: 0 landed-wait, 1 barrier, 2 stage (MFMA + DMA
+// issue), 3 epilogue rest (clearing the accumulators), 4 item start, 5 item end, 7 = tiles, 8 / 9 / 10 = the epilogue's flush /
+// threshold pass / list read + position atomics.  tools/pf_stamps.py prints the table.
+#ifdef LMI_PF_STAMPS
+#define PF_STAMP(PH) if (!SAMPLE) { const unsigned long long t_ = __builtin_readcyclecounter(); st_acc[PH] += t_ - st_last; st_last = t_; }
+#else
+#define PF_STAMP(PH)
+#endif
+
 template <int NCB, bool SAMPLE, int NG>
 struct PreItem {
     static constexpr int NLIST = SAMPLE ? NCB : 1;
@@ -387,6 +401,9 @@ struct PreItem {
     unsigned pend_pos, pend_row, pend_col;  // pass 2: this lane's candidate of the previous tile ...
     float pend_s;                           // ... whose position atomic is in flight
     f32x16 acc[PF_RB][NCB];
+#ifdef LMI_PF_STAMPS
+    unsigned long long st_acc[12], st_last;
+#endif
 
     template <int SLOT>
     __device__ __forceinline__ void issue_dma(const uint4* ap0, const uint4* ap1, const uint4* qp) {
@@ -551,6 +568,7 @@ struct PreItem {
 
     __device__ __forceinline__ void epilogue_emit(int rb_tile0, int n_b, size_t col0) {
         flush_pending();
+        PF_STAMP(8)
         const unsigned row0 = (unsigned)((rb_tile0 + wr * PF_RB) * 32);  // first of this wave's 64 rows
         if (row0 + 32u * PF_RB > (unsigned)n_b) {  // wave-uniform: the bucket's ragged end (zero-padded / clamped rows)
 #pragma unroll
@@ -563,43 +581,64 @@ struct PreItem {
         }
         // optimistic compaction: (column, row, shat) of every passing score -> list[0..cnt); more than 64
         // discards the list and re-emits the whole tile on the direct path below
-        uint2* list = sList + w * 64;
+        uint2* list = sList + w * PF_LIST;
         int tot = 0;  // wave-uniform
         {
             // entry key = (column in tile) << 8 | (row in the wave's 64 rows); opaque so that the 128
             // per-(j,n,r) keys are formed where they are used (base + literal), not hoisted out of the K loop
             unsigned kb = (unsigned)((c << 8) | (4 * h));
             asm volatile("" : "+v"(kb));
+            // Scores that pass are rare (~16 of the wave's 8 192), so the registers are tested in groups of LMI_PF_EPI_G
+            // through their maximum and the per-register pass (ballot + compaction) runs for a group with a hit only;
+            // the no-hit case is the FALL-THROUGH path (a taken branch per register cost ~40 cycles x 128).
 #pragma unroll
             for (int j = 0; j < PF_RB; ++j)
 #pragma unroll
                 for (int n = 0; n < NCB; ++n)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        bool pass = acc[j][n][r] >= thr[n];  // thr = +inf for idle columns
+                    for (int r0 = 0; r0 < 16; r0 += LMI_PF_EPI_G) {
+                        // one v_max / v_max3 + v_max (fmaxf() also canonicalises both operands: 3 instructions per pair); a quiet
+                        // NaN (ragged rows) never wins
+                        float gm = acc[j][n][r0];
+                        if (LMI_PF_EPI_G == 2) asm("v_max_f32 %0, %1, %2" : "=v"(gm) : "v"(acc[j][n][r0]), "v"(acc[j][n][r0 + (LMI_PF_EPI_G > 1 ? 1 : 0)]));
+                        if (LMI_PF_EPI_G == 4) {
+                            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(gm) : "v"(acc[j][n][r0]), "v"(acc[j][n][r0 + (LMI_PF_EPI_G > 1 ? 1 : 0)]), "v"(acc[j][n][r0 + (LMI_PF_EPI_G > 2 ? 2 : 0)]));
+                            asm("v_max_f32 %0, %1, %2" : "=v"(gm) : "v"(gm), "v"(acc[j][n][r0 + (LMI_PF_EPI_G > 3 ? 3 : 0)]));
+                        }
+                        static_assert(LMI_PF_EPI_G == 1 || LMI_PF_EPI_G == 2 || LMI_PF_EPI_G == 4, "group maximum written out for 1, 2, 4");
+                        bool gpass = gm >= thr[n];  // thr = +inf for idle columns
 #ifdef LMI_ABL_NOEMIT
-                        pass = pass && thr[n] == 12345.678f;  // never true, keeps the compares alive
+                        gpass = gpass && thr[n] == 12345.678f;  // never true, keeps the compares alive
 #endif
-                        const unsigned long long mask = __ballot(pass);
-                        if (mask) {
-                            if (pass) {
-                                const int my = tot + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                                                    __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                                if (my < 64)
-                                    list[my] = make_uint2(kb + (unsigned)(((n * 32) << 8) | (j * 32 + (r & 3) + 8 * (r >> 2))),
-                                                          __float_as_uint(acc[j][n][r]));
+                        const unsigned long long gmask = __ballot(gpass);
+                        if (__builtin_expect(gmask != 0ull, 0)) {
+                            // every lane of the group with a hit takes LMI_PF_EPI_G consecutive list entries (one ballot per
+                            // group, no branch per register); a register below the threshold leaves its entry invalid
+                            if (gpass) {
+                                const int my = tot + LMI_PF_EPI_G * (int)__builtin_amdgcn_mbcnt_hi((unsigned)(gmask >> 32),
+                                                                                                  __builtin_amdgcn_mbcnt_lo((unsigned)gmask, 0u));
+                                uint2* at = list + min(my, 64);  // past the list: its slack entries (the tile then takes the direct path)
+#pragma unroll
+                                for (int u = 0; u < LMI_PF_EPI_G; ++u) {
+                                    const int r = r0 + u;
+                                    const unsigned key = kb + (unsigned)(((n * 32) << 8) | (j * 32 + (r & 3) + 8 * (r >> 2)));
+                                    at[u] = make_uint2(acc[j][n][r] >= thr[n] ? key : 0xffffffffu, __float_as_uint(acc[j][n][r]));
+                                }
                             }
-                            tot += (int)__popcll(mask);
+                            tot += LMI_PF_EPI_G * (int)__popcll(gmask);
                         }
                     }
         }
+        PF_STAMP(9)
         if (tot > 0 && tot <= 64) {
             if (lane < tot) {
                 const uint2 e = list[lane];
-                pend_col = (unsigned)(col0 + (e.x >> 8));
-                pend_row = row0 + (e.x & 255u);
-                pend_s = __uint_as_float(e.y);
-                pend_pos = atomicAdd(P.cand_cnt + pend_col, 1u);
+                if (e.x != 0xffffffffu) {
+                    pend_col = (unsigned)(col0 + (e.x >> 8));
+                    pend_row = row0 + (e.x & 255u);
+                    pend_s = __uint_as_float(e.y);
+                    pend_pos = atomicAdd(P.cand_cnt + pend_col, 1u);
+                }
             }
         } else if (tot > 64) {
             float t3[NCB];
@@ -620,6 +659,7 @@ struct PreItem {
                             }
                         }
         }
+        PF_STAMP(10)
 #pragma unroll
         for (int j = 0; j < PF_RB; ++j)
 #pragma unroll
@@ -633,6 +673,10 @@ struct PreItem {
     // SAMPLE: `ch` is the part p in [0, P.parts): the item covers the tiles (p + P.parts*i)*PF_SAMPLE, i = 0,1,..
     // of the whole bucket and writes its 10 best values; !SAMPLE: chunk `ch`, every tile.
     __device__ __forceinline__ void run(int b, int cbt0, int ncb_tile, int cbofs_, bool idle, int ch) {
+#ifdef LMI_PF_STAMPS
+        for (int i = 0; i < 12; ++i) st_acc[i] = 0;
+        st_last = __builtin_readcyclecounter();
+#endif
         const int tid = threadIdx.x;
         lane = tid & 63; h = lane >> 5; c = lane & 31;
         w = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: stage pointers and LDS destinations stay in SGPRs
@@ -718,7 +762,9 @@ struct PreItem {
         // all at once after the barrier (where both waves of a SIMD sit in DMA issue with the MFMA pipe idle).
 #define PF_STEP(SLOT, LIVE)                                                                       \
         PF_WAIT_LANDED                                                                            \
+        PF_STAMP(0)                                                                               \
         PF_BARRIER                                                                                \
+        PF_STAMP(1)                                                                               \
         if (NG == 2 && PF_FUSED && (LIVE)) {                                                      \
             step_fused<SLOT, (SLOT + RING - 1) % RING>(ap0, qp, SLOT > 0 || t > 0);               \
             PF_ADVANCE                                                                            \
@@ -726,7 +772,9 @@ struct PreItem {
             issue_dma<(SLOT + RING - 1) % RING>(ap0, ap1, qp);                                    \
             PF_ADVANCE                                                                            \
             if (LIVE) compute_dma<SLOT>();                                                        \
-        }
+        }                                                                                         \
+        PF_STAMP(2)
+        PF_STAMP(4)
         if (nvt > 0) {
             issue_dma<0>(ap0, ap1, qp);
             PF_ADVANCE
@@ -749,9 +797,20 @@ struct PreItem {
             if (NG == 2 && PF_FUSED) mma<1>(p_a, p_b);  // the tile's last deferred group
             if (SAMPLE) epilogue_sample(rb_in_b0 + vt * TSTEP * 4 * PF_RB, n_b);
             else epilogue_emit(rb_in_b0 + vt * TSTEP * 4 * PF_RB, n_b, col0);
+            PF_STAMP(3)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the look-ahead before the LDS is reused
         __syncthreads();
+#ifdef LMI_PF_STAMPS
+        if (!SAMPLE) {
+            PF_STAMP(5)
+            st_acc[7] = (unsigned long long)nvt;
+            if (lane == 0) {
+                unsigned long long* g = reinterpret_cast<unsigned long long*>(P.bound) + w * 12;
+                for (int i = 0; i < 12; ++i) atomicAdd(g + i, st_acc[i]);
+            }
+        }
+#endif
 #undef PF_STEP
 #undef PF_ADVANCE
 #undef PF_WAIT_LANDED
@@ -854,7 +913,7 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void prefilter_kernel(Pr
     constexpr bool RING4 = NG == 2 && LMI_PF_RING2 == 4;
     __shared__ __attribute__((aligned(16))) uint4 sB3[RING4 ? 4 * NG * PF_STAGE_G * 64 : 1];
     __shared__ __attribute__((aligned(16))) uint4 sA3[RING4 ? 4 * PF_RB * PF_STAGE_G * 64 : 1];
-    __shared__ uint2 sList[SAMPLE ? 1 : 4 * NG * 64];
+    __shared__ uint2 sList[SAMPLE ? 1 : 4 * NG * PF_LIST];
 #define PF_ITEM_ARGS P, sB0, sB1, sB2, sA0, sA1, sA2, sB3, sA3, sList
     int* s_item = reinterpret_cast<int*>(sB1);
     int grp = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & (NGRP - 1));

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from scan_ab import load_capi  # noqa: E402
 
 
-def main():
+def main(report=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("lib")
     ap.add_argument("--n", type=int, default=10_000_000)
@@ -49,6 +49,8 @@ def main():
     for _ in range(3):
         idx.scan_topk_device(q, bo, nb, 10, out_d, out_i)
     t = idx.timings()
+    if report is not None:
+        return report(capi, idx, t)
     print("pass 2:", float(t[capi.T_PF_EMIT]), "ms")
     raw = idx.debug_peek("pf_bound", 2 * 8 * 12 * 8).view(np.uint64).reshape(2, 8, 12).astype(np.float64)
     # epi = rest of the epilogue after its two inner stamps (atomic issue); flush = waiting for / storing the previous
