@@ -1048,7 +1048,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         Q.fallback = h->fallback.as<int>();
         Q.nkeep = h->nkeep.as<int>();
 #ifndef LMI_ABL_NOEMIT  // timing-only ablation builds emit nothing: no re-rank, no fallback
-        if (h->rescore_streamed && h->d % 4 == 0 && h->d <= RS_MAXD) {
+        if (h->rescore_streamed && h->d % 4 == 0 && h->d <= RS_MAXD && RC_WAVES * rc_wave_lds(h->d, 4) <= 160 * 1024) {
             // selection at full occupancy, then the survivors' rows streamed through LDS in coalesced pieces (lmi_rescore.h)
             const int G = nb % 4 == 0 ? 4 : nb % 3 == 0 ? 3 : nb % 2 == 0 ? 2 : 1;  // slots of one query per wave
             const int groups = nslots / G;

@@ -637,7 +637,11 @@ struct PreItem {
                     pend_col = (unsigned)(col0 + (e.x >> 8));
                     pend_row = row0 + (e.x & 255u);
                     pend_s = __uint_as_float(e.y);
+#ifdef LMI_ABL_NOATOMIC  // timing-only ablation: no returning atomic in the K pipeline (positions collide)
+                    pend_pos = (unsigned)lane;
+#else
                     pend_pos = atomicAdd(P.cand_cnt + pend_col, 1u);
+#endif
                 }
             }
         } else if (tot > 64) {

@@ -8,9 +8,9 @@
 //   select_kernel    one wave per (query, rank) slot: That by bisection on the candidates' keys, the survivor
 //                    rows -> surv_row[slot][..] (the first half of select_rescore_kernel, at full occupancy);
 //   rescore_kernel   one wave per G slots of ONE query (G | n_buckets, <= 4), one wave per SIMD.  The wave's
-//                    survivors are processed 32 rows at a time; their rows are STREAMED through LDS in chunks of
-//                    128 floats: one LDS-DMA piece moves 1 KiB = 512 contiguous bytes of two rows (lane -> (row,
-//                    16-byte segment), rows 528 bytes apart in LDS so that the 32 chains' ds_read_b128 hit distinct
+//                    survivors are processed 64 rows at a time (one lane per chain); their rows are STREAMED through LDS in
+//                    chunks of 64 floats: one LDS-DMA piece moves 1 KiB = 256 contiguous bytes of four rows (lane -> (row,
+//                    16-byte segment), rows 272 bytes apart in LDS so that the chains' ds_read_b128 hit distinct
 //                    banks), chunk c+1 is in flight while lane r runs the canonical chain acc = fmaf(q[k], x[k], acc)
 //                    over chunk c of row r (q broadcast from LDS).  The wave owns its buffers: no barriers, the
 //                    ring is ordered by the wave's own counted `s_waitcnt vmcnt`.  Then, per slot, the 10 best by
@@ -22,8 +22,20 @@
 
 namespace lmi {
 
-constexpr int RC_ROWS = 32;                       // chains per wave and batch
-constexpr int RC_CHUNK = 128;                     // floats of a row per chunk
+// A/B on MI355X at C2 (rows, chunk, depth -> re-rank phase): (32, 128, 2) 0.574 ms, (64, 64, 2) 0.497, (64, 32, 3) 0.496,
+// (32, 64, 3) 0.553, (32, 32, 4) 0.579: a wave's ~48 survivors are ONE batch of 64 chains instead of 32 + 16
+#ifndef LMI_RC_ROWS
+#define LMI_RC_ROWS 64
+#endif
+#ifndef LMI_RC_CHUNK
+#define LMI_RC_CHUNK 64
+#endif
+#ifndef LMI_RC_DEPTH
+#define LMI_RC_DEPTH 2
+#endif
+constexpr int RC_ROWS = LMI_RC_ROWS;              // chains per wave and batch (32 or 64)
+constexpr int RC_CHUNK = LMI_RC_CHUNK;            // floats of a row per chunk (a multiple of 32)
+constexpr int RC_DEPTH = LMI_RC_DEPTH;            // chunk buffers per wave: RC_DEPTH - 1 chunks in flight while one is chained
 constexpr int RC_PITCH = RC_CHUNK * 4 + 16;       // bytes between rows in a chunk buffer (bank spread)
 constexpr int RC_PIECES = (RC_ROWS * RC_PITCH + 1023) / 1024;  // 17 LDS-DMA pieces per chunk (16 896 bytes of rows)
 constexpr int RC_BUF = RC_PIECES * 1024;          // a chunk buffer holds WHOLE pieces: the last one writes 512 bytes past the rows
@@ -117,7 +129,8 @@ __global__ __launch_bounds__(256) void select_kernel(RescoreParams P, SelectOut 
 }
 
 // dynamic LDS per wave: 2 chunk buffers | q [d] | rows [G*PF_KEEP] | scores [G*PF_KEEP]
-__host__ __device__ inline int rc_wave_lds(int d, int G) { return 2 * RC_BUF + d * 4 + G * PF_KEEP * 8; }
+__host__ __device__ inline int rc_wave_lds(int d, int G) { return RC_DEPTH * RC_BUF + d * 4 + G * PF_KEEP * 8; }
+static_assert(RC_CHUNK % 32 == 0 && (RC_ROWS == 32 || RC_ROWS == 64) && RC_DEPTH >= 2 && RC_DEPTH <= 4, "rescore_kernel shapes");
 
 template <int G>
 __global__ __launch_bounds__(64 * RC_WAVES, 1) void rescore_kernel(RescoreParams P, SelectOut O) {
@@ -128,10 +141,8 @@ __global__ __launch_bounds__(64 * RC_WAVES, 1) void rescore_kernel(RescoreParams
     const int p0 = O.active[1 + wid] * G;
     const int d = P.d;
     unsigned char* mine = rc_smem + (size_t)wv * rc_wave_lds(d, G);
-    unsigned char* buf0 = mine;
-    unsigned char* buf1 = mine + RC_BUF;
-    float* qs = reinterpret_cast<float*>(mine + 2 * RC_BUF);
-    unsigned* krow = reinterpret_cast<unsigned*>(mine + 2 * RC_BUF + d * 4);
+    float* qs = reinterpret_cast<float*>(mine + RC_DEPTH * RC_BUF);
+    unsigned* krow = reinterpret_cast<unsigned*>(mine + RC_DEPTH * RC_BUF + d * 4);
     float* ksc = reinterpret_cast<float*>(krow + G * PF_KEEP);
     const float FMAXV = 3.402823466e+38f;
     // the survivor lists of the wave's slots, slot after slot, and the wave's query (G divides nb: one query per wave)
@@ -183,15 +194,19 @@ __global__ __launch_bounds__(64 * RC_WAVES, 1) void rescore_kernel(RescoreParams
             }
         };
         float acc = 0.0f;
-        issue(0, buf0);
+#pragma unroll
+        for (int c = 0; c < RC_DEPTH - 1; ++c)
+            if (c < nchunks) issue(c, mine + c * RC_BUF);
+        int slot = 0;  // c % RC_DEPTH
         for (int c = 0; c < nchunks; ++c) {
-            unsigned char* cur = (c & 1) ? buf1 : buf0;
-            if (c + 1 < nchunks) {
-                issue(c + 1, (c & 1) ? buf0 : buf1);
-                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(RC_PIECES) : "memory");  // chunk c landed, c+1 may be out
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            unsigned char* cur = mine + slot * RC_BUF;
+            const int ahead = min(RC_DEPTH - 1, nchunks - 1 - c);  // chunks that may stay in flight once chunk c has landed
+            if (c + RC_DEPTH - 1 < nchunks) issue(c + RC_DEPTH - 1, mine + (slot == 0 ? RC_DEPTH - 1 : slot - 1) * RC_BUF);
+            if (ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * RC_PIECES) : "memory");
+            else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * RC_PIECES) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(RC_PIECES) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            slot = slot + 1 == RC_DEPTH ? 0 : slot + 1;
             if (lane < nrows) {
                 typedef float f32x4 __attribute__((ext_vector_type(4)));
                 const unsigned xa = (unsigned)reinterpret_cast<uintptr_t>(cur) + (unsigned)lane * RC_PITCH;
