@@ -1054,17 +1054,19 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
             const int groups = nslots / G;
             CHK(h->surv_row.reserve((size_t)nslots * PF_KEEP * 4));
             CHK(h->rs_flag.reserve((size_t)groups * 4));
-            CHK(h->rs_active.reserve((size_t)(groups + 1) * 4));
+            const int sub_cap = cdiv(groups, RC_SUB);
+            CHK(h->rs_active.reserve((size_t)(RC_SUB + RC_SUB * sub_cap) * 4));
             SelectOut O;
             O.surv_row = h->surv_row.as<unsigned>();
             O.G = G;
             O.grp_flag = h->rs_flag.as<int>();
             O.active = h->rs_active.as<int>();
+            O.sub_cap = sub_cap;
             {
                 FillRanges Zr;
                 Zr.count = 2;
                 Zr.p[0] = reinterpret_cast<unsigned*>(O.grp_flag); Zr.n[0] = groups; Zr.v[0] = 0u;
-                Zr.p[1] = reinterpret_cast<unsigned*>(O.active); Zr.n[1] = 1; Zr.v[1] = 0u;
+                Zr.p[1] = reinterpret_cast<unsigned*>(O.active); Zr.n[1] = RC_SUB; Zr.v[1] = 0u;
                 fill_ranges_kernel<<<cdiv(groups, 1024), 256, 0, h->stream>>>(Zr);
                 HIPCHK(hipGetLastError());
             }

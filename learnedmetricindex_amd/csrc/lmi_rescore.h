@@ -45,9 +45,73 @@ struct SelectOut {
     unsigned* surv_row;   // [nslots][PF_KEEP]
     int G;                // slots per rescore wave
     int* grp_flag;        // [groups] zeroed per call: the group has a slot with survivors
-    int* active;          // [1 + groups]: count, then the groups to re-score (any order; a rank of a sharded index
-                          // owns 1/world of the slots: its rescore waves are packed into the first blocks)
+    int* active;          // the groups to re-score, compacted (a rank of a sharded index owns 1/world of the slots: its
+                          // rescore waves are packed into the first blocks) as RC_SUB sub-lists: [RC_SUB] counts, then
+                          // [RC_SUB][sub_cap] group numbers; group g goes to sub-list g % RC_SUB (10 000 returning atomics on
+                          // ONE counter were most of select_kernel's 139 us)
+    int sub_cap;          // ceil(groups / RC_SUB)
 };
+constexpr int RC_SUB = 64;
+
+// The part of select_kernel after the candidate count is known, for slots of up to 64 PERV candidates.  The bisection is
+// issue-bound (32 steps x one ballot per 64 candidates): a slot emits ~160, so PERV = 4 does a quarter of the work of the
+// general PERV = 16 (select_kernel: 140 -> 45 us at C2).
+template <int PERV, int SPEC>
+__device__ __forceinline__ void select_tail(const RescoreParams& P, const SelectOut& O, int p, int col, int lane, unsigned cnt,
+                                            const float* __restrict__ cs, const unsigned* __restrict__ cr,
+                                            const float (&s_spec)[SPEC], const unsigned (&r_spec)[SPEC]) {
+    const int nper = (int)((cnt + 63u) >> 6);
+    unsigned key[PERV];  // monotone image of shat; 0 = no candidate
+#pragma unroll
+    for (int i = 0; i < PERV; ++i) {
+        const int e = lane + 64 * i;
+        key[i] = 0u;
+        if (i < nper && e < (int)cnt) {
+            const unsigned bits = __float_as_uint(i < SPEC ? s_spec[i < SPEC ? i : 0] : cs[e]);
+            key[i] = bits ^ ((bits >> 31) ? 0xffffffffu : 0x80000000u);
+        }
+    }
+    float pv = -INFINITY;  // fewer than 10 candidates: everything survives
+    if (cnt >= (unsigned)KPB) {
+        unsigned T = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned probe = T | (1u << bit);
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < PERV; ++i)
+                if (PERV <= 4 || i < nper) c += (int)__popcll(__ballot(key[i] >= probe));  // empty entries (key 0) never count: probe >= 1
+            if (c >= KPB) T = probe;
+        }
+        pv = __uint_as_float(T ^ ((T >> 31) ? 0x80000000u : 0xffffffffu));
+    }
+    const float cut = pv - P.eps2[col];
+    const unsigned cbits = __float_as_uint(cut);
+    const unsigned kcut = cut != cut ? 1u : cbits ^ ((cbits >> 31) ? 0xffffffffu : 0x80000000u);
+    unsigned* out = O.surv_row + (size_t)p * PF_KEEP;
+    unsigned nk = 0;
+#pragma unroll
+    for (int i = 0; i < PERV; ++i) {
+        if (i < nper) {
+            const bool keep = key[i] != 0u && key[i] >= kcut;
+            const unsigned long long bal = __ballot(keep);
+            if (keep) {
+                const unsigned k = nk + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+                if (k < (unsigned)PF_KEEP) out[k] = i < SPEC ? r_spec[i < SPEC ? i : 0] : cr[lane + 64 * i];
+            }
+            nk += (unsigned)__popcll(bal);
+        }
+    }
+    if (lane == 0) {
+        if (nk > (unsigned)PF_KEEP) P.fallback[p] = 1;
+        else {
+            P.nkeep[p] = (int)nk;
+            if (nk > 0 && atomicExch(&O.grp_flag[p / O.G], 1) == 0) {
+                const int g = p / O.G, sub = g % RC_SUB;
+                O.active[RC_SUB + sub * O.sub_cap + atomicAdd(&O.active[sub], 1)] = g;
+            }
+        }
+    }
+}
 
 // That + survivors of one slot; unvisited slots get their (inf, 0) rank list here.
 __global__ __launch_bounds__(256) void select_kernel(RescoreParams P, SelectOut O) {
@@ -78,54 +142,8 @@ __global__ __launch_bounds__(256) void select_kernel(RescoreParams P, SelectOut 
         if (lane == 0) P.fallback[p] = 1;
         return;
     }
-    const int nper = (int)((cnt + 63u) >> 6);
-    unsigned key[PER];  // monotone image of shat; 0 = no candidate
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int e = lane + 64 * i;
-        key[i] = 0u;
-        if (i < nper && e < (int)cnt) {
-            const unsigned bits = __float_as_uint(i < SPEC ? s_spec[i < SPEC ? i : 0] : cs[e]);
-            key[i] = bits ^ ((bits >> 31) ? 0xffffffffu : 0x80000000u);
-        }
-    }
-    float pv = -INFINITY;  // fewer than 10 candidates: everything survives
-    if (cnt >= (unsigned)KPB) {
-        unsigned T = 0;
-        for (int bit = 31; bit >= 0; --bit) {
-            const unsigned probe = T | (1u << bit);
-            int c = 0;
-#pragma unroll
-            for (int i = 0; i < PER; ++i)
-                if (i < nper) c += (int)__popcll(__ballot(key[i] >= probe));
-            if (c >= KPB) T = probe;
-        }
-        pv = __uint_as_float(T ^ ((T >> 31) ? 0x80000000u : 0xffffffffu));
-    }
-    const float cut = pv - P.eps2[col];
-    const unsigned cbits = __float_as_uint(cut);
-    const unsigned kcut = cut != cut ? 1u : cbits ^ ((cbits >> 31) ? 0xffffffffu : 0x80000000u);
-    unsigned* out = O.surv_row + (size_t)p * PF_KEEP;
-    unsigned nk = 0;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        if (i < nper) {
-            const bool keep = key[i] != 0u && key[i] >= kcut;
-            const unsigned long long bal = __ballot(keep);
-            if (keep) {
-                const unsigned k = nk + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
-                if (k < (unsigned)PF_KEEP) out[k] = i < SPEC ? r_spec[i < SPEC ? i : 0] : cr[lane + 64 * i];
-            }
-            nk += (unsigned)__popcll(bal);
-        }
-    }
-    if (lane == 0) {
-        if (nk > (unsigned)PF_KEEP) P.fallback[p] = 1;
-        else {
-            P.nkeep[p] = (int)nk;
-            if (nk > 0 && atomicExch(&O.grp_flag[p / O.G], 1) == 0) O.active[1 + atomicAdd(&O.active[0], 1)] = p / O.G;
-        }
-    }
+    if (cnt <= 256u) select_tail<4, SPEC>(P, O, p, col, lane, cnt, cs, cr, s_spec, r_spec);
+    else select_tail<PER, SPEC>(P, O, p, col, lane, cnt, cs, cr, s_spec, r_spec);
 }
 
 // dynamic LDS per wave: 2 chunk buffers | q [d] | rows [G*PF_KEEP] | scores [G*PF_KEEP]
@@ -137,8 +155,17 @@ __global__ __launch_bounds__(64 * RC_WAVES, 1) void rescore_kernel(RescoreParams
     extern __shared__ __attribute__((aligned(16))) unsigned char rc_smem[];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wid = blockIdx.x * RC_WAVES + wv;
-    if (wid >= O.active[0]) return;
-    const int p0 = O.active[1 + wid] * G;
+    // wave wid -> the wid-th entry of the concatenated sub-lists (inclusive prefix of the 64 counts across the lanes)
+    int incl = O.active[lane];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    const int sub = (int)__popcll(__ballot(incl <= wid));  // sub-lists that end at or before entry wid
+    if (sub >= RC_SUB) return;                             // wid >= total
+    const int before = sub ? __shfl(incl, sub - 1, 64) : 0;
+    const int p0 = O.active[RC_SUB + sub * O.sub_cap + (wid - before)] * G;
     const int d = P.d;
     unsigned char* mine = rc_smem + (size_t)wv * rc_wave_lds(d, G);
     float* qs = reinterpret_cast<float*>(mine + RC_DEPTH * RC_BUF);
