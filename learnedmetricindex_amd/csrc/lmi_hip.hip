@@ -1004,7 +1004,9 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         constexpr int PF_BLOCKS_PER_CU = PF_NG == 1 ? 2 : 1;
         prefilter_kernel<true, PF_NG><<<h->num_cus * PF_BLOCKS_PER_CU, 256 * PF_NG, 0, h->stream>>>(F);   // pass 1: bounds from a sample
         HIPCHK(hipGetLastError());
-        bound_merge_kernel<<<cdiv((long long)ncols, 256), 256, 0, h->stream>>>(F.bound, (long long)ncols, pf_parts, F.bound1);
+        if (pf_parts <= 4) bound_merge_kernel<4><<<cdiv((long long)ncols * 4, 256), 256, 0, h->stream>>>(F.bound, (long long)ncols, pf_parts, F.bound1);
+        else if (pf_parts <= 8) bound_merge_kernel<8><<<cdiv((long long)ncols * 8, 256), 256, 0, h->stream>>>(F.bound, (long long)ncols, pf_parts, F.bound1);
+        else bound_merge_kernel<16><<<cdiv((long long)ncols * 16, 256), 256, 0, h->stream>>>(F.bound, (long long)ncols, pf_parts, F.bound1);
         HIPCHK(hipGetLastError());
         if (h->debug_emit_all) {  // test hook: bound = -inf, every row of the bucket is a candidate
             FillRanges D;
