@@ -135,6 +135,7 @@ struct lmi_index {
 #define LMI_PASS2_QR_DEFAULT false
 #endif
     bool pass2_qr = LMI_PASS2_QR_DEFAULT;   // lmi_set_prefilter(h, 2) / LMI_PASS2_QR=1: pass2_qr_kernel (lmi_pass2_qr.h) instead of prefilter_kernel<false, 2>
+    size_t stamps_off = 0;         // developer builds: byte offset of the phase stamps inside pf_bound
     bool rescore_streamed = true;  // lmi_rescore.h (LMI_RESCORE_SIMPLE=1 in the environment: select_rescore_kernel)
     int last_nslots = 0, last_nb = 0;
     bool last_fast = false;
@@ -915,8 +916,8 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         for (int b = 0; b < L; ++b) { owned_rows += h->h_nb_rows[b]; owned_buckets += h->h_nb_rows[b] > 0; }
         const double pairs_est = (double)nslots * (double)owned_rows / (double)std::max<long long>(1, h->N) / (32.0 * 4 * PF_NG) + (double)owned_buckets;
         pf_parts = pairs_est * 4 >= 4.0 * h->num_cus ? 4 : pairs_est * 8 >= 4.0 * h->num_cus ? 8 : PF_PARTS_MAX;
-        CHK(h->pf_bound.reserve(ncols * pf_parts * KPB * 4));
-        fill(h->pf_bound.p, (long long)(ncols * pf_parts * KPB), 0xFF800000u /* -inf */);
+        CHK(h->pf_bound.reserve(ncols * pf_parts * 4 * PF_LK * 4 + 4096));  // + room for the developer builds' phase stamps
+        fill(h->pf_bound.p, (long long)(ncols * pf_parts * 4 * PF_LK), 0xFF800000u /* -inf */);
         fill(h->cand_cnt.p, (long long)ncols, 0u);
         fill(h->stats.as<long long>() + 2, 4, 0u);
     }
@@ -1001,12 +1002,17 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         F.cand_cnt = h->cand_cnt.as<unsigned>();
         F.cand_row = h->cand_row.as<unsigned>();
         F.cand_s = h->cand_s.as<float>();
+        h->stamps_off = (ncols * pf_parts * 4 * PF_LK * 4 + 255) / 256 * 256;
+        F.stamps = reinterpret_cast<unsigned long long*>(static_cast<char*>(h->pf_bound.p) + h->stamps_off);
+#if defined(LMI_QR_STAMPS) || defined(LMI_PF_STAMPS)
+        HIPCHK(hipMemsetAsync(F.stamps, 0, 2 * 8 * 12 * 8, h->stream));
+#endif
         constexpr int PF_BLOCKS_PER_CU = PF_NG == 1 ? 2 : 1;
         prefilter_kernel<true, PF_NG><<<h->num_cus * PF_BLOCKS_PER_CU, 256 * PF_NG, 0, h->stream>>>(F);   // pass 1: bounds from a sample
         HIPCHK(hipGetLastError());
-        if (pf_parts <= 4) bound_merge_kernel<4><<<cdiv((long long)ncols * 4, 256), 256, 0, h->stream>>>(F.bound, (long long)ncols, pf_parts, F.bound1);
-        else if (pf_parts <= 8) bound_merge_kernel<8><<<cdiv((long long)ncols * 8, 256), 256, 0, h->stream>>>(F.bound, (long long)ncols, pf_parts, F.bound1);
-        else bound_merge_kernel<16><<<cdiv((long long)ncols * 16, 256), 256, 0, h->stream>>>(F.bound, (long long)ncols, pf_parts, F.bound1);
+if (pf_parts <= 4) bound_merge_kernel<16><<<cdiv((long long)ncols * 16, 256), 256, 0, h->stream>>>(F.bound, (long long)ncols, F.bound1);
+        else if (pf_parts <= 8) bound_merge_kernel<32><<<cdiv((long long)ncols * 32, 256), 256, 0, h->stream>>>(F.bound, (long long)ncols, F.bound1);
+        else bound_merge_kernel<64><<<cdiv((long long)ncols * 64, 256), 256, 0, h->stream>>>(F.bound, (long long)ncols, F.bound1);
         HIPCHK(hipGetLastError());
         if (h->debug_emit_all) {  // test hook: bound = -inf, every row of the bucket is a candidate
             FillRanges D;
@@ -1015,9 +1021,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
             HIPCHK(hipGetLastError());
         }
         CHK(record(h, 5));
-#if defined(LMI_QR_STAMPS) || defined(LMI_PF_STAMPS)
-        HIPCHK(hipMemsetAsync(F.bound, 0, 2 * 8 * 12 * 8, h->stream));
-#endif
+
         // pass 2: candidates.  The query-resident form (opt-in: measured slower) needs a col-block's
         // fragments to fit a wave's registers (d <= 768)
         if (h->pass2_qr && PF_NG == 2 && h->KG16 <= QR_KMAX) {
@@ -1614,10 +1618,12 @@ extern "C" LMI_API int lmi_debug_peek(lmi_index* h, const char* name, void* dst,
     CHK(set_dev(h));
     HIPCHK(hipStreamSynchronize(h->stream));
     DevBuf* b = nullptr;
+    size_t off = 0;
     if (!strcmp(name, "pf_bound")) b = &h->pf_bound;
+    if (!strcmp(name, "pf_stamps")) { b = &h->pf_bound; off = h->stamps_off; }
     if (!b) return fail("lmi_debug_peek: unknown buffer '%s'", name);
-    if (bytes < 0 || (size_t)bytes > b->cap) return fail("lmi_debug_peek: %lld bytes asked of a %zu-byte buffer", (long long)bytes, b->cap);
-    if (bytes) HIPCHK(hipMemcpy(dst, b->p, (size_t)bytes, hipMemcpyDeviceToHost));
+    if (bytes < 0 || off + (size_t)bytes > b->cap) return fail("lmi_debug_peek: %lld bytes asked of a %zu-byte buffer", (long long)bytes, b->cap);
+    if (bytes) HIPCHK(hipMemcpy(dst, static_cast<char*>(b->p) + off, (size_t)bytes, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -387,7 +387,7 @@ struct QrItem {
         QR_STAMP(6)
         st_acc[7] = (unsigned long long)nrb;
         if (lane == 0) {
-            unsigned long long* g = reinterpret_cast<unsigned long long*>(P.bound) + ((split ? 1 : 0) * 8 + w) * 12;
+            unsigned long long* g = P.stamps + ((split ? 1 : 0) * 8 + w) * 12;
             for (int i = 0; i < 12; ++i) atomicAdd(g + i, st_acc[i]);
         }
 #endif

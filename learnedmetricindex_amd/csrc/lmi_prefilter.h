@@ -339,12 +339,13 @@ struct PrefilterParams {
     const int* grp_total;
     unsigned* head;       // [NGRP] pass-2 queue heads; [NGRP] = pass-1 head
     int parts;            // pass-1 items per (bucket, query tile): 4, 8 or 16
-    float* bound;         // [columns][parts][KPB] pass 1: each part's 10 best sampled shat
+    float* bound;         // [columns][parts][4 row-waves][PF_LK] pass 1: the best sampled shat of every 64-row strip
     float* bound1;        // [columns] bound_merge_kernel: 10th best of the union of the parts -> pass 2
     const float* eps2;    // 2 eps' per column
     unsigned* cand_cnt;   // [columns]
     unsigned* cand_row;   // [columns][PF_CAP]
     float* cand_s;        // [columns][PF_CAP]
+    unsigned long long* stamps;  // LMI_PF_STAMPS / LMI_QR_STAMPS builds: phase cycles (behind the pass-1 lists in pf_bound)
 };
 
 // Pass 1 keeps the PF_LK best values per lane and column.  The bound only has to be the 10th best of SOME
@@ -359,10 +360,18 @@ constexpr int PF_LIST = 64 + LMI_PF_EPI_G;  // compaction-list entries per wave 
 #define LMI_PF_LK 4
 #endif
 constexpr int PF_LK = LMI_PF_LK;
-__device__ __forceinline__ void vlist_insert(float (&v)[PF_LK], float s) {  // values-only sorted insert
+// one instruction each (fmaxf / fminf also canonicalise both operands: three); a quiet NaN operand yields the other one
+__device__ __forceinline__ float vmaxf(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vminf(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ void vlist_insert(float (&v)[PF_LK], float s) {  // values-only sorted insert (descending)
+    // compare-exchange chain: the carried value sinks through the list; 2 PF_LK - 1 min/max, no branch, no predicate
+    // (v_max/v_min return the other operand for a NaN: a NaN never enters the list)
 #pragma unroll
-    for (int t = PF_LK - 1; t > 0; --t) v[t] = (s > v[t - 1]) ? v[t - 1] : ((s > v[t]) ? s : v[t]);
-    v[0] = (s > v[0]) ? s : v[0];
+    for (int t = 0; t < PF_LK; ++t) {
+        const float hi = vmaxf(v[t], s);
+        if (t + 1 < PF_LK) s = vminf(v[t], s);
+        v[t] = hi;
+    }
 }
 
 // NG = wave groups per block.  NG 1: 4 waves, 256 vectors x 128 queries, two blocks per CU.  NG 2: 8 waves,
@@ -374,9 +383,21 @@ __device__ __forceinline__ void vlist_insert(float (&v)[PF_LK], float s) {  // v
 // issue), 3 epilogue rest (clearing the accumulators), 4 item start, 5 item end, 7 = tiles, 8 / 9 / 10 = the epilogue's flush /
 // threshold pass / list read + position atomics.  tools/pf_stamps.py prints the table.
 #ifdef LMI_PF_STAMPS
-#define PF_STAMP(PH) if (!SAMPLE) { const unsigned long long t_ = __builtin_readcyclecounter(); st_acc[PH] += t_ - st_last; st_last = t_; }
+#ifndef LMI_PF_STAMPS_SAMPLE
+#define LMI_PF_STAMPS_SAMPLE 0  // 1: stamp pass 1 (prefilter_kernel<true, .>) instead of pass 2
+#endif
+#define PF_STAMP(PH) if (SAMPLE == (LMI_PF_STAMPS_SAMPLE != 0)) { const unsigned long long t_ = __builtin_readcyclecounter(); st_acc[PH] += t_ - st_last; st_last = t_; }
+#define PF_STAMPS_WRITE(NVT)                                                                         \
+        if (SAMPLE == (LMI_PF_STAMPS_SAMPLE != 0)) {                                                 \
+            st_acc[7] = (unsigned long long)(NVT);                                                   \
+            if (lane == 0) {                                                                         \
+                unsigned long long* g = P.stamps + w * 12;                                           \
+                for (int i = 0; i < 12; ++i) atomicAdd(g + i, st_acc[i]);                            \
+            }                                                                                        \
+        }
 #else
 #define PF_STAMP(PH)
+#define PF_STAMPS_WRITE(NVT)
 #endif
 
 template <int NCB, bool SAMPLE, int NG>
@@ -533,6 +554,7 @@ struct PreItem {
 
     // pass 1: per-lane values-only top-10 lists (predicated insert; a ballot + branch per score was 20 % slower)
     __device__ __forceinline__ void epilogue_sample(int rb_tile0, int n_b) {
+        const bool ragged = (unsigned)((rb_tile0 + (wr + 1) * PF_RB) * 32) > (unsigned)n_b;  // wave-uniform: rows past the bucket's end
 #pragma unroll
         for (int j = 0; j < PF_RB; ++j) {
             const unsigned rowbase = (unsigned)((rb_tile0 + wr * PF_RB + j) * 32);
@@ -540,9 +562,9 @@ struct PreItem {
             for (int n = 0; n < NCB; ++n) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float s = acc[j][n][r];
-                    if (s > lv[SAMPLE ? n : 0][PF_LK - 1] && rowbase + acc_row(r, h) < (unsigned)n_b)
-                        vlist_insert(lv[SAMPLE ? n : 0], s);
+                    float s = acc[j][n][r];
+                    if (ragged && rowbase + acc_row(r, h) >= (unsigned)n_b) s = -INFINITY;  // zero-padded / clamped rows
+                    vlist_insert(lv[SAMPLE ? n : 0], s);
                     acc[j][n][r] = 0.0f;
                 }
             }
@@ -805,103 +827,61 @@ struct PreItem {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the look-ahead before the LDS is reused
         __syncthreads();
-#ifdef LMI_PF_STAMPS
-        if (!SAMPLE) {
-            PF_STAMP(5)
-            st_acc[7] = (unsigned long long)nvt;
-            if (lane == 0) {
-                unsigned long long* g = reinterpret_cast<unsigned long long*>(P.bound) + w * 12;
-                for (int i = 0; i < 12; ++i) atomicAdd(g + i, st_acc[i]);
-            }
-        }
-#endif
+        PF_STAMP(5)
 #undef PF_STEP
 #undef PF_ADVANCE
 #undef PF_WAIT_LANDED
 #undef PF_BARRIER
         if (!SAMPLE) {
             flush_pending();
+            PF_STAMPS_WRITE(nvt)
             return;
         }
-        // ---- pass 1: bound[col] = 10th best of the sample; the 8 (row-wave, half) value lists of a
-        //      column are merged in two rounds of 4 lists (5 KiB per group in sB0) + a carried list (sB1).
-        //      Every wave runs all four n steps (the groups may own different numbers of col-blocks and
-        //      must meet at the same barriers). ----
-        float* buf = reinterpret_cast<float*>(sB0) + grp * (32 * 4 * PF_LK);  // [32 cols][4 lists][PF_LK]
-        float* carry = reinterpret_cast<float*>(sB1) + grp * (32 * KPB);    // [32 cols][KPB], touched by its own thread only
+        // ---- pass 1: the lists go to bound[col][part][row-wave][PF_LK]; bound_merge_kernel takes the 10th best of a column's
+        //      parts x 4 lists.  The two halves of a wave (lanes l, l ^ 32: same column, other rows) are merged here, by
+        //      shuffles: any subset of the bucket's scores gives a valid bound, and one top-PF_LK list per 64 rows x sampled
+        //      tiles still holds the sample's ten best unless five of them fall into the same 64 rows.  (The block-wide
+        //      merge through LDS this replaces -- 8 barriers, 32 threads merging serially -- was 15 % of pass 1.) ----
+        if (!idle) {
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const bool live = n < NCB && !idle;
+            for (int n = 0; n < NCB; ++n) {
+                float other[PF_LK];
 #pragma unroll
-            for (int round = 0; round < 2; ++round) {
-                __syncthreads();
-                if (live && (wr >> 1) == round) {
-                    const int o = (c * 4 + ((wr & 1) * 2 + h)) * PF_LK;
+                for (int j = 0; j < PF_LK; ++j) other[j] = __shfl_xor(lv[SAMPLE ? n : 0][j], 32, 64);
 #pragma unroll
-                    for (int j = 0; j < PF_LK; ++j) buf[o + j] = lv[SAMPLE && n < NCB ? n : 0][j];
-                }
-                __syncthreads();
-                if (live && wr == 0 && lane < 32) {
-                    float best[KPB];
-                    unsigned heads = 0;
-                    int hc = (round == 0) ? KPB : 0;  // the carried list is empty in round 0
-                    const int o = lane * 4 * PF_LK;
+                for (int j = 0; j < PF_LK; ++j) vlist_insert(lv[SAMPLE ? n : 0], other[j]);
+                if (h == 0) {
+                    float* bl = P.bound + (((col0 + n * 32 + c) * (size_t)P.parts + ch) * 4 + wr) * PF_LK;
 #pragma unroll
-                    for (int j = 0; j < KPB; ++j) {
-                        float bs = -INFINITY;
-                        int bsrc = -1;
-#pragma unroll
-                        for (int src = 0; src < 4; ++src) {
-                            const int hd = (heads >> (4 * src)) & 15;
-                            if (hd < PF_LK) {
-                                const float s = buf[o + src * PF_LK + hd];
-                                if (s > bs) { bs = s; bsrc = src; }
-                            }
-                        }
-                        if (hc < KPB) {
-                            const float s = carry[lane * KPB + hc];
-                            if (s > bs) { bs = s; bsrc = 4; }
-                        }
-                        if (bsrc == 4) ++hc;
-                        else if (bsrc >= 0) heads += 1u << (4 * bsrc);
-                        best[j] = bs;
-                    }
-#pragma unroll
-                    for (int j = 0; j < KPB; ++j) carry[lane * KPB + j] = best[j];
-                    // this part's 10 best sampled values (descending; -inf where the sample ran out)
-                    if (round == 1) {
-                        float* bl = P.bound + (col0 + n * 32 + lane) * (size_t)(P.parts * KPB) + ch * KPB;
-#pragma unroll
-                        for (int j = 0; j < KPB; ++j) bl[j] = best[j];
-                    }
+                    for (int j = 0; j < PF_LK; ++j) bl[j] = lv[SAMPLE ? n : 0][j];
                 }
             }
         }
-        __syncthreads();
+        PF_STAMP(6)   // pass 1: the merge of the value lists
+        PF_STAMPS_WRITE(nvt)
     }
 };
 
-// 10th best of the union of the `nparts` sampled lists of every column (each sorted descending).  `nparts` lanes per column, lane i
-// holds part i's list in registers (one 40-byte load); ten steps of "largest head wins and advances", the maximum over the
-// column's lanes by butterfly steps.  (One thread per column chased 10 x nparts dependent loads: 33 us at 16 parts.)
-template <int LPC>  // lanes per column = parts (4, 8 or 16)
-__global__ __launch_bounds__(256) void bound_merge_kernel(const float* __restrict__ parts, long long ncols, int nparts, float* __restrict__ bound1) {
+// 10th best of the union of a column's nparts x 4 sampled lists (each PF_LK values, sorted descending).  One lane per list
+// (LPC = 4 nparts lanes per column: 16, 32 or 64), the list in registers (one 16-byte load); ten steps of "largest head wins
+// and advances", the maximum over the column's lanes by butterfly steps.
+template <int LPC>
+__global__ __launch_bounds__(256) void bound_merge_kernel(const float* __restrict__ lists, long long ncols, float* __restrict__ bound1) {
     const long long col = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / LPC;
-    const int part = threadIdx.x & (LPC - 1);
-    float v[KPB];
+    const int li = threadIdx.x & (LPC - 1);
+    float v[PF_LK];
 #pragma unroll
-    for (int j = 0; j < KPB; ++j) v[j] = -INFINITY;
-    if (col < ncols && part < nparts) {
-        const float* src = parts + (col * nparts + part) * KPB;
+    for (int j = 0; j < PF_LK; ++j) v[j] = -INFINITY;
+    if (col < ncols) {
+        const float* src = lists + (col * LPC + li) * PF_LK;
 #pragma unroll
-        for (int j = 0; j < KPB; ++j) v[j] = src[j];
+        for (int j = 0; j < PF_LK; ++j) v[j] = src[j];
     }
     float pv = -INFINITY;
 #pragma unroll
     for (int step = 0; step < KPB; ++step) {
-        // the lane's head is v[0]: a winner shifts its list up by one
-        float m = v[0];
-        int who = part;
+        float m = v[0];  // the lane's head; a winner shifts its list up by one
+        int who = li;
 #pragma unroll
         for (int o = 1; o < LPC; o <<= 1) {
             const float om = __shfl_xor(m, o, 64);
@@ -909,13 +889,13 @@ __global__ __launch_bounds__(256) void bound_merge_kernel(const float* __restric
             if (om > m || (om == m && ow < who)) { m = om; who = ow; }
         }
         pv = m;  // -inf once the sample is exhausted: fewer than 10 sampled rows
-        if (who == part && m > -INFINITY) {
+        if (who == li && m > -INFINITY) {
 #pragma unroll
-            for (int j = 0; j + 1 < KPB; ++j) v[j] = v[j + 1];
-            v[KPB - 1] = -INFINITY;
+            for (int j = 0; j + 1 < PF_LK; ++j) v[j] = v[j + 1];
+            v[PF_LK - 1] = -INFINITY;
         }
     }
-    if (col < ncols && part == 0) bound1[col] = pv;
+    if (col < ncols && li == 0) bound1[col] = pv;
 }
 
 template <bool SAMPLE, int NG>

@@ -13,16 +13,16 @@ import qr_stamps  # noqa: E402  (shares the synthetic index)
 
 
 def report(capi, idx, t):
-    print("pass 2:", float(t[capi.T_PF_EMIT]), "ms")
-    raw = idx.debug_peek("pf_bound", 8 * 12 * 8).view(np.uint64).reshape(8, 12).astype(np.float64)
-    names = ["wait", "bar", "stage", "clear", "start", "end", "flush", "thrpass", "atomics"]
+    print("pass 2:", float(t[capi.T_PF_EMIT]), "ms; pass 1:", float(t[capi.T_PF_SAMPLE]), "ms (a -DLMI_PF_STAMPS_SAMPLE=1 build stamps pass 1)")
+    raw = idx.debug_peek("pf_stamps", 8 * 12 * 8).view(np.uint64).reshape(8, 12).astype(np.float64)
+    names = ["wait", "bar", "stage", "epi", "start", "end", "flush", "thrpass", "atomics", "merge"]
     tiles = raw[:, 7:8].copy()
-    raw = np.concatenate([raw[:, :6], raw[:, 8:11], tiles], axis=1)
-    print(f"-- {raw[0, 9]:.0f} tiles per wave, {raw[:, :9].sum(axis=1).mean() / max(1.0, raw[0, 9]):.0f} cycles per tile and wave")
+    raw = np.concatenate([raw[:, :6], raw[:, 8:11], raw[:, 6:7], tiles], axis=1)
+    print(f"-- {raw[0, 10]:.0f} tiles per wave, {raw[:, :10].sum(axis=1).mean() / max(1.0, raw[0, 10]):.0f} cycles per tile and wave")
     print("   wave " + " ".join(f"{n:>7s}" for n in names) + "   cycles/tile: " + " ".join(f"{n:>7s}" for n in names))
     for wv in range(8):
-        r = raw[wv, :9]
-        print(f"   {wv:4d} " + " ".join(f"{100 * v / max(1.0, r.sum()):6.1f}%" for v in r) + "                " + " ".join(f"{v / max(1.0, raw[wv, 9]):7.0f}" for v in r))
+        r = raw[wv, :10]
+        print(f"   {wv:4d} " + " ".join(f"{100 * v / max(1.0, r.sum()):6.1f}%" for v in r) + "                " + " ".join(f"{v / max(1.0, raw[wv, 10]):7.0f}" for v in r))
 
 
 if __name__ == "__main__":

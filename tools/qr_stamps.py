@@ -52,7 +52,7 @@ def main(report=None):
     if report is not None:
         return report(capi, idx, t)
     print("pass 2:", float(t[capi.T_PF_EMIT]), "ms")
-    raw = idx.debug_peek("pf_bound", 2 * 8 * 12 * 8).view(np.uint64).reshape(2, 8, 12).astype(np.float64)
+    raw = idx.debug_peek("pf_stamps", 2 * 8 * 12 * 8).view(np.uint64).reshape(2, 8, 12).astype(np.float64)
     # epi = rest of the epilogue after its two inner stamps (atomic issue); flush = waiting for / storing the previous
     # epilogue's candidates; cmpct = threshold test + compaction
     names = ["wait", "bar", "epi", "comp", "idle", "start", "end", "flush", "cmpct"]
