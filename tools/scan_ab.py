@@ -82,6 +82,7 @@ def main():
                 times.append(float(t[capi.T_SCAN]))
                 emit.setdefault(path, []).append(float(t[capi.T_PF_EMIT]))
                 emit.setdefault(path + "#rs", []).append(float(t[capi.T_RESCORE]))
+                emit.setdefault(path + "#p1", []).append(float(t[capi.T_PF_SAMPLE]))
             elif ref is None:
                 ref = out_i.clone()
             else:
@@ -91,7 +92,8 @@ def main():
         med, mn = float(np.median(times)), float(np.min(times))
         e = emit.get(path, [0.0])
         rs_ = emit.get(path + "#rs", [0.0])
-        print(f"{os.path.basename(path):28s} pass2 median {float(np.median(e)):7.3f} min {float(np.min(e)):7.3f} ms | rescore median {float(np.median(rs_)):6.3f} | scan median {med:8.3f} ms  min {mn:8.3f} ms  "
+        p1_ = float(np.median(emit.get(path + "#p1", [0.0])))
+        print(f"{os.path.basename(path):28s} pass2 median {float(np.median(e)):7.3f} min {float(np.min(e)):7.3f} ms | rescore median {float(np.median(rs_)):6.3f} | pass1 median {p1_:6.3f} | scan median {med:8.3f} ms  min {mn:8.3f} ms  "
               f"{fl / med / 1e9:7.2f} TFLOP/s (median)  items {items}  prefilter {idx.prefilter_stats()}  "
               f"rounds {[round(t, 1) for t in times]}  last phases {[round(float(v), 2) for v in idx.timings()]}", flush=True)
 
