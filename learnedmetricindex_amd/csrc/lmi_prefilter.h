@@ -304,7 +304,10 @@ __device__ __forceinline__ int sample_stride(int n_b) {
     return s;
 }
 #ifndef LMI_PF_RING2
-#define LMI_PF_RING2 3  // ring slots of the NG 2 kernel (3 or 4; A/B on MI355X: 4 is 3 % slower, more in flight only raised the load latency)
+#define LMI_PF_RING2 3  // ring slots of the NG 2 pass-2 kernel (3 or 4; A/B on MI355X: 4 is 1-3 % slower, more in flight only raised the load latency)
+#endif
+#ifndef LMI_PF_RING2_SAMPLE
+#define LMI_PF_RING2_SAMPLE 4  // .. of pass 1, which waits 3-4 x longer for a stage to land (stamps) and has the LDS: -3.4 %
 #endif
 #ifndef LMI_PF_A_AUX
 #define LMI_PF_A_AUX 0  // cache policy of the vector-fragment DMA (2 = nt: measured 3 % slower, a chunk is read by its 2 query tiles)
@@ -405,7 +408,7 @@ struct PreItem {
     static constexpr int NLIST = SAMPLE ? NCB : 1;
     // ring slots: what is in flight (RING - 1 stages) over the load latency bounds the stage rate; NG 2's
     // one block per CU leaves LDS for a fourth slot (3 x 32 KiB in flight instead of 2 x 24 KiB x 2 blocks)
-    static constexpr int RING = NG == 1 ? 3 : LMI_PF_RING2;
+    static constexpr int RING = NG == 1 ? 3 : (SAMPLE ? LMI_PF_RING2_SAMPLE : LMI_PF_RING2);
     const PrefilterParams& P;
     uint4* sB0;
     uint4* sB1;  // three DISTINCT __shared__ B arrays [4 NG col-blocks][PF_STAGE_G][64] uint4 = 8 NG KiB each ...
@@ -906,7 +909,7 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void prefilter_kernel(Pr
     __shared__ __attribute__((aligned(16))) uint4 sA0[4 * PF_RB * PF_STAGE_G * 64];
     __shared__ __attribute__((aligned(16))) uint4 sA1[4 * PF_RB * PF_STAGE_G * 64];
     __shared__ __attribute__((aligned(16))) uint4 sA2[4 * PF_RB * PF_STAGE_G * 64];
-    constexpr bool RING4 = NG == 2 && LMI_PF_RING2 == 4;
+    constexpr bool RING4 = NG == 2 && (SAMPLE ? LMI_PF_RING2_SAMPLE : LMI_PF_RING2) == 4;
     __shared__ __attribute__((aligned(16))) uint4 sB3[RING4 ? 4 * NG * PF_STAGE_G * 64 : 1];
     __shared__ __attribute__((aligned(16))) uint4 sA3[RING4 ? 4 * PF_RB * PF_STAGE_G * 64 : 1];
     __shared__ uint2 sList[SAMPLE ? 1 : 4 * NG * PF_LIST];
