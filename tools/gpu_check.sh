@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# Developer aid (GPU box): GPU test suite + a short headline bench, outputs under gpurun_out/$1
+# Developer aid (GPU box): GPU test suite + a short headline bench, outputs under gpurun_out/$1   (bash tools/gpu_check.sh tag [tests|bench])
 set -uo pipefail
 out="gpurun_out/${1:-qr}"; mkdir -p "$out"
 if [ "${2:-tests}" = "tests" ]; then
