@@ -80,6 +80,8 @@ struct DevBuf {
 struct lmi_index {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;           // library-owned: the per-layer MLP of a batch's tail beside the fused kernel (mlp_enqueue)
+    hipEvent_t side_fork = nullptr, side_join = nullptr;
     int num_cus = 256;
     int scan_blocks_per_cu = 2;
 
@@ -219,6 +221,12 @@ extern "C" LMI_API int lmi_destroy(lmi_index* h) {
     if (!h) return 0;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    if (h->side) {
+        (void)hipStreamSynchronize(h->side);
+        (void)hipStreamDestroy(h->side);
+        (void)hipEventDestroy(h->side_fork);
+        (void)hipEventDestroy(h->side_join);
+    }
     for (auto& b : h->Wf) b.release();
     for (auto& b : h->bias) b.release();
     DevBuf* bufs[] = {&h->slab, &h->ids_slab, &h->pos, &h->d_nb_rows, &h->d_rb_start, &h->d_nch, &h->stage,
@@ -687,51 +695,16 @@ static int input_ptr(lmi_index* h, const void* src, size_t bytes, int on_device,
 }
 
 // MLP forward + class ranking (+ softmax when d_probs: then nb == L and d_order receives the full class order)
-static int mlp_enqueue(lmi_index* h, const float* d_q, int nq, int nb, int* d_order, float* d_logits_out, float* d_probs = nullptr) {
-    if (h->n_layers == 0) return fail("lmi_mlp_topk: no MLP set (lmi_set_mlp)");
+// the per-layer form: one mlp_layer_kernel launch per Linear, then the ranking (and softmax) kernels, on stream `st`
+static int mlp_layers_enqueue(lmi_index* h, hipStream_t st, const float* d_q, int nq, int nb, int* d_order, float* d_logits_out, float* d_probs) {
     const int L = h->dims[h->n_layers];
-    if (nb < 1 || nb > L) return fail("lmi_mlp_topk: n_buckets %d outside [1,%d]", nb, L);
-    CHK(build_descs(h));
-    // One launch for every layer + ranking when the batch fills the chip (a block = 32 queries, one per CU for the wide
-    // models: 8 192 queries 100 us against 138 us for the per-layer kernels); small batches (a rank's slice of a
-    // sharded batch, single queries) have too few 32-query blocks for that and take the per-layer kernels, whose grids
-    // also split the features (2 048 queries: 79 us against 88 us).  predict_proba always takes the fused kernel.
-    const bool fill = cdiv(nq, FM_COLS) * 2 >= h->num_cus || d_probs != nullptr || h->fused_mlp == 2;
-    if (h->fused_mlp && h->fm_ok && fill) {
-        // every layer, the ranking and the softmax in ONE launch (lmi_mlp_fused.h)
-        FusedParams P;
-        fused_base(h, d_q, nq, P);
-        float* d_logits = d_logits_out;
-        if (!h->fm_logits_lds && !d_logits) {  // wide output layer: logits through global memory, ranked below
-            CHK(h->logits.reserve((size_t)nq * L * 4));
-            d_logits = h->logits.as<float>();
-        }
-        P.logits_out = d_logits;
-        P.nb = nb;
-        P.order = d_order;
-        P.probs = d_probs;
-        P.classes = d_order;
-        const int grid = cdiv(nq, FM_COLS);
-        if (d_probs) mlp_fused_kernel<FM_PROBA><<<grid, 256, h->fm_lds, h->stream>>>(P);
-        else mlp_fused_kernel<FM_TOPK><<<grid, 256, h->fm_lds, h->stream>>>(P);
-        HIPCHK(hipGetLastError());
-        if (!h->fm_logits_lds) {
-            rank_classes_kernel<<<nq, 64, 0, h->stream>>>(d_logits, nq, L, nb, d_order);
-            HIPCHK(hipGetLastError());
-            if (d_probs) {
-                softmax_ranked_kernel<<<cdiv(nq, 64), 64, 0, h->stream>>>(d_logits, d_order, nq, L, d_probs);
-                HIPCHK(hipGetLastError());
-            }
-        }
-        return 0;
-    }
     const int ncb = cdiv(nq, 32);
     // pack the queries as the B operand of layer 0
     CHK(h->xfrag.reserve((size_t)ncb * h->KG[0] * 1024));
     {
         long long total = (long long)ncb * 32 * h->KG[0];
-        pack_gather_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(d_q, h->dims[0], nullptr, nq, (long long)ncb * 32,
-                                                                   h->KG[0], h->xfrag.as<float4>());
+        pack_gather_kernel<<<cdiv(total, 256), 256, 0, st>>>(d_q, h->dims[0], nullptr, nq, (long long)ncb * 32,
+                                                            h->KG[0], h->xfrag.as<float4>());
         HIPCHK(hipGetLastError());
     }
     int maxrb = 0;
@@ -754,8 +727,8 @@ static int mlp_enqueue(lmi_index* h, const float* d_q, int nq, int nb, int* d_or
         float* o = last ? d_logits : h->act[i & 1].as<float>();
         const int KGn = last ? 0 : h->n_rb[i] * 4;
 #define LMI_MLP_LAUNCH(LASTV, CBWV)                                                                        \
-        mlp_layer_kernel<LASTV, CBWV><<<grid, 256, 0, h->stream>>>(h->Wf[i].as<float4>(), h->bias[i].as<float>(), in, \
-                                                                  h->KG[i], h->n_rb[i], ncb, o, KGn, nq, L)
+        mlp_layer_kernel<LASTV, CBWV><<<grid, 256, 0, st>>>(h->Wf[i].as<float4>(), h->bias[i].as<float>(), in, \
+                                                           h->KG[i], h->n_rb[i], ncb, o, KGn, nq, L)
         if (last) {
             if (cbw == 4) LMI_MLP_LAUNCH(true, 4); else if (cbw == 2) LMI_MLP_LAUNCH(true, 2); else LMI_MLP_LAUNCH(true, 1);
         } else {
@@ -765,13 +738,78 @@ static int mlp_enqueue(lmi_index* h, const float* d_q, int nq, int nb, int* d_or
 #undef LMI_MLP_LAUNCH
         HIPCHK(hipGetLastError());
     }
-    rank_classes_kernel<<<nq, 64, 0, h->stream>>>(d_logits, nq, L, nb, d_order);
+    rank_classes_kernel<<<nq, 64, 0, st>>>(d_logits, nq, L, nb, d_order);
     HIPCHK(hipGetLastError());
     if (d_probs) {
-        softmax_ranked_kernel<<<cdiv(nq, 64), 64, 0, h->stream>>>(d_logits, d_order, nq, L, d_probs);
+        softmax_ranked_kernel<<<cdiv(nq, 64), 64, 0, st>>>(d_logits, d_order, nq, L, d_probs);
         HIPCHK(hipGetLastError());
     }
     return 0;
+}
+
+static int mlp_enqueue(lmi_index* h, const float* d_q, int nq, int nb, int* d_order, float* d_logits_out, float* d_probs = nullptr) {
+    if (h->n_layers == 0) return fail("lmi_mlp_topk: no MLP set (lmi_set_mlp)");
+    const int L = h->dims[h->n_layers];
+    if (nb < 1 || nb > L) return fail("lmi_mlp_topk: n_buckets %d outside [1,%d]", nb, L);
+    CHK(build_descs(h));
+    // One launch for every layer + ranking when the batch fills the chip (a block = 32 queries, one per CU for the wide
+    // models: 8 192 queries 100 us against 138 us for the per-layer kernels); small batches (a rank's slice of a
+    // sharded batch, single queries) have too few 32-query blocks for that and take the per-layer kernels, whose grids
+    // also split the features (2 048 queries: 79 us against 88 us).  predict_proba always takes the fused kernel.
+    const bool fill = cdiv(nq, FM_COLS) * 2 >= h->num_cus || d_probs != nullptr || h->fused_mlp == 2;
+    if (h->fused_mlp && h->fm_ok && fill) {
+        // every layer, the ranking and the softmax in ONE launch (lmi_mlp_fused.h)
+        // A batch whose last round of 32-query blocks would fill under 30 % of the CUs (10 000 queries: 313 blocks = 256 + 57)
+        // pays a whole second round for it.  The tail's queries go through the per-layer kernels on a side stream instead,
+        // beside the fused kernel's one full round (the fused blocks leave wave slots and half of the MFMA pipe): 182 ->
+        // ~125 us at 10 000 queries; identical results (both forms are the canonical chain).
+        int grid = cdiv(nq, FM_COLS);
+        int nq_head = nq;
+        const int rem = grid % h->num_cus;
+        if (h->fused_mlp == 1 && !d_probs && !d_logits_out && h->fm_logits_lds && grid > h->num_cus && rem > 0 && rem * 10 < h->num_cus * 3) {
+            nq_head = (grid - rem) * FM_COLS;
+            grid -= rem;
+        }
+        FusedParams P;
+        fused_base(h, d_q, nq_head, P);
+        float* d_logits = d_logits_out;
+        if (!h->fm_logits_lds && !d_logits) {  // wide output layer: logits through global memory, ranked below
+            CHK(h->logits.reserve((size_t)nq * L * 4));
+            d_logits = h->logits.as<float>();
+        }
+        P.logits_out = d_logits;
+        P.nb = nb;
+        P.order = d_order;
+        P.probs = d_probs;
+        P.classes = d_order;
+        if (nq_head < nq) {
+            if (!h->side) {
+                HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+                HIPCHK(hipEventCreateWithFlags(&h->side_fork, hipEventDisableTiming));
+                HIPCHK(hipEventCreateWithFlags(&h->side_join, hipEventDisableTiming));
+            }
+            HIPCHK(hipEventRecord(h->side_fork, h->stream));
+            HIPCHK(hipStreamWaitEvent(h->side, h->side_fork, 0));
+        }
+        if (d_probs) mlp_fused_kernel<FM_PROBA><<<grid, 256, h->fm_lds, h->stream>>>(P);
+        else mlp_fused_kernel<FM_TOPK><<<grid, 256, h->fm_lds, h->stream>>>(P);
+        HIPCHK(hipGetLastError());
+        if (nq_head < nq) {
+            CHK(mlp_layers_enqueue(h, h->side, d_q + (size_t)nq_head * h->dims[0], nq - nq_head, nb, d_order + (size_t)nq_head * nb, nullptr, nullptr));
+            HIPCHK(hipEventRecord(h->side_join, h->side));
+            HIPCHK(hipStreamWaitEvent(h->stream, h->side_join, 0));
+        }
+        if (!h->fm_logits_lds) {
+            rank_classes_kernel<<<nq, 64, 0, h->stream>>>(d_logits, nq, L, nb, d_order);
+            HIPCHK(hipGetLastError());
+            if (d_probs) {
+                softmax_ranked_kernel<<<cdiv(nq, 64), 64, 0, h->stream>>>(d_logits, d_order, nq, L, d_probs);
+                HIPCHK(hipGetLastError());
+            }
+        }
+        return 0;
+    }
+    return mlp_layers_enqueue(h, h->stream, d_q, nq, nb, d_order, d_logits_out, d_probs);
 }
 
 extern "C" LMI_API int lmi_mlp_topk(lmi_index* h, const float* queries_nav, int nq, int nb, int32_t* bucket_order,

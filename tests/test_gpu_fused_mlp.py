@@ -70,3 +70,28 @@ def test_fused_shapes(oracle, d, hidden, L):
     np.testing.assert_array_equal(pf, po)
     fused.close()
     plain.close()
+
+
+def test_batch_with_a_thin_last_round_is_split(oracle):
+    """Default mode, a batch whose last round of 32-query blocks would fill under 30 % of the CUs (here 8 192 + 600
+    queries = 256 + 19 blocks): the head takes the fused kernel, the tail the per-layer kernels on a side stream.
+    Same bucket order as either pure form and as the oracle."""
+    from learnedmetricindex_amd import _capi
+
+    rs = np.random.RandomState(31)
+    d, hidden, L, nb = 96, 128, 40, 4
+    layers = [((rs.randn(hidden, d) / np.sqrt(d)).astype(np.float32), rs.randn(hidden).astype(np.float32) * 0.1),
+              ((rs.randn(L, hidden) / np.sqrt(hidden)).astype(np.float32), rs.randn(L).astype(np.float32) * 0.1)]
+    q = rs.randn(8192 + 600, d).astype(np.float32)
+    out = {}
+    for mode in (1, 2, 0):
+        idx = _capi.Index(0)
+        idx.set_fused_mlp(mode)
+        idx.set_mlp(layers)
+        out[mode] = idx.mlp_topk(q, nb)
+        if mode == 1:   # twice: the side stream and its events are created on first use
+            np.testing.assert_array_equal(idx.mlp_topk(q, nb), out[mode])
+        idx.close()
+    np.testing.assert_array_equal(out[1], out[2])
+    np.testing.assert_array_equal(out[1], out[0])
+    np.testing.assert_array_equal(out[1], oracle.rank_classes(oracle.forward_logits(layers, q, nthreads=8), nb))
