@@ -15,7 +15,7 @@ rs = np.random.RandomState(0)
 layers = [((rs.randn(H, d) / np.sqrt(d)).astype(np.float32), np.zeros(H, np.float32)),
           ((rs.randn(L, H) / np.sqrt(H)).astype(np.float32), np.zeros(L, np.float32))]
 dev = torch.device("cuda", 0)
-for fused in (2, 0):
+for fused in (1, 2, 0):
     idx = _capi.Index(0)
     idx.set_fused_mlp(fused)
     idx.set_mlp(layers)
