@@ -695,6 +695,24 @@ static int input_ptr(lmi_index* h, const void* src, size_t bytes, int on_device,
 }
 
 // MLP forward + class ranking (+ softmax when d_probs: then nb == L and d_order receives the full class order)
+// Side stream (library-owned): work that does not depend on what the handle's stream runs next is forked onto it and
+// joined before its results are needed.  side_fork: the side stream waits for everything enqueued on h->stream so far.
+static int side_fork(lmi_index* h) {
+    if (!h->side) {
+        HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&h->side_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->side_join, hipEventDisableTiming));
+    }
+    HIPCHK(hipEventRecord(h->side_fork, h->stream));
+    HIPCHK(hipStreamWaitEvent(h->side, h->side_fork, 0));
+    return 0;
+}
+static int side_join(lmi_index* h) {
+    HIPCHK(hipEventRecord(h->side_join, h->side));
+    HIPCHK(hipStreamWaitEvent(h->stream, h->side_join, 0));
+    return 0;
+}
+
 // the per-layer form: one mlp_layer_kernel launch per Linear, then the ranking (and softmax) kernels, on stream `st`
 static int mlp_layers_enqueue(lmi_index* h, hipStream_t st, const float* d_q, int nq, int nb, int* d_order, float* d_logits_out, float* d_probs) {
     const int L = h->dims[h->n_layers];
@@ -782,22 +800,13 @@ static int mlp_enqueue(lmi_index* h, const float* d_q, int nq, int nb, int* d_or
         P.order = d_order;
         P.probs = d_probs;
         P.classes = d_order;
-        if (nq_head < nq) {
-            if (!h->side) {
-                HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-                HIPCHK(hipEventCreateWithFlags(&h->side_fork, hipEventDisableTiming));
-                HIPCHK(hipEventCreateWithFlags(&h->side_join, hipEventDisableTiming));
-            }
-            HIPCHK(hipEventRecord(h->side_fork, h->stream));
-            HIPCHK(hipStreamWaitEvent(h->side, h->side_fork, 0));
-        }
+        if (nq_head < nq) CHK(side_fork(h));
         if (d_probs) mlp_fused_kernel<FM_PROBA><<<grid, 256, h->fm_lds, h->stream>>>(P);
         else mlp_fused_kernel<FM_TOPK><<<grid, 256, h->fm_lds, h->stream>>>(P);
         HIPCHK(hipGetLastError());
         if (nq_head < nq) {
             CHK(mlp_layers_enqueue(h, h->side, d_q + (size_t)nq_head * h->dims[0], nq - nq_head, nb, d_order + (size_t)nq_head * nb, nullptr, nullptr));
-            HIPCHK(hipEventRecord(h->side_join, h->side));
-            HIPCHK(hipStreamWaitEvent(h->stream, h->side_join, 0));
+            CHK(side_join(h));
         }
         if (!h->fm_logits_lds) {
             rank_classes_kernel<<<nq, 64, 0, h->stream>>>(d_logits, nq, L, nb, d_order);
@@ -965,7 +974,10 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     HIPCHK(hipGetLastError());
     route_scan_kernel<<<1, 256, 0, h->stream>>>(L, R);
     HIPCHK(hipGetLastError());
-    route_group_kernel<<<1, 1024, (size_t)L * 20, h->stream>>>(L, R);
+    // the work queues (one 1 024-thread block, ~20 us) are only read by the scan kernels: built on the side stream while
+    // this one packs the queries
+    CHK(side_fork(h));
+    route_group_kernel<<<1, 1024, (size_t)L * 20, h->side>>>(L, R);
     HIPCHK(hipGetLastError());
     route_fill_kernel<<<cdiv(nslots, 256), 256, 0, h->stream>>>(d_order, h->slot_local.as<int>(), nslots, nb,
                                                                R.cb_start, h->colmap.as<int>(), h->slot_col.as<int>());
@@ -995,6 +1007,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         pack_gather_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(d_qs, h->d, h->colmap.as<int>(), nq, ncb_bound * 32,
                                                                    h->KGs, h->qfrag.as<float4>());
         HIPCHK(hipGetLastError());
+        CHK(side_join(h));   // the work queues
         CHK(record(h, 2));
         scan_kernel<<<h->num_cus * h->scan_blocks_per_cu, 256, SCAN_LDS, h->stream>>>(S);
         HIPCHK(hipGetLastError());
@@ -1014,6 +1027,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
                                                                    h->qnorm.as<float>(), h->qdelta.as<float>(),
                                                                    h->bnorm.as<unsigned>(), h->bdelta.as<unsigned>(), h->eps2.as<float>());
         HIPCHK(hipGetLastError());
+        CHK(side_join(h));   // the work queues
         CHK(record(h, 2));
         PrefilterParams F;
         F.slab16 = h->slab16.as<uint4>();
