@@ -5,8 +5,13 @@ One batch needs 31 MB of queries over PCIe (10 000 x 768 f32: ~0.55 ms at Gen5 x
 back; the search itself is ~6 ms.  `HostPipeline` keeps `depth` batches in flight on two HIP streams so the
 upload of batch i+1 runs under the scan of batch i:
 
-    copy-in stream :  H2D(q[i+1]) ............
-    compute stream :  wait(H2D i) -> lmi_search(batch i, device pointers) -> D2H(dists, ids [, bucket order]) -> event
+    copy-in stream    :  H2D(q[i+1]) ............
+    navigation stream :  wait(H2D i+1) -> lmi_mlp_topk(batch i+1) -> event               (`overlap_inference`)
+    compute stream    :  wait(nav i) -> lmi_scan_topk(batch i, device pointers) -> D2H(dists, ids [, bucket order]) -> event
+
+The MLP of the next batch depends on nothing the scan of the current one produces.  On a stream of its own its blocks
+start as soon as CUs come free: in the tail of the scan's persistent kernels and of the re-rank, instead of after them
+(0.18 ms of a 5.7 ms step otherwise spent with the chip to itself).
 
 The 1 MB result download is a KERNEL on the compute stream that stores into the pinned result buffers
 (`lmi_copy_out`, ~30 us): every `hipMemcpyAsync` D2H form tried (own stream behind an event wait; in the compute
@@ -27,7 +32,7 @@ import numpy as np
 class HostPipeline:
     def __init__(self, index, nq: int, d_nav: int, d_search: int, nb: int, k: int = 10, depth: int = 2,
                  device: Optional[int] = None, same_queries: bool = False, want_bucket_order: bool = False,
-                 search_fn=None):
+                 search_fn=None, overlap_inference: bool = True):
         """`search_fn(qn_dev, qs_dev) -> (dists_t, ids_t, bucket_order_t)`: optional replacement of the single-GPU
         `lmi_search` call, run on the compute stream (the bucket-sharded searcher of sharded.py, whose collectives
         then run on that stream too); its output tensors may be reused by its next call."""
@@ -38,9 +43,13 @@ class HostPipeline:
         self.same = bool(same_queries) and d_nav == d_search   # navigation and scan vectors are one array
         self.want_bo = bool(want_bucket_order)
         self.search_fn = search_fn
+        # two C-ABI calls per batch (lmi_mlp_topk on the navigation stream, lmi_scan_topk on the compute stream) instead
+        # of one lmi_search: `calls_per_batch` tells a reader of lmi_timings_mean how many calls make up one batch
+        self.overlap = bool(overlap_inference) and search_fn is None
+        self.calls_per_batch = 2 if self.overlap else 1
         dev = torch.device("cuda", index.device if device is None else device)
         self.dev = dev
-        self.s_in, self.s_run = (torch.cuda.Stream(dev) for _ in range(2))
+        self.s_in, self.s_run, self.s_nav = (torch.cuda.Stream(dev) for _ in range(3))
         index.set_stream(self.s_run.cuda_stream)
         f32, i32 = torch.float32, torch.int32
         mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)   # noqa: E731
@@ -50,7 +59,7 @@ class HostPipeline:
             s = dict(qn_h=pin((nq, d_nav), f32), qn_d=mk((nq, d_nav), f32),
                      d_d=mk((nq, self.kout), f32), i_d=mk((nq, self.kout), i32), bo_d=mk((nq, nb), i32),
                      d_h=pin((nq, self.kout), f32), i_h=pin((nq, self.kout), i32), bo_h=pin((nq, nb), i32),
-                     ev_in=torch.cuda.Event(), ev_out=torch.cuda.Event(), busy=False)
+                     ev_in=torch.cuda.Event(), ev_nav=torch.cuda.Event(), ev_out=torch.cuda.Event(), busy=False)
             if not self.same:
                 s["qs_h"], s["qs_d"] = pin((nq, d_search), f32), mk((nq, d_search), f32)
             self.slots.append(s)
@@ -79,9 +88,19 @@ class HostPipeline:
                 qs_src = stage(queries_nav if queries_search is None else queries_search, s["qs_h"])
                 s["qs_d"].copy_(qs_src, non_blocking=True)
             s["ev_in"].record(self.s_in)
+        if self.overlap:
+            with torch.cuda.stream(self.s_nav):
+                self.s_nav.wait_event(s["ev_in"])
+                self.index.set_stream(self.s_nav.cuda_stream)
+                self.index.mlp_topk_device(s["qn_d"], self.nb, s["bo_d"])
+                s["ev_nav"].record(self.s_nav)
+            self.index.set_stream(self.s_run.cuda_stream)
         with torch.cuda.stream(self.s_run):
-            self.s_run.wait_event(s["ev_in"])
-            if self.search_fn is None:
+            self.s_run.wait_event(s["ev_nav"] if self.overlap else s["ev_in"])
+            if self.overlap:
+                self.index.scan_topk_device(s["qn_d"] if self.same else s["qs_d"], s["bo_d"], self.nb, self.k, s["d_d"], s["i_d"])
+                d_t, i_t, bo_t = s["d_d"], s["i_d"], s["bo_d"]
+            elif self.search_fn is None:
                 self.index.search_device(s["qn_d"], s["qn_d"] if self.same else s["qs_d"], self.nb, self.k,
                                          s["d_d"], s["i_d"], None, s["bo_d"])
                 d_t, i_t, bo_t = s["d_d"], s["i_d"], s["bo_d"]
