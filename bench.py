@@ -176,7 +176,8 @@ class Workload:
 
         q_host = self.queries.cpu().pin_memory()  # the batch as it arrives: host memory (pinned, DMA-able)
         pipe = HostPipeline(eng, nq, d, d, nb, k, depth=int(os.environ.get("LMI_PIPE_DEPTH", "2")), same_queries=True, want_bucket_order=True,
-                            overlap_inference=os.environ.get("LMI_PIPE_OVERLAP", "1") != "0",
+                            overlap_inference=os.environ.get("LMI_PIPE_OVERLAP", "1") == "1",
+                            two_handles=os.environ.get("LMI_PIPE_OVERLAP", "1") == "2",
                             search_fn=(lambda qn, qs: searcher.search(qn, qs, nb, k)) if world > 1 else None)
         for _ in range(warmup):
             pipe.submit(q_host)

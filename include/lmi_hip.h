@@ -215,6 +215,12 @@ LMI_API int lmi_scan_stats(lmi_index *h, double *flops, int64_t *pairs, int64_t 
  * on = 2: the prefilter with the query-resident form of its pass 2 (lmi_pass2_qr.h; d <= 768, else as 1) instead of the
  * streamed one; 1 <-> 2 may be switched at any time, results are identical (the streamed form is the faster one). */
 LMI_API int lmi_set_prefilter(lmi_index *h, int on);
+/* A second handle on the SAME index (no reference counterpart: the reference is single-threaded Python).  The clone
+ * borrows the parent's MLP weights, tree and bucket slabs and has per-call workspaces, a stream and timing events of its
+ * own, so that two searches can be in flight on one index, one per handle and stream (learnedmetricindex_amd/pipeline.py
+ * alternates handles: a batch's kernels start in the tails of the previous batch's).  Destroy the clone before the parent;
+ * do not rebuild the parent's index while a clone lives. */
+LMI_API int lmi_clone_view(lmi_index *h, lmi_index **out);
 /* Developer aid: copies the first `bytes` of a named internal device buffer to host memory ("pf_bound"). */
 LMI_API int lmi_debug_peek(lmi_index *h, const char *name, void *dst, int64_t bytes);
 LMI_API int lmi_prefilter_stats(lmi_index *h, int *active, int64_t *survivors, int64_t *fallbacks);

@@ -70,6 +70,7 @@ SIGNATURES = {
     "lmi_set_chunk_rows": (ctypes.c_int, [_vp, ctypes.c_int]),
     "lmi_set_prefilter": (ctypes.c_int, [_vp, ctypes.c_int]),
     "lmi_debug_peek": (ctypes.c_int, [_vp, ctypes.c_char_p, _vp, ctypes.c_int64]),
+    "lmi_clone_view": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
     "lmi_prefilter_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), _i64p, _i64p]),
     "lmi_debug_emit_all": (ctypes.c_int, [_vp, ctypes.c_int]),
     "lmi_debug_read_candidates": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, _vp, _vp,
@@ -145,9 +146,25 @@ class Index:
         self.metric = metric
 
     def close(self) -> None:
+        for c in getattr(self, "_views", []):   # clones borrow this handle's memory: they go first
+            c.close()
+        self._views = []
         if getattr(self, "_h", None) is not None and self._h:
             lib().lmi_destroy(self._h)
             self._h = None
+
+    def clone_view(self) -> "Index":
+        """A second handle on the same index (`lmi_clone_view`): shares the weights and the bucket slabs, has its own
+        workspaces, stream and timings.  Closed with (before) this one."""
+        v = Index.__new__(Index)
+        v._h = _vp()
+        _check(lib().lmi_clone_view(self._h, ctypes.byref(v._h)))
+        for a in ("device", "n_classes", "d_nav", "d", "L", "N", "metric"):
+            setattr(v, a, getattr(self, a, None))
+        v._views = []
+        v._parent = self
+        self.__dict__.setdefault("_views", []).append(v)
+        return v
 
     def __del__(self):
         try:

@@ -56,8 +56,10 @@ inline long long rup(long long a, long long b) { return (a + b - 1) / b * b; }
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    bool borrowed = false;  // lmi_clone_view: the memory belongs to the handle this one was cloned from
     int reserve(size_t bytes) {
         if (bytes <= cap) return 0;
+        if (borrowed) return fail("internal: a buffer shared with the parent handle would have to grow");
         if (p) HIPCHK(hipFree(p));
         p = nullptr;
         cap = 0;
@@ -67,10 +69,13 @@ struct DevBuf {
         return 0;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && !borrowed) (void)hipFree(p);
         p = nullptr;
         cap = 0;
+        borrowed = false;
     }
+    void borrow() { borrowed = p != nullptr; }   // keep the pointer, never free it
+    void forget() { p = nullptr; cap = 0; borrowed = false; }  // a copied struct's workspace: start empty
     template <class T>
     T* as() const { return reinterpret_cast<T*>(p); }
 };
@@ -243,6 +248,45 @@ extern "C" LMI_API int lmi_destroy(lmi_index* h) {
         for (int i = 0; i < 10; ++i)
             if (h->ev_ring[r][i]) (void)hipEventDestroy(h->ev_ring[r][i]);
     delete h;
+    return 0;
+}
+
+static int build_descs(lmi_index* h);
+
+// A second handle on the SAME index: its MLP weights, tree and bucket slabs are the parent's memory (borrowed), its
+// per-call workspaces, stream, side stream and timing events are its own.  Two searches can then be in flight on one
+// index (one per handle, each on its own stream): the pipeline alternates handles so that a batch's kernels start in
+// the tails of the previous batch's.  The clone must be destroyed before the parent and the parent's index must not be
+// rebuilt while it lives.
+extern "C" LMI_API int lmi_clone_view(lmi_index* h, lmi_index** out) {
+    if (!h || !out) return fail("lmi_clone_view: NULL argument");
+    if (h->building) return fail("lmi_clone_view: the parent's index is being built");
+    CHK(set_dev(h));
+    CHK(build_descs(h));                       // the device copy of the model descriptors is shared as it stands
+    HIPCHK(hipStreamSynchronize(h->stream));
+    lmi_index* c = new lmi_index(*h);          // vectors are copied, DevBufs are pointer copies: sorted out below
+    c->stream = nullptr; c->side = nullptr; c->side_fork = nullptr; c->side_join = nullptr;
+    for (auto& b : c->Wf) b.borrow();
+    for (auto& b : c->bias) b.borrow();
+    for (auto& m : c->node_models) { for (auto& b : m.Wf) b.borrow(); for (auto& b : m.bias) b.borrow(); }
+    DevBuf* shared[] = {&c->d_models, &c->d_child_offset, &c->d_child_model, &c->d_child_bucket, &c->slab, &c->ids_slab, &c->pos,
+                        &c->d_nb_rows, &c->d_rb_start, &c->d_nch, &c->slab16, &c->rowmajor, &c->xscale, &c->xmaxbits, &c->bnorm, &c->bdelta};
+    for (DevBuf* b : shared) b->borrow();
+    DevBuf* own[] = {&c->gather_send, &c->gather_recv, &c->pq_prob, &c->pq_ent, &c->pq_len, &c->nav_len, &c->nav_slab, &c->nav_ent,
+                     &c->nav_count, &c->nav_colq, &c->nav_active, &c->aug_rows, &c->q_aug, &c->qn2, &c->stage, &c->qdelta, &c->qnorm,
+                     &c->qscale, &c->qfrag16, &c->eps2, &c->cand_cnt, &c->cand_row, &c->cand_s, &c->fallback, &c->pf_bound, &c->nkeep,
+                     &c->surv_row, &c->rs_flag, &c->rs_active, &c->act[0], &c->act[1], &c->xfrag, &c->logits, &c->order, &c->q_nav,
+                     &c->q_srch, &c->m, &c->cb_start, &c->item_base, &c->part_base, &c->stats, &c->head, &c->slot_local, &c->slot_col,
+                     &c->colmap, &c->qfrag, &c->grp, &c->col_thr, &c->part_score, &c->part_row, &c->rank_d, &c->rank_id, &c->out_d,
+                     &c->out_id, &c->out_key};
+    for (DevBuf* b : own) b->forget();
+    memset(c->ev_ring, 0, sizeof(c->ev_ring));
+    memset(c->valid_ring, 0, sizeof(c->valid_ring));
+    c->ev_cur = 0; c->ev_calls = 0;
+    c->ev = c->ev_ring[0]; c->ev_valid = c->valid_ring[0];
+    c->stats_pending = false;
+    c->last_nslots = 0; c->last_fast = false;
+    *out = c;
     return 0;
 }
 

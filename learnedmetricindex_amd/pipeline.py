@@ -32,7 +32,7 @@ import numpy as np
 class HostPipeline:
     def __init__(self, index, nq: int, d_nav: int, d_search: int, nb: int, k: int = 10, depth: int = 2,
                  device: Optional[int] = None, same_queries: bool = False, want_bucket_order: bool = False,
-                 search_fn=None, overlap_inference: bool = True):
+                 search_fn=None, overlap_inference: bool = True, two_handles: bool = False):
         """`search_fn(qn_dev, qs_dev) -> (dists_t, ids_t, bucket_order_t)`: optional replacement of the single-GPU
         `lmi_search` call, run on the compute stream (the bucket-sharded searcher of sharded.py, whose collectives
         then run on that stream too); its output tensors may be reused by its next call."""
@@ -45,12 +45,21 @@ class HostPipeline:
         self.search_fn = search_fn
         # two C-ABI calls per batch (lmi_mlp_topk on the navigation stream, lmi_scan_topk on the compute stream) instead
         # of one lmi_search: `calls_per_batch` tells a reader of lmi_timings_mean how many calls make up one batch
-        self.overlap = bool(overlap_inference) and search_fn is None
+        # two_handles: batches alternate between the index handle and a clone of it (`lmi_clone_view`: same index memory, own
+        # workspaces), each with its compute stream -- every phase of batch i+1 may start in the tails of batch i's kernels
+        self.two = bool(two_handles) and search_fn is None
+        self.overlap = bool(overlap_inference) and search_fn is None and not self.two
         self.calls_per_batch = 2 if self.overlap else 1
         dev = torch.device("cuda", index.device if device is None else device)
         self.dev = dev
         self.s_in, self.s_run, self.s_nav = (torch.cuda.Stream(dev) for _ in range(3))
         index.set_stream(self.s_run.cuda_stream)
+        self.handles = [(index, self.s_run)]
+        if self.two:
+            twin = index.clone_view()
+            s2 = torch.cuda.Stream(dev)
+            twin.set_stream(s2.cuda_stream)
+            self.handles.append((twin, s2))
         f32, i32 = torch.float32, torch.int32
         mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)   # noqa: E731
         pin = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)   # noqa: E731
@@ -95,9 +104,14 @@ class HostPipeline:
                 self.index.mlp_topk_device(s["qn_d"], self.nb, s["bo_d"])
                 s["ev_nav"].record(self.s_nav)
             self.index.set_stream(self.s_run.cuda_stream)
-        with torch.cuda.stream(self.s_run):
-            self.s_run.wait_event(s["ev_nav"] if self.overlap else s["ev_in"])
-            if self.overlap:
+        index, s_run = self.handles[self.t % len(self.handles)]
+        with torch.cuda.stream(s_run):
+            s_run.wait_event(s["ev_nav"] if self.overlap else s["ev_in"])
+            if self.two:
+                index.search_device(s["qn_d"], s["qn_d"] if self.same else s["qs_d"], self.nb, self.k,
+                                    s["d_d"], s["i_d"], None, s["bo_d"])
+                d_t, i_t, bo_t = s["d_d"], s["i_d"], s["bo_d"]
+            elif self.overlap:
                 self.index.scan_topk_device(s["qn_d"] if self.same else s["qs_d"], s["bo_d"], self.nb, self.k, s["d_d"], s["i_d"])
                 d_t, i_t, bo_t = s["d_d"], s["i_d"], s["bo_d"]
             elif self.search_fn is None:
@@ -106,11 +120,11 @@ class HostPipeline:
                 d_t, i_t, bo_t = s["d_d"], s["i_d"], s["bo_d"]
             else:
                 d_t, i_t, bo_t = self.search_fn(s["qn_d"], s["qn_d"] if self.same else s["qs_d"])
-            self.index.copy_out(s["d_h"], d_t)          # a kernel storing to the pinned buffers (see the module docstring)
-            self.index.copy_out(s["i_h"], i_t)
+            index.copy_out(s["d_h"], d_t)          # a kernel storing to the pinned buffers (see the module docstring)
+            index.copy_out(s["i_h"], i_t)
             if self.want_bo:
-                self.index.copy_out(s["bo_h"], bo_t)
-            s["ev_out"].record(self.s_run)
+                index.copy_out(s["bo_h"], bo_t)
+            s["ev_out"].record(s_run)
         self.t += 1
         return self.t - 1
 

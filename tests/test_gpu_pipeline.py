@@ -10,8 +10,10 @@ from helpers import inputs_for, layers_from, load_golden
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name,depth", [("G3", 2), ("G6", 3), ("G4", 1)])
-def test_pipeline_equals_synchronous_search(oracle, name, depth):
+@pytest.mark.parametrize("name,depth,mode", [("G3", 2, "nav"), ("G6", 3, "nav"), ("G4", 1, "nav"), ("G3", 2, "plain"), ("G6", 2, "twin")])
+def test_pipeline_equals_synchronous_search(oracle, name, depth, mode):
+    """mode: "nav" (default) -- the next batch's MLP on a navigation stream beside the current scan; "plain" -- one lmi_search
+    per batch; "twin" -- batches alternate between the handle and a clone of it (lmi_clone_view: same index memory)."""
     from learnedmetricindex_amd import _capi
     from learnedmetricindex_amd.pipeline import HostPipeline
 
@@ -25,7 +27,9 @@ def test_pipeline_equals_synchronous_search(oracle, name, depth):
     idx.set_buckets(Xs, g["data_prediction"][:, 0], L)
     nq = 96
     same = Xn.shape[1] == Xs.shape[1] and np.array_equal(Qn, Qs)
-    pipe = HostPipeline(idx, nq, Qn.shape[1], Qs.shape[1], nb, k, depth=depth, same_queries=same, want_bucket_order=True)
+    pipe = HostPipeline(idx, nq, Qn.shape[1], Qs.shape[1], nb, k, depth=depth, same_queries=same, want_bucket_order=True,
+                        overlap_inference=mode == "nav", two_handles=mode == "twin")
+    assert pipe.calls_per_batch == (2 if mode == "nav" else 1) and len(pipe.handles) == (2 if mode == "twin" else 1)
     rs = np.random.RandomState(0)
     batches = [np.sort(rs.choice(Qn.shape[0], nq, replace=False)) for _ in range(7)]
     tickets, expect = [], []
