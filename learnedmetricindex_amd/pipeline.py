@@ -32,7 +32,7 @@ import numpy as np
 class HostPipeline:
     def __init__(self, index, nq: int, d_nav: int, d_search: int, nb: int, k: int = 10, depth: int = 2,
                  device: Optional[int] = None, same_queries: bool = False, want_bucket_order: bool = False,
-                 search_fn=None, overlap_inference: bool = True, two_handles: bool = False):
+                 search_fn=None, overlap_inference: bool = True, two_handles: bool = False, sharded=None):
         """`search_fn(qn_dev, qs_dev) -> (dists_t, ids_t, bucket_order_t)`: optional replacement of the single-GPU
         `lmi_search` call, run on the compute stream (the bucket-sharded searcher of sharded.py, whose collectives
         then run on that stream too); its output tensors may be reused by its next call."""
@@ -47,8 +47,16 @@ class HostPipeline:
         # of one lmi_search: `calls_per_batch` tells a reader of lmi_timings_mean how many calls make up one batch
         # two_handles: batches alternate between the index handle and a clone of it (`lmi_clone_view`: same index memory, own
         # workspaces), each with its compute stream -- every phase of batch i+1 may start in the tails of batch i's kernels
-        self.two = bool(two_handles) and search_fn is None
-        self.overlap = bool(overlap_inference) and search_fn is None and not self.two
+        # sharded: a sharded.ShardedSearcher (instead of search_fn).  With its inference sharded, the rank's MLP slice of
+        # batch i+1 (no collective) runs on the navigation stream; the collectives and the scan stay on the compute stream
+        self.sharded = sharded
+        assert sharded is None or search_fn is None
+        self.sh_overlap = sharded is not None and bool(overlap_inference) and sharded.shard_inference
+        if sharded is not None and not self.sh_overlap:
+            search_fn = lambda qn, qs: sharded.search(qn, qs, self.nb, self.k)   # noqa: E731
+            self.search_fn = search_fn
+        self.two = bool(two_handles) and search_fn is None and sharded is None
+        self.overlap = bool(overlap_inference) and search_fn is None and not self.two and sharded is None
         self.calls_per_batch = 2 if self.overlap else 1
         dev = torch.device("cuda", index.device if device is None else device)
         self.dev = dev
@@ -71,6 +79,8 @@ class HostPipeline:
                      ev_in=torch.cuda.Event(), ev_nav=torch.cuda.Event(), ev_out=torch.cuda.Event(), busy=False)
             if not self.same:
                 s["qs_h"], s["qs_d"] = pin((nq, d_search), f32), mk((nq, d_search), f32)
+            if self.sh_overlap:
+                s["bo_loc"] = sharded.new_route_buffer(nq, nb, dev)
             self.slots.append(s)
         self.t = 0
 
@@ -104,10 +114,19 @@ class HostPipeline:
                 self.index.mlp_topk_device(s["qn_d"], self.nb, s["bo_d"])
                 s["ev_nav"].record(self.s_nav)
             self.index.set_stream(self.s_run.cuda_stream)
+        if self.sh_overlap:
+            with torch.cuda.stream(self.s_nav):
+                self.s_nav.wait_event(s["ev_in"])
+                self.index.set_stream(self.s_nav.cuda_stream)
+                self.sharded.route_local(s["qn_d"], self.nb, s["bo_loc"])
+                s["ev_nav"].record(self.s_nav)
+            self.index.set_stream(self.s_run.cuda_stream)
         index, s_run = self.handles[self.t % len(self.handles)]
         with torch.cuda.stream(s_run):
-            s_run.wait_event(s["ev_nav"] if self.overlap else s["ev_in"])
-            if self.two:
+            s_run.wait_event(s["ev_nav"] if (self.overlap or self.sh_overlap) else s["ev_in"])
+            if self.sh_overlap:
+                d_t, i_t, bo_t = self.sharded.search_routed(s["qn_d"] if self.same else s["qs_d"], s["bo_loc"], self.nb, self.k)
+            elif self.two:
                 index.search_device(s["qn_d"], s["qn_d"] if self.same else s["qs_d"], self.nb, self.k,
                                     s["d_d"], s["i_d"], None, s["bo_d"])
                 d_t, i_t, bo_t = s["d_d"], s["i_d"], s["bo_d"]

@@ -133,29 +133,43 @@ class ShardedSearcher:
         self._buf = None
         self._bo_loc = None
 
-    def search(self, qn_t, qs_t, nb: int, k: int):
+    def _buffers(self, nq: int, nb: int, kout: int, dev):
         import torch
 
-        nq = qn_t.shape[0]
-        kout = self.index.kout(nb, k)
         if self._buf is None or self._buf[0].shape != (3, nq, kout):
-            dev = qn_t.device
             self._buf = (torch.empty((3, nq, kout), dtype=torch.int32, device=dev),
                          torch.empty((nq, kout), dtype=torch.float32, device=dev),
                          torch.empty((nq, kout), dtype=torch.int32, device=dev),
                          torch.empty((nq, nb), dtype=torch.int32, device=dev))
-        blk, out_d, out_i, bo = self._buf
-        # the three planes of `blk` are written in place by lmi_search / lmi_scan_topk
-        if self.shard_inference:
-            per, lo, hi = row_slice(nq, self.rank, self.world)
-            if self._bo_loc is None or self._bo_loc.shape != (per, nb):
-                self._bo_loc = torch.full((per, nb), -1, dtype=torch.int32, device=qn_t.device)
-            if hi > lo:
-                self.index.mlp_topk_device(qn_t[lo:hi], nb, self._bo_loc[: hi - lo])
-            bo = all_gather_rows(self._bo_loc, nq, self.world, self.group)
-            self.index.scan_topk_device(qs_t, bo, nb, k, blk[0], blk[1], blk[2])
-        else:
-            self.index.search_device(qn_t, qs_t, nb, k, blk[0], blk[1], blk[2], bo)
+        return self._buf
+
+    def new_route_buffer(self, nq: int, nb: int, dev):
+        """[ceil(nq / world), nb] int32 buffer for `route_local` (a pipeline keeps one per batch in flight)."""
+        import torch
+
+        per, _, _ = row_slice(nq, self.rank, self.world)
+        return torch.full((per, nb), -1, dtype=torch.int32, device=dev)
+
+    def route_local(self, qn_t, nb: int, bo_loc) -> None:
+        """This rank's share of the routing: the MLP on its 1/world slice of the batch -> bo_loc[: hi - lo].  No
+        collective, so a pipeline may run it for batch i+1 on a stream of its own beside the scan of batch i."""
+        assert self.shard_inference
+        _, lo, hi = row_slice(qn_t.shape[0], self.rank, self.world)
+        if hi > lo:
+            self.index.mlp_topk_device(qn_t[lo:hi], nb, bo_loc[: hi - lo])
+
+    def search_routed(self, qs_t, bo_loc, nb: int, k: int):
+        """The rest of a sharded search: all-gather of the bucket order, scan of the owned buckets, all-gather + merge."""
+        nq = qs_t.shape[0]
+        kout = self.index.kout(nb, k)
+        blk, out_d, out_i, _ = self._buffers(nq, nb, kout, qs_t.device)
+        bo = all_gather_rows(bo_loc, nq, self.world, self.group)
+        self.index.scan_topk_device(qs_t, bo, nb, k, blk[0], blk[1], blk[2])
+        return self._exchange(blk, out_d, out_i, bo, nq, kout)
+
+    def _exchange(self, blk, out_d, out_i, bo, nq: int, kout: int):
+        import torch
+
         if self.world == 1 and self.lib_comm is None:
             return blk[0].view(torch.float32), blk[1], bo
         if self.lib_comm is not None:
@@ -166,3 +180,16 @@ class ShardedSearcher:
         self.index.merge_gathered(g[0, 0], g[0, 1], g[0, 2], self.world, nq, kout, out_d, out_i,
                                   world_stride=3 * plane)
         return out_d, out_i, bo
+
+    def search(self, qn_t, qs_t, nb: int, k: int):
+        nq = qn_t.shape[0]
+        kout = self.index.kout(nb, k)
+        blk, out_d, out_i, bo = self._buffers(nq, nb, kout, qn_t.device)
+        # the three planes of `blk` are written in place by lmi_search / lmi_scan_topk
+        if self.shard_inference:
+            if self._bo_loc is None or self._bo_loc.shape[1] != nb or self._bo_loc.shape[0] != row_slice(nq, self.rank, self.world)[0]:
+                self._bo_loc = self.new_route_buffer(nq, nb, qn_t.device)
+            self.route_local(qn_t, nb, self._bo_loc)
+            return self.search_routed(qs_t, self._bo_loc, nb, k)
+        self.index.search_device(qn_t, qs_t, nb, k, blk[0], blk[1], blk[2], bo)
+        return self._exchange(blk, out_d, out_i, bo, nq, kout)
