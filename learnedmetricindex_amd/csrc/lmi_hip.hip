@@ -1154,7 +1154,7 @@ if (pf_parts <= 4) bound_merge_kernel<16><<<cdiv((long long)ncols * 16, 256), 25
             // selection at full occupancy, then the survivors' rows streamed through LDS in coalesced pieces (lmi_rescore.h)
             const int G = nb % 4 == 0 ? 4 : nb % 3 == 0 ? 3 : nb % 2 == 0 ? 2 : 1;  // slots of one query per wave
             const int groups = nslots / G;
-            CHK(h->surv_row.reserve((size_t)nslots * PF_KEEP * 4));
+            CHK(h->surv_row.reserve((size_t)nslots * RC_KEEP * 4));
             CHK(h->rs_flag.reserve((size_t)groups * 4));
             const int sub_cap = cdiv(groups, RC_SUB);
             CHK(h->rs_active.reserve((size_t)(RC_SUB + RC_SUB * sub_cap) * 4));

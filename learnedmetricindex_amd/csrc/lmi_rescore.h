@@ -9,9 +9,9 @@
 //                    rows -> surv_row[slot][..] (the first half of select_rescore_kernel, at full occupancy);
 //   rescore_kernel   one wave per G slots of ONE query (G | n_buckets, <= 4), one wave per SIMD.  The wave's
 //                    survivors are processed 64 rows at a time (one lane per chain); their rows are STREAMED through LDS in
-//                    chunks of 64 floats: one LDS-DMA piece moves 1 KiB = 256 contiguous bytes of four rows (lane -> (row,
-//                    16-byte segment), rows 272 bytes apart in LDS so that the chains' ds_read_b128 hit distinct
-//                    banks), chunk c+1 is in flight while lane r runs the canonical chain acc = fmaf(q[k], x[k], acc)
+//                    chunks of 32 floats: one LDS-DMA piece moves 1 KiB = 128 contiguous bytes of eight rows (lane -> (row,
+//                    16-byte segment), rows 144 bytes apart in LDS so that the chains' ds_read_b128 hit distinct
+//                    banks), chunks c+1, c+2 are in flight while lane r runs the canonical chain acc = fmaf(q[k], x[k], acc)
 //                    over chunk c of row r (q broadcast from LDS).  The wave owns its buffers: no barriers, the
 //                    ring is ordered by the wave's own counted `s_waitcnt vmcnt`.  Then, per slot, the 10 best by
 //                    (score desc, row asc) become the slot's rank list exactly as before.
@@ -22,27 +22,35 @@
 
 namespace lmi {
 
-// A/B on MI355X at C2 (rows, chunk, depth -> re-rank phase): (32, 128, 2) 0.574 ms, (64, 64, 2) 0.497, (64, 32, 3) 0.496,
+// A/B on MI355X at C2 (rows, chunk, depth -> re-rank phase, RC_KEEP 64): (32, 128, 2) 0.574 ms, (64, 64, 2) 0.497, (64, 32, 3) 0.496,
 // (32, 64, 3) 0.553, (32, 32, 4) 0.579: a wave's ~48 survivors are ONE batch of 64 chains instead of 32 + 16
 #ifndef LMI_RC_ROWS
 #define LMI_RC_ROWS 64
 #endif
 #ifndef LMI_RC_CHUNK
-#define LMI_RC_CHUNK 64
+#define LMI_RC_CHUNK 32
 #endif
 #ifndef LMI_RC_DEPTH
-#define LMI_RC_DEPTH 2
+#define LMI_RC_DEPTH 3
+#endif
+#ifndef LMI_RC_KEEP
+#define LMI_RC_KEEP 256
 #endif
 constexpr int RC_ROWS = LMI_RC_ROWS;              // chains per wave and batch (32 or 64)
 constexpr int RC_CHUNK = LMI_RC_CHUNK;            // floats of a row per chunk (a multiple of 32)
 constexpr int RC_DEPTH = LMI_RC_DEPTH;            // chunk buffers per wave: RC_DEPTH - 1 chunks in flight while one is chained
+// Survivors re-scored per slot on this path; more -> the exact fallback (one block brute-forcing the bucket per slot: the
+// cliff of duplicate-heavy data, tools/dup_cliff.py).  256 instead of the simple kernel's 64 lets clusters of up to ~200
+// copies of a vector through; (rows 64, chunk 32, depth 3) holds the 4 x 256 row / score lists in the same LDS and runs
+// at the speed of (64, 64, 2).
+constexpr int RC_KEEP = LMI_RC_KEEP;
 constexpr int RC_PITCH = RC_CHUNK * 4 + 16;       // bytes between rows in a chunk buffer (bank spread)
-constexpr int RC_PIECES = (RC_ROWS * RC_PITCH + 1023) / 1024;  // 17 LDS-DMA pieces per chunk (16 896 bytes of rows)
+constexpr int RC_PIECES = (RC_ROWS * RC_PITCH + 1023) / 1024;  // LDS-DMA pieces per chunk (9 for 64 rows x 144 bytes)
 constexpr int RC_BUF = RC_PIECES * 1024;          // a chunk buffer holds WHOLE pieces: the last one writes 512 bytes past the rows
 constexpr int RC_WAVES = 4;
 
 struct SelectOut {
-    unsigned* surv_row;   // [nslots][PF_KEEP]
+    unsigned* surv_row;   // [nslots][RC_KEEP]
     int G;                // slots per rescore wave
     int* grp_flag;        // [groups] zeroed per call: the group has a slot with survivors
     int* active;          // the groups to re-score, compacted (a rank of a sharded index owns 1/world of the slots: its
@@ -87,7 +95,7 @@ __device__ __forceinline__ void select_tail(const RescoreParams& P, const Select
     const float cut = pv - P.eps2[col];
     const unsigned cbits = __float_as_uint(cut);
     const unsigned kcut = cut != cut ? 1u : cbits ^ ((cbits >> 31) ? 0xffffffffu : 0x80000000u);
-    unsigned* out = O.surv_row + (size_t)p * PF_KEEP;
+    unsigned* out = O.surv_row + (size_t)p * RC_KEEP;
     unsigned nk = 0;
 #pragma unroll
     for (int i = 0; i < PERV; ++i) {
@@ -96,13 +104,13 @@ __device__ __forceinline__ void select_tail(const RescoreParams& P, const Select
             const unsigned long long bal = __ballot(keep);
             if (keep) {
                 const unsigned k = nk + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
-                if (k < (unsigned)PF_KEEP) out[k] = i < SPEC ? r_spec[i < SPEC ? i : 0] : cr[lane + 64 * i];
+                if (k < (unsigned)RC_KEEP) out[k] = i < SPEC ? r_spec[i < SPEC ? i : 0] : cr[lane + 64 * i];
             }
             nk += (unsigned)__popcll(bal);
         }
     }
     if (lane == 0) {
-        if (nk > (unsigned)PF_KEEP) P.fallback[p] = 1;
+        if (nk > (unsigned)RC_KEEP) P.fallback[p] = 1;
         else {
             P.nkeep[p] = (int)nk;
             if (nk > 0 && atomicExch(&O.grp_flag[p / O.G], 1) == 0) {
@@ -146,8 +154,8 @@ __global__ __launch_bounds__(256) void select_kernel(RescoreParams P, SelectOut 
     else select_tail<PER, SPEC>(P, O, p, col, lane, cnt, cs, cr, s_spec, r_spec);
 }
 
-// dynamic LDS per wave: 2 chunk buffers | q [d] | rows [G*PF_KEEP] | scores [G*PF_KEEP]
-__host__ __device__ inline int rc_wave_lds(int d, int G) { return RC_DEPTH * RC_BUF + d * 4 + G * PF_KEEP * 8; }
+// dynamic LDS per wave: RC_DEPTH chunk buffers | q [d] | rows [G*RC_KEEP] | scores [G*RC_KEEP]
+__host__ __device__ inline int rc_wave_lds(int d, int G) { return RC_DEPTH * RC_BUF + d * 4 + G * RC_KEEP * 8; }
 static_assert(RC_CHUNK % 32 == 0 && (RC_ROWS == 32 || RC_ROWS == 64) && RC_DEPTH >= 2 && RC_DEPTH <= 4, "rescore_kernel shapes");
 
 template <int G>
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(64 * RC_WAVES, 1) void rescore_kernel(RescoreParams
     unsigned char* mine = rc_smem + (size_t)wv * rc_wave_lds(d, G);
     float* qs = reinterpret_cast<float*>(mine + RC_DEPTH * RC_BUF);
     unsigned* krow = reinterpret_cast<unsigned*>(mine + RC_DEPTH * RC_BUF + d * 4);
-    float* ksc = reinterpret_cast<float*>(krow + G * PF_KEEP);
+    float* ksc = reinterpret_cast<float*>(krow + G * RC_KEEP);
     const float FMAXV = 3.402823466e+38f;
     // the survivor lists of the wave's slots, slot after slot, and the wave's query (G divides nb: one query per wave)
     int off[G + 1];
@@ -179,7 +187,7 @@ __global__ __launch_bounds__(64 * RC_WAVES, 1) void rescore_kernel(RescoreParams
     for (int sl = 0; sl < G; ++sl) {
         const int p = p0 + sl;
         const int nk = (P.slot_col[p] >= 0 && !P.fallback[p]) ? P.nkeep[p] : 0;   // wave-uniform
-        if (lane < nk) krow[off[sl] + lane] = O.surv_row[(size_t)p * PF_KEEP + lane];
+        for (int i = lane; i < nk; i += 64) krow[off[sl] + i] = O.surv_row[(size_t)p * RC_KEEP + i];
         off[sl + 1] = off[sl] + nk;
     }
     const int total = off[G];
