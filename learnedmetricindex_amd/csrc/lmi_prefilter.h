@@ -39,7 +39,11 @@ constexpr int PF_TILE_ROWS = 256;
 #define LMI_PF_STAGE_G 2
 #endif
 constexpr int PF_STAGE_G = LMI_PF_STAGE_G;  // k16-groups per stage -> BK = 16 * PF_STAGE_G
-constexpr int PF_CAP = 1024;        // candidate slots per (query, rank); overflow -> exact fallback
+#ifndef LMI_PF_CAP
+#define LMI_PF_CAP 1024  // 2048: duplicate-heavy data (60-100 copies of a vector) stops overflowing the buffers (tools/dup_cliff.py:
+                         // 11 -> 1.7 ms at 100 copies) for +1.2 % on the benchmark (the buffers' stride doubles)
+#endif
+constexpr int PF_CAP = LMI_PF_CAP;        // candidate slots per (query, rank); overflow -> exact fallback
 constexpr int PF_KEEP = 64;         // survivors re-scored per slot; more -> exact fallback
 
 // ---- ingest (prefilter mode): the index keeps a bucket-contiguous ROW-MAJOR f32 copy (exact
