@@ -138,11 +138,13 @@ struct lmi_index {
     int KG16 = 0;
     DevBuf slab16, rowmajor, xscale, xmaxbits, bnorm, bdelta, qdelta;
     DevBuf qnorm, qscale, qfrag16, eps2, cand_cnt, cand_row, cand_s, fallback, pf_bound, nkeep, surv_row, rs_flag, rs_active;
+    DevBuf redo;   // [1] count | [L] bucket flags | [columns] column flags (bytes): overflow_rebound_kernel
 #ifndef LMI_PASS2_QR_DEFAULT
 #define LMI_PASS2_QR_DEFAULT false
 #endif
     bool pass2_qr = LMI_PASS2_QR_DEFAULT;   // lmi_set_prefilter(h, 2) / LMI_PASS2_QR=1: pass2_qr_kernel (lmi_pass2_qr.h) instead of prefilter_kernel<false, 2>
     size_t stamps_off = 0;         // developer builds: byte offset of the phase stamps inside pf_bound
+    bool pf_redo = true;           // overflow_rebound_kernel + pass 2's redo launch (LMI_PF_NO_REDO=1 in the environment: off)
     bool rescore_streamed = true;  // lmi_rescore.h (LMI_RESCORE_SIMPLE=1 in the environment: select_rescore_kernel)
     int last_nslots = 0, last_nb = 0;
     bool last_fast = false;
@@ -214,6 +216,7 @@ extern "C" LMI_API int lmi_create(int device, lmi_index** out) {
     }
     if (const char* e = getenv("LMI_RESCORE_SIMPLE")) h->rescore_streamed = !(e[0] && e[0] != '0');
     if (const char* e = getenv("LMI_PASS2_QR")) h->pass2_qr = e[0] && e[0] != '0';
+    if (const char* e = getenv("LMI_PF_NO_REDO")) h->pf_redo = !(e[0] && e[0] != '0');
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pass2_qr_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)QR_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pass2_qr_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -237,7 +240,7 @@ extern "C" LMI_API int lmi_destroy(lmi_index* h) {
     DevBuf* bufs[] = {&h->slab, &h->ids_slab, &h->pos, &h->d_nb_rows, &h->d_rb_start, &h->d_nch, &h->stage,
                       &h->act[0], &h->act[1], &h->xfrag, &h->logits, &h->order, &h->q_nav, &h->q_srch, &h->m,
                       &h->cb_start, &h->item_base, &h->part_base, &h->stats, &h->head, &h->slot_local,
-                      &h->slot_col, &h->colmap, &h->qfrag, &h->grp, &h->col_thr, &h->slab16, &h->rowmajor, &h->xscale, &h->xmaxbits, &h->bnorm, &h->bdelta, &h->qdelta, &h->qnorm, &h->qscale, &h->qfrag16, &h->eps2, &h->cand_cnt, &h->cand_row, &h->cand_s, &h->fallback, &h->pf_bound, &h->nkeep, &h->part_score, &h->part_row, &h->rank_d,
+                      &h->slot_col, &h->colmap, &h->qfrag, &h->grp, &h->col_thr, &h->slab16, &h->rowmajor, &h->xscale, &h->xmaxbits, &h->bnorm, &h->bdelta, &h->qdelta, &h->qnorm, &h->qscale, &h->qfrag16, &h->eps2, &h->cand_cnt, &h->cand_row, &h->cand_s, &h->fallback, &h->pf_bound, &h->nkeep, &h->redo, &h->part_score, &h->part_row, &h->rank_d,
                       &h->rank_id, &h->out_d, &h->out_id, &h->out_key};
     for (DevBuf* b : bufs) b->release();
     for (auto& m : h->node_models) { for (auto& b : m.Wf) b.release(); for (auto& b : m.bias) b.release(); }
@@ -274,7 +277,7 @@ extern "C" LMI_API int lmi_clone_view(lmi_index* h, lmi_index** out) {
     for (DevBuf* b : shared) b->borrow();
     DevBuf* own[] = {&c->gather_send, &c->gather_recv, &c->pq_prob, &c->pq_ent, &c->pq_len, &c->nav_len, &c->nav_slab, &c->nav_ent,
                      &c->nav_count, &c->nav_colq, &c->nav_active, &c->aug_rows, &c->q_aug, &c->qn2, &c->stage, &c->qdelta, &c->qnorm,
-                     &c->qscale, &c->qfrag16, &c->eps2, &c->cand_cnt, &c->cand_row, &c->cand_s, &c->fallback, &c->pf_bound, &c->nkeep,
+                     &c->qscale, &c->qfrag16, &c->eps2, &c->cand_cnt, &c->cand_row, &c->cand_s, &c->fallback, &c->pf_bound, &c->nkeep, &c->redo,
                      &c->surv_row, &c->rs_flag, &c->rs_active, &c->act[0], &c->act[1], &c->xfrag, &c->logits, &c->order, &c->q_nav,
                      &c->q_srch, &c->m, &c->cb_start, &c->item_base, &c->part_base, &c->stats, &c->head, &c->slot_local, &c->slot_col,
                      &c->colmap, &c->qfrag, &c->grp, &c->col_thr, &c->part_score, &c->part_row, &c->rank_d, &c->rank_id, &c->out_d,
@@ -952,7 +955,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     CHK(h->item_base.reserve((L + 1) * 4));
     CHK(h->part_base.reserve((L + 1) * 8));
     CHK(h->stats.reserve(32));
-    CHK(h->head.reserve(64));
+    CHK(h->head.reserve(128));
     const size_t grp_ints = (size_t)NGRP * L + (size_t)NGRP * (L + 1) + 2 * NGRP + L + (L + 1);
     CHK(h->grp.reserve(grp_ints * 4));
     CHK(h->slot_local.reserve((size_t)nslots * 4));
@@ -987,7 +990,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     Z.count = 0;
     auto fill = [&](void* ptr, long long words, unsigned value) { Z.p[Z.count] = static_cast<unsigned*>(ptr); Z.n[Z.count] = words; Z.v[Z.count] = value; ++Z.count; };
     fill(h->m.p, L, 0u);
-    fill(h->head.p, 16, 0u);
+    fill(h->head.p, 32, 0u);   // [0..8] pass-2 queue heads + the pass-1 head, [16..24) the heads of pass 2's redo launch
     fill(h->colmap.p, (long long)ncols, 0xFFFFFFFFu);
     fill(h->col_thr.p, (long long)ncols, 0xFF800000u /* -inf */);
     if (fast) {
@@ -1011,6 +1014,8 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         fill(h->pf_bound.p, (long long)(ncols * pf_parts * 4 * PF_LK), 0xFF800000u /* -inf */);
         fill(h->cand_cnt.p, (long long)ncols, 0u);
         fill(h->stats.as<long long>() + 2, 4, 0u);
+        CHK(h->redo.reserve((size_t)(1 + L) * 4 + ncols));
+        fill(h->redo.p, (long long)(1 + L) + (long long)((ncols + 3) / 4), 0u);
     }
     fill_ranges_kernel<<<h->num_cus * 4, 256, 0, h->stream>>>(Z);
     HIPCHK(hipGetLastError());
@@ -1098,6 +1103,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         F.cand_cnt = h->cand_cnt.as<unsigned>();
         F.cand_row = h->cand_row.as<unsigned>();
         F.cand_s = h->cand_s.as<float>();
+        F.redo_count = nullptr; F.redo_bucket = nullptr; F.redo_col = nullptr;
         h->stamps_off = (ncols * pf_parts * 4 * PF_LK * 4 + 255) / 256 * 256;
         F.stamps = reinterpret_cast<unsigned long long*>(static_cast<char*>(h->pf_bound.p) + h->stamps_off);
 #if defined(LMI_QR_STAMPS) || defined(LMI_PF_STAMPS)
@@ -1128,6 +1134,21 @@ if (pf_parts <= 4) bound_merge_kernel<16><<<cdiv((long long)ncols * 16, 256), 25
         }
         HIPCHK(hipGetLastError());
         CHK(record(h, 6));
+        if (h->pf_redo && !h->debug_emit_all) {
+            // columns whose candidate buffer overflowed get the 10th best stored score as their bound and one more run of pass 2
+            // over their buckets (a launch that returns at once when there is none: ~15 us per batch; lmi_prefilter.h)
+            unsigned* rc = h->redo.as<unsigned>();
+            int* rb = reinterpret_cast<int*>(rc + 1);
+            unsigned char* rcol = reinterpret_cast<unsigned char*>(rc + 1 + L);
+            overflow_rebound_kernel<<<cdiv(nslots, 256), 256, 0, h->stream>>>(h->slot_col.as<int>(), d_order, nslots, F.cand_cnt, F.cand_s,
+                                                                             F.bound1, rc, rb, rcol);
+            HIPCHK(hipGetLastError());
+            PrefilterParams F2 = F;
+            F2.head = F.head + 16;
+            F2.redo_count = rc; F2.redo_bucket = rb; F2.redo_col = rcol;
+            prefilter_kernel<false, PF_NG><<<h->num_cus * PF_BLOCKS_PER_CU, 256 * PF_NG, 0, h->stream>>>(F2);
+            HIPCHK(hipGetLastError());
+        }
         RescoreParams Q;
         Q.bucket_order = d_order;
         Q.slot_col = h->slot_col.as<int>();

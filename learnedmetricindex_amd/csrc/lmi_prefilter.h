@@ -353,6 +353,10 @@ struct PrefilterParams {
     unsigned* cand_row;   // [columns][PF_CAP]
     float* cand_s;        // [columns][PF_CAP]
     unsigned long long* stamps;  // LMI_PF_STAMPS / LMI_QR_STAMPS builds: phase cycles (behind the pass-1 lists in pf_bound)
+    // second run of pass 2 for the columns whose candidate buffer overflowed (overflow_rebound_kernel); all null in the first
+    const unsigned* redo_count;      // [1] columns to redo: 0 -> the launch returns at once
+    const int* redo_bucket;          // [L] the bucket has such a column: its items are run again, the others skipped
+    const unsigned char* redo_col;   // [columns] only these columns keep a finite threshold
 };
 
 // Pass 1 keeps the PF_LK best values per lane and column.  The bound only has to be the 10th best of SOME
@@ -743,7 +747,8 @@ struct PreItem {
                 for (int j = 0; j < PF_LK; ++j) lv[SAMPLE ? n : 0][j] = -INFINITY;
             } else {
                 const float v10 = P.bound1[col0 + n * 32 + c];
-                thr[n] = n * 32 + c < m_left ? v10 - P.eps2[col0 + n * 32 + c] : INFINITY;
+                const bool wanted = !P.redo_col || (n * 32 + c < m_left && P.redo_col[col0 + n * 32 + c]);
+                thr[n] = n * 32 + c < m_left && wanted ? v10 - P.eps2[col0 + n * 32 + c] : INFINITY;
             }
 #pragma unroll
             for (int j = 0; j < PF_RB; ++j)
@@ -920,9 +925,12 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void prefilter_kernel(Pr
 #define PF_ITEM_ARGS P, sB0, sB1, sB2, sA0, sA1, sA2, sB3, sA3, sList
     int* s_item = reinterpret_cast<int*>(sB1);
     int grp = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & (NGRP - 1));
+    if (!SAMPLE && P.redo_count && *P.redo_count == 0u) return;  // the redo launch of a batch without overflowed columns
     for (;;) {
         if (threadIdx.x == 0) {
             int b = -1, local = 0;
+          do {
+            b = -1;
             if (SAMPLE) {  // one plain queue of (bucket, query tile) items
                 const int tot = P.qt_base[P.L] * P.parts;
                 const int it = (int)atomicAdd(&P.head[NGRP], 1u);
@@ -956,6 +964,7 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void prefilter_kernel(Pr
                     grp = (grp + 1) & (NGRP - 1);
                 }
             }
+          } while (!SAMPLE && P.redo_bucket && b >= 0 && !P.redo_bucket[b]);  // redo launch: items of untouched buckets are dropped
             s_item[0] = b;
             s_item[1] = local;
         }
@@ -1238,6 +1247,40 @@ __global__ __launch_bounds__(64 * RS_WAVES) __attribute__((amdgpu_waves_per_eu(L
 }
 
 // statistics on request: out[0] += survivors, out[1] += fallback slots
+// Candidate-buffer overflow (more than PF_CAP rows passed a column's threshold: the sampled bound was loose, typically many
+// copies of the same vectors near the top).  The PF_CAP candidates that were stored are a subset of the bucket: the 10th best
+// of their scores is a valid -- and much tighter -- lower bound of That.  The column gets that bound, an empty buffer and a
+// flag; prefilter_kernel<false> is launched once more and re-runs the buckets that hold such columns with every other
+// column's threshold at +inf.  Without this such a slot took the exact fallback (one block brute-forcing the bucket).
+__global__ void overflow_rebound_kernel(const int* __restrict__ slot_col, const int* __restrict__ bucket_order, int nslots,
+                                        unsigned* __restrict__ cand_cnt, const float* __restrict__ cand_s, float* __restrict__ bound1,
+                                        unsigned* __restrict__ redo_count, int* __restrict__ redo_bucket, unsigned char* __restrict__ redo_col) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nslots) return;
+    const int col = slot_col[p];
+    if (col < 0 || cand_cnt[col] <= (unsigned)PF_CAP) return;
+    float v[KPB];
+#pragma unroll
+    for (int j = 0; j < KPB; ++j) v[j] = -INFINITY;
+    const float* cs = cand_s + (size_t)col * PF_CAP;
+    for (int i = 0; i < PF_CAP; ++i) {
+        float s = cs[i];
+        if (s > v[KPB - 1]) {
+#pragma unroll
+            for (int t = 0; t < KPB; ++t) {  // sorted insert (descending)
+                const float hi = fmaxf(v[t], s);
+                s = fminf(v[t], s);
+                v[t] = hi;
+            }
+        }
+    }
+    if (v[KPB - 1] > bound1[col]) bound1[col] = v[KPB - 1];
+    cand_cnt[col] = 0u;
+    redo_col[col] = 1;
+    redo_bucket[bucket_order[p]] = 1;
+    atomicAdd(redo_count, 1u);
+}
+
 __global__ void prefilter_stats_kernel(const int* __restrict__ nkeep, const int* __restrict__ fallback, int nslots,
                                        unsigned long long* __restrict__ out) {
     unsigned long long a = 0, b = 0;

@@ -160,3 +160,24 @@ def test_query_tile_shapes(capi, oracle, d):
     D, I = oracle.knn_ip(Q[qsel], X[rows], 10)
     np.testing.assert_array_equal(i1[qsel], (rows[I] + 1).astype(np.uint32))
     np.testing.assert_array_equal(d1[qsel], np.float32(1) - D)
+
+
+def test_duplicate_heavy_buckets_recover_without_fallback(capi, oracle):
+    """Every vector copied 100 times (1e-7 apart): far more than PF_CAP rows pass a column's sampled threshold.  The
+    overflowed columns get the 10th best STORED score as their bound and a second run of pass 2 (overflow_rebound_kernel),
+    the ~100 survivors per slot fit the streamed re-rank: (almost) no slot takes the exact fallback, results as always
+    identical to the all-f32 scan."""
+    rs = np.random.RandomState(21)
+    d, L, dup, U, nq, nb = 64, 4, 100, 1200, 160, 2
+    base = rs.randn(U, d).astype(np.float32)
+    base /= np.linalg.norm(base, axis=1, keepdims=True)
+    X = np.repeat(base, dup, axis=0) + (1e-7 * rs.randn(U * dup, d)).astype(np.float32)
+    labels = rs.randint(0, L, size=U).repeat(dup).astype(np.int64)
+    Q = base[rs.choice(U, nq)] + 0.05 * rs.randn(nq, d).astype(np.float32)
+    Q = (Q / np.linalg.norm(Q, axis=1, keepdims=True)).astype(np.float32)
+    order = np.stack([rs.permutation(L)[:nb] for _ in range(nq)]).astype(np.int32)
+    (d1, i1, sv, fb), (d0, i0, _, _) = both_modes(capi, X, labels, L, Q, order, chunk_rows=2048)
+    np.testing.assert_array_equal(i1, i0)
+    np.testing.assert_array_equal(d1, d0)
+    assert fb <= nq * nb // 20, f"{fb} of {nq * nb} slots fell back"
+    assert sv / (nq * nb) > 50   # the copies of the best vectors are all re-scored
