@@ -1316,9 +1316,32 @@ __global__ __launch_bounds__(256) void fallback_kernel(RescoreParams P) {
     unsigned id[KPB];
 #pragma unroll
     for (int j = 0; j < KPB; ++j) { v[j] = -INFINITY; id[j] = NOROW; }
+    // A slot whose candidate buffer did NOT overflow is here for its survivor count only (more rows within 2 eps' of its
+    // top-10 than the re-rank holds: hundreds of copies of a vector): its candidates are a complete superset of the
+    // canonical top-10, so re-scoring those <= PF_CAP rows is exact and ~100 x cheaper than the whole bucket.
+    const int ccol = P.slot_col[p];
+    const unsigned ccnt = ccol >= 0 ? P.cand_cnt[ccol] : 0xffffffffu;
+    if (ccnt <= (unsigned)PF_CAP) {
+        const unsigned* cr = P.cand_row + (size_t)ccol * PF_CAP;
+        for (unsigned it = tid; it < ccnt; it += 256) {
+            const unsigned row = cr[it];
+            const float s = exact_score(P.rows, (size_t)rb0 * 32 + row, qv, P.d);
+            if (better(s, row, v[KPB - 1], id[KPB - 1])) {  // candidates come in no order: ties by row here
+#pragma unroll
+                for (int t = KPB - 1; t > 0; --t) {   // list_insert with the (score desc, row asc) order
+                    const bool shift = better(s, row, v[t - 1], id[t - 1]);
+                    const bool here = better(s, row, v[t], id[t]);
+                    id[t] = shift ? id[t - 1] : (here ? row : id[t]);
+                    v[t] = shift ? v[t - 1] : (here ? s : v[t]);
+                }
+                if (better(s, row, v[0], id[0])) { v[0] = s; id[0] = row; }
+            }
+        }
+    } else {
     for (unsigned row = tid; row < (unsigned)n_b; row += 256) {
         const float s = exact_score(P.rows, (size_t)rb0 * 32 + row, qv, P.d);
         if (s > v[KPB - 1]) list_insert(v, id, s, row);  // rows ascend per thread: strict > keeps the earlier
+    }
     }
 #pragma unroll
     for (int j = 0; j < KPB; ++j) { fs[tid * KPB + j] = v[j]; fr[tid * KPB + j] = id[j]; }

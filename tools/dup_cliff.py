@@ -3,7 +3,7 @@ sys.path.insert(0, "/root/repo")
 from learnedmetricindex_amd import _capi
 rs = np.random.RandomState(0)
 d, L, nb = 128, 16, 2
-for dup in (1, 20, 60, 100):
+for dup in (1, 20, 60, 100, 300, 600):
     U = 200_000 // dup
     base = rs.randn(U, d).astype(np.float32); base /= np.linalg.norm(base, axis=1, keepdims=True)
     X = np.repeat(base, dup, axis=0)
