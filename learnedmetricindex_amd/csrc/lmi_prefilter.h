@@ -1002,7 +1002,9 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void prefilter_kernel(Pr
 //   each survivor is re-scored by one lane with the canonical chain acc = fmaf(q[k], x[k], acc)
 //   on the f32 slab; the 10 best by (score desc, row asc) become the slot's rank list, in the same
 //   form merge_kernel's phase A writes (dist = 1 - s, ids, faiss padding for short buckets).
-// Candidate overflow (> PF_CAP emitted or > PF_KEEP survivors) sets fallback[p] instead.
+// Overflow: a column with more than PF_CAP emitted candidates first gets a tighter bound and a second run of pass 2
+// (overflow_rebound_kernel); a slot still over PF_CAP, or with more survivors than the re-rank holds (PF_KEEP here, RC_KEEP
+// on the streamed path), sets fallback[p]: fallback_kernel re-scores its candidates (buffer complete) or its whole bucket.
 // ------------------------------------------------------------------------------------------------
 struct RescoreParams {
     const int* bucket_order;
