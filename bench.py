@@ -206,7 +206,7 @@ class Workload:
         tm = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-        res = dict(elapsed=float(tm.item()), phases=phases, n_timed=int(n_timed) // calls,
+        res = dict(elapsed=float(tm.item()), elapsed_local=elapsed, phases=phases, n_timed=int(n_timed) // calls,
                    out_d=out_d, out_i=out_i, bo=bo, calls=calls, overlapped=bool(pipe.overlap or pipe.sh_overlap))
         if measure_resident:
             eng.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -359,6 +359,54 @@ def cpu_baselines(wl, res, args):
             "host_cpu_count": host_cores, "index_copy_to_host_s": round(t_copy, 2), "variants": variants}
 
 
+def launch_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as a CHILD torchrun (one process per GPU) before this
+    process has touched the GPU (no torch import, no HIP call so far -- a process that has initialised the GPU must
+    never be replaced or forked from), forward the children's stdout (rank 0's JSON line) and return their exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    log(f"[bench] --gpus {n} without WORLD_SIZE: launching {' '.join(cmd[1:9])} ...")
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, bufsize=1)
+    try:
+        for line in child.stdout:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        return child.wait()
+    except BaseException:
+        child.kill()
+        child.wait()
+        raise
+
+
+def launch_check() -> None:
+    """LMI_BENCH_LAUNCH_CHECK=1: rendezvous + one all-reduce over gloo and a JSON line from rank 0, nothing else -- lets
+    the CPU test suite (no GPU) drive `python bench.py --gpus N` through launch_ranks end to end."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    fail = os.environ.get("LMI_BENCH_LAUNCH_CHECK_FAIL_RANK")
+    if fail is not None and int(fail) == rank:
+        sys.exit(7)
+    t = torch.tensor([rank + 1], dtype=torch.int64)
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "world": world, "sum": int(t.item())}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -403,6 +451,12 @@ def main():
         if getattr(args, key) is not None:
             cfg[key] = getattr(args, key)
     N, d, L, nb, nq, k = cfg["n"], cfg["d"], cfg["leaves"], cfg["nb"], cfg["nq"], args.k
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if os.environ.get("LMI_BENCH_LAUNCH_CHECK"):
+        assert int(os.environ.get("WORLD_SIZE", "1")) == args.gpus
+        return launch_check()
 
     import torch
     import torch.distributed as dist
@@ -450,6 +504,16 @@ def main():
         alt = {"mode": "replicated MLP on every rank, ONE all-gather (per-rank top-k)",
                "value": round(nq * args.steps / r2["elapsed"], 2), "ms_per_step": round(r2["elapsed"] / args.steps * 1e3, 4)}
     recall = None if args.no_recall else wl.recall(out_i, min(args.recall_queries, nq))
+    # N > 1: every rank's own phase means and scan share, so that a SCALE line explains itself (rank 0 prints them)
+    per_rank = None
+    if world > 1:
+        names = ("inference", "route_pack", "scan", "merge", "total", "pf_sample", "pf_emit", "rescore", "fallback")
+        mine = {"rank": rank, "scan_pairs": int(pairs), "scan_items": int(items),
+                "rows_owned": int(sizes[owner == rank].sum()), "buckets_owned": int((owner == rank).sum()),
+                "step_ms_this_rank": round(res["elapsed_local"] / args.steps * 1e3, 4),
+                "phases_ms": {n_: round(float(phases[i]), 4) for i, n_ in enumerate(names)}}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -551,6 +615,7 @@ def main():
             "cpu_baseline": cpu,
             "resident": resident,
             "sharded_alt_mode": alt,
+            "per_rank": per_rank,
             "hard_leg": hard,
             **({"diagnostic": f"emulated shard {args.emulate_shard}: NOT a bench line"} if args.emulate_shard else {}),
             "phases_ms": {"inference": round(float(res["phases_resident"][0] if res.get("overlapped") and "phases_resident" in res else phases[0]), 4), "route_pack": round(float(phases[1]), 4),

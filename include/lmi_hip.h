@@ -211,9 +211,8 @@ LMI_API int lmi_scan_stats(lmi_index *h, double *flops, int64_t *pairs, int64_t 
  * re-ranking of the survivors (lmi_prefilter.h); off: every similarity by f32 MFMA.  Both modes
  * return bit-identical results; call before lmi_buckets_begin (the index is stored differently:
  * row-major f32 + fp16 fragments vs f32 fragments).  lmi_prefilter_stats: whether the last scan used the prefilter, how many candidates were
- * re-scored exactly and how many (query, rank) slots fell back to the exact brute-force kernel.
- * on = 2: the prefilter with the query-resident form of its pass 2 (lmi_pass2_qr.h; d <= 768, else as 1) instead of the
- * streamed one; 1 <-> 2 may be switched at any time, results are identical (the streamed form is the faster one). */
+ * re-scored exactly and how many (query, rank) slots fell back to the exact brute-force kernel.  Any other value of
+ * `on` is an error. */
 LMI_API int lmi_set_prefilter(lmi_index *h, int on);
 /* A second handle on the SAME index (no reference counterpart: the reference is single-threaded Python).  The clone
  * borrows the parent's MLP weights, tree and bucket slabs and has per-call workspaces, a stream and timing events of its

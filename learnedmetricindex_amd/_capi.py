@@ -173,8 +173,7 @@ class Index:
             pass
 
     def set_prefilter(self, on) -> None:
-        """fp16 prefilter + exact re-rank (default) or f32 MFMA for every similarity; same results.
-        2: the prefilter with the query-resident pass 2 (1 <-> 2 can be switched on a built index)."""
+        """fp16 prefilter + exact re-rank (default) or f32 MFMA for every similarity; same results."""
         _check(lib().lmi_set_prefilter(self._h, int(on)))
 
     def debug_peek(self, name: str, nbytes: int) -> np.ndarray:

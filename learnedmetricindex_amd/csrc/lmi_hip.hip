@@ -3,7 +3,6 @@
 // weights and the per-call workspaces; enqueues the kernels of lmi_kernels.h on one HIP stream.
 #include "lmi_kernels.h"
 #include "lmi_prefilter.h"
-#include "lmi_pass2_qr.h"
 #include "lmi_mlp_fused.h"
 #include "lmi_rescore.h"
 
@@ -139,10 +138,6 @@ struct lmi_index {
     DevBuf slab16, rowmajor, xscale, xmaxbits, bnorm, bdelta, qdelta;
     DevBuf qnorm, qscale, qfrag16, eps2, cand_cnt, cand_row, cand_s, fallback, pf_bound, nkeep, surv_row, rs_flag, rs_active;
     DevBuf redo;   // [1] count | [L] bucket flags | [columns] column flags (bytes): overflow_rebound_kernel
-#ifndef LMI_PASS2_QR_DEFAULT
-#define LMI_PASS2_QR_DEFAULT false
-#endif
-    bool pass2_qr = LMI_PASS2_QR_DEFAULT;   // lmi_set_prefilter(h, 2) / LMI_PASS2_QR=1: pass2_qr_kernel (lmi_pass2_qr.h) instead of prefilter_kernel<false, 2>
     size_t stamps_off = 0;         // developer builds: byte offset of the phase stamps inside pf_bound
     bool pf_redo = true;           // overflow_rebound_kernel + pass 2's redo launch (LMI_PF_NO_REDO=1 in the environment: off)
     bool rescore_streamed = true;  // lmi_rescore.h (LMI_RESCORE_SIMPLE=1 in the environment: select_rescore_kernel)
@@ -215,12 +210,12 @@ extern "C" LMI_API int lmi_create(int device, lmi_index** out) {
         if (!h->pf_hw_ok) h->prefilter = false;
     }
     if (const char* e = getenv("LMI_RESCORE_SIMPLE")) h->rescore_streamed = !(e[0] && e[0] != '0');
-    if (const char* e = getenv("LMI_PASS2_QR")) h->pass2_qr = e[0] && e[0] != '0';
     if (const char* e = getenv("LMI_PF_NO_REDO")) h->pf_redo = !(e[0] && e[0] != '0');
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pass2_qr_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)QR_LDS));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pass2_qr_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)QR_LDS));
+    // per handle = per device (a process may hold handles on several devices; the attribute is per device)
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     *out = h;
     return 0;
 }
@@ -321,8 +316,8 @@ extern "C" LMI_API int lmi_set_prefilter(lmi_index* h, int on) {
     if ((h->built || h->building) && (on != 0) != h->prefilter)
         return fail("lmi_set_prefilter: the mode is fixed once lmi_buckets_begin has run (the index is stored differently)");
     if (on && !h->pf_hw_ok) return fail("lmi_set_prefilter: fp16 subnormal self-test failed on this device; the prefilter's error bound does not hold");
+    if (on != 0 && on != 1) return fail("lmi_set_prefilter: mode %d unknown (0: all-f32 scan, 1: fp16 prefilter + exact re-rank)", on);
     h->prefilter = on != 0;
-    if (on) h->pass2_qr = on == 2;
     return 0;
 }
 
@@ -988,7 +983,8 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     int pf_parts = 4;
     FillRanges Z;
     Z.count = 0;
-    auto fill = [&](void* ptr, long long words, unsigned value) { Z.p[Z.count] = static_cast<unsigned*>(ptr); Z.n[Z.count] = words; Z.v[Z.count] = value; ++Z.count; };
+    bool fill_ok = true;
+    auto fill = [&](void* ptr, long long words, unsigned value) { fill_ok = Z.add(ptr, words, value) && fill_ok; };
     fill(h->m.p, L, 0u);
     fill(h->head.p, 32, 0u);   // [0..8] pass-2 queue heads + the pass-1 head, [16..24) the heads of pass 2's redo launch
     fill(h->colmap.p, (long long)ncols, 0xFFFFFFFFu);
@@ -1017,6 +1013,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         CHK(h->redo.reserve((size_t)(1 + L) * 4 + ncols));
         fill(h->redo.p, (long long)(1 + L) + (long long)((ncols + 3) / 4), 0u);
     }
+    if (!fill_ok) return fail("internal: more than %d fill ranges queued (%s:%d)", FillRanges::MAXR, __FILE__, __LINE__);
     fill_ranges_kernel<<<h->num_cus * 4, 256, 0, h->stream>>>(Z);
     HIPCHK(hipGetLastError());
     route_count_kernel<<<cdiv(nslots, 256), 256, 0, h->stream>>>(d_order, nslots, L, R, h->slot_local.as<int>());
@@ -1106,7 +1103,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         F.redo_count = nullptr; F.redo_bucket = nullptr; F.redo_col = nullptr;
         h->stamps_off = (ncols * pf_parts * 4 * PF_LK * 4 + 255) / 256 * 256;
         F.stamps = reinterpret_cast<unsigned long long*>(static_cast<char*>(h->pf_bound.p) + h->stamps_off);
-#if defined(LMI_QR_STAMPS) || defined(LMI_PF_STAMPS)
+#if defined(LMI_PF_STAMPS)
         HIPCHK(hipMemsetAsync(F.stamps, 0, 2 * 8 * 12 * 8, h->stream));
 #endif
         constexpr int PF_BLOCKS_PER_CU = PF_NG == 1 ? 2 : 1;
@@ -1126,12 +1123,7 @@ if (pf_parts <= 4) bound_merge_kernel<16><<<cdiv((long long)ncols * 16, 256), 25
 
         // pass 2: candidates.  The query-resident form (opt-in: measured slower) needs a col-block's
         // fragments to fit a wave's registers (d <= 768)
-        if (h->pass2_qr && PF_NG == 2 && h->KG16 <= QR_KMAX) {
-            if (h->KG16 == QR_KMAX) pass2_qr_kernel<true><<<h->num_cus, 64 * QR_WAVES, QR_LDS, h->stream>>>(F);
-            else pass2_qr_kernel<false><<<h->num_cus, 64 * QR_WAVES, QR_LDS, h->stream>>>(F);
-        } else {
-            prefilter_kernel<false, PF_NG><<<h->num_cus * PF_BLOCKS_PER_CU, 256 * PF_NG, 0, h->stream>>>(F);
-        }
+        prefilter_kernel<false, PF_NG><<<h->num_cus * PF_BLOCKS_PER_CU, 256 * PF_NG, 0, h->stream>>>(F);
         HIPCHK(hipGetLastError());
         CHK(record(h, 6));
         if (h->pf_redo && !h->debug_emit_all) {
@@ -1197,15 +1189,7 @@ if (pf_parts <= 4) bound_merge_kernel<16><<<cdiv((long long)ncols * 16, 256), 25
             HIPCHK(hipGetLastError());
             const int blocks = cdiv(groups, RC_WAVES);
             const int lds = RC_WAVES * rc_wave_lds(h->d, G);
-#define LMI_RC_LAUNCH(GV)                                                                                              \
-            {                                                                                                          \
-                static bool attr_set = false;                                                                          \
-                if (!attr_set) {                                                                                       \
-                    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<GV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-                    attr_set = true;                                                                                   \
-                }                                                                                                      \
-                rescore_kernel<GV><<<blocks, 64 * RC_WAVES, lds, h->stream>>>(Q, O);                                   \
-            }
+#define LMI_RC_LAUNCH(GV) { rescore_kernel<GV><<<blocks, 64 * RC_WAVES, lds, h->stream>>>(Q, O); }
             if (G == 4) LMI_RC_LAUNCH(4) else if (G == 3) LMI_RC_LAUNCH(3) else if (G == 2) LMI_RC_LAUNCH(2) else LMI_RC_LAUNCH(1)
 #undef LMI_RC_LAUNCH
             HIPCHK(hipGetLastError());
@@ -1633,12 +1617,14 @@ extern "C" LMI_API int lmi_nav_order(lmi_index* h, const float* queries_nav, int
     CHK(record(h, 0));
     FillRanges Z;
     Z.count = 0;
-    auto fill = [&](void* ptr, long long words, unsigned value) { Z.p[Z.count] = static_cast<unsigned*>(ptr); Z.n[Z.count] = words; Z.v[Z.count] = value; ++Z.count; };
+    bool fill_ok = true;
+    auto fill = [&](void* ptr, long long words, unsigned value) { fill_ok = Z.add(ptr, words, value) && fill_ok; };
     fill(h->pq_len.p, nq, 0u);
     fill(h->nav_len.p, nq, 0u);
     fill(d_slab, (long long)nq * nb, 0xFFFFFFFFu);
     fill(d_ent, (long long)nq * nb, 0xFFFFFFFFu);
     fill(h->nav_count.p, 2 * (nm + 1), 0u);
+    if (!fill_ok) return fail("internal: more than %d fill ranges queued (%s:%d)", FillRanges::MAXR, __FILE__, __LINE__);
     fill_ranges_kernel<<<h->num_cus * 2, 256, 0, h->stream>>>(Z);
     HIPCHK(hipGetLastError());
     FusedParams P;
@@ -1729,7 +1715,7 @@ extern "C" LMI_API int lmi_debug_read_candidates(lmi_index* h, int64_t slot, int
     return 0;
 }
 
-// developer aid: the first `bytes` of a named internal device buffer ("pf_bound": LMI_QR_STAMPS builds keep phase timings there)
+// developer aid: the first `bytes` of a named internal device buffer ("pf_bound": LMI_PF_STAMPS builds keep phase timings there)
 extern "C" LMI_API int lmi_debug_peek(lmi_index* h, const char* name, void* dst, int64_t bytes) {
     if (!h || !name || !dst) return fail("lmi_debug_peek: NULL argument");
     CHK(set_dev(h));

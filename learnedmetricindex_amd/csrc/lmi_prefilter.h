@@ -166,11 +166,17 @@ __global__ void pf_selftest_kernel(int* __restrict__ ok) {
 
 // ---- per batch: one launch initialises every per-call array (eight hipMemsetAsync calls took 37 us) ----
 struct FillRanges {
-    static constexpr int MAXR = 8;
+    static constexpr int MAXR = 12;
     unsigned* p[MAXR];
     long long n[MAXR];   // 32-bit words
     unsigned v[MAXR];
     int count;
+    // host side: false (and nothing written) when the list is full -- callers turn that into an error, never a stray write
+    bool add(void* ptr, long long words, unsigned value) {
+        if (count >= MAXR) return false;
+        p[count] = static_cast<unsigned*>(ptr); n[count] = words; v[count] = value; ++count;
+        return true;
+    }
 };
 __global__ void fill_ranges_kernel(FillRanges F) {
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -352,7 +358,7 @@ struct PrefilterParams {
     unsigned* cand_cnt;   // [columns]
     unsigned* cand_row;   // [columns][PF_CAP]
     float* cand_s;        // [columns][PF_CAP]
-    unsigned long long* stamps;  // LMI_PF_STAMPS / LMI_QR_STAMPS builds: phase cycles (behind the pass-1 lists in pf_bound)
+    unsigned long long* stamps;  // LMI_PF_STAMPS builds: phase cycles (behind the pass-1 lists in pf_bound)
     // second run of pass 2 for the columns whose candidate buffer overflowed (overflow_rebound_kernel); all null in the first
     const unsigned* redo_count;      // [1] columns to redo: 0 -> the launch returns at once
     const int* redo_bucket;          // [L] the bucket has such a column: its items are run again, the others skipped

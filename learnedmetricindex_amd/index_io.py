@@ -2,7 +2,7 @@
 DataFrames -- replaces the reference's whole-object pickle (search.py:234-241, utils.py:14-29),
 which stores the models only and drops `data_prediction` and the vectors.
 
-    <dir>/meta.json      format/version, N, d, n_categories, bucket paths, model descriptions
+    <dir>/meta.json      format/version, N, d, metric ("ip" | "l2"), n_categories, bucket paths, model descriptions
     <dir>/weights.npz    Linear weights/biases of the root and internal models (float32)
     <dir>/sizes.npy      int64 [B]    objects per bucket, in bucket-id order
     <dir>/ids.npy        uint32 [N]   object labels, bucket-contiguous
@@ -20,7 +20,7 @@ from . import _capi
 from .li.LearnedIndex import LearnedIndex
 from .li.model import linear_layers, network_from_layers
 
-FORMAT, VERSION = "lmi-mi355x-index", 1
+FORMAT, VERSION = "lmi-mi355x-index", 2   # 2: + "metric" (a version-1 directory has none: inner product)
 
 
 def _put(store, prefix, net):
@@ -42,7 +42,7 @@ def save_index(path: str, li: LearnedIndex, n_categories: List[int]) -> None:
     sizes = eng.bucket_sizes()
     N, d = int(sizes.sum()), eng.d
     weights = {}
-    meta = {"format": FORMAT, "version": VERSION, "N": N, "d": d, "n_categories": [int(v) for v in n_categories],
+    meta = {"format": FORMAT, "version": VERSION, "N": N, "d": d, "metric": eng.metric, "n_categories": [int(v) for v in n_categories],
             "bucket_paths": [[int(v) for v in p] for p in li.bucket_paths],
             "root_layers": _put(weights, "root_", li.root_model), "internal": []}
     for i, (p, net) in enumerate(li.internal_models.items()):
@@ -69,7 +69,9 @@ def save_index(path: str, li: LearnedIndex, n_categories: List[int]) -> None:
 def load_index(path: str, device: int = 0) -> Tuple[LearnedIndex, List[int]]:
     """(LearnedIndex with the index resident on `device`, n_categories); use `li.search_resident`."""
     meta = json.load(open(os.path.join(path, "meta.json")))
-    assert meta["format"] == FORMAT and meta["version"] == VERSION
+    assert meta["format"] == FORMAT and meta["version"] in (1, VERSION), f"unknown index format {meta.get('format')} v{meta.get('version')}"
+    metric = meta.get("metric", "ip")
+    assert metric in _capi.Index.METRICS, f"unknown metric {metric!r} in {path}/meta.json"
     store = np.load(os.path.join(path, "weights.npz"))
     root = network_from_layers(_get(store, "root_", meta["root_layers"]))
     internal = {tuple(e["path"]): network_from_layers(_get(store, f"int{i}_", e["layers"]))
@@ -78,7 +80,7 @@ def load_index(path: str, device: int = 0) -> Tuple[LearnedIndex, List[int]]:
     sizes = np.load(os.path.join(path, "sizes.npy"))
     ids = np.load(os.path.join(path, "ids.npy"))
     vec = np.load(os.path.join(path, "vectors.f32.npy"), mmap_mode="r")
-    eng = _capi.Index(device)
+    eng = _capi.Index(device, metric=metric)
     if len(meta["n_categories"]) == 1:
         eng.set_mlp(linear_layers(root.model))
     else:

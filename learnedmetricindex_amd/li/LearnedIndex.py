@@ -102,19 +102,38 @@ class LearnedIndex(Logger):
         if dp.ndim == 1:
             dp = dp[:, None]
         assert dp.shape[0] == data_navigation.shape[0] == data_search.shape[0]
-        # What the resident copy was built from.  The reference re-reads the frames on every call; here a cheap
-        # content fingerprint (strided samples of the vectors, the labels, the placement and the root weights) makes
-        # an in-place edit, a re-labelled or re-trained index miss the cache instead of answering from a stale slab,
-        # and an equal-content copy of `data_prediction` hit it.  `invalidate()` forces a rebuild.
-        def _sample(a, n=4096):
-            a = np.asarray(a).reshape(-1)
-            return float(np.asarray(a[:: max(1, a.shape[0] // n)], dtype=np.float64).sum()) if a.size else 0.0
+        # What the resident copy was built from.  The reference re-reads the frames on every call; here the key is the
+        # frames' identity (object id, shape, address of a single-block frame's values) AND an order-sensitive CRC of
+        # content samples (strided rows of the vectors, labels, placement) and of EVERY model's weights: an in-place
+        # edit at a sampled position, a re-labelled, re-placed or re-trained index misses the cache instead of being
+        # answered from a stale slab.  An in-place edit of unsampled rows of the same frame object is the one case
+        # only `invalidate()` catches.
+        import zlib
 
-        rows = np.linspace(0, max(0, data_search.shape[0] - 1), num=min(64, max(1, data_search.shape[0])), dtype=np.int64)
-        first = linear_layers(self.root_model.model)[0][0]
-        key = (tuple(data_search.shape), _sample(data_search.iloc[rows].to_numpy(dtype=np.float32)) if data_search.shape[0] else 0.0,
-               _sample(data_navigation.index.to_numpy()), dp.shape, _sample(dp), _sample(first), len(self.internal_models),
-               tuple(n_categories), device, metric)
+        def _crc(a, n=65536):
+            a = np.ascontiguousarray(np.asarray(a).reshape(-1))
+            if a.size > n:
+                a = np.ascontiguousarray(a[:: a.shape[0] // n])
+            return zlib.crc32(a.view(np.uint8)) if a.size else 0
+
+        def _addr(df):
+            try:
+                mgr = df._mgr
+                if len(mgr.blocks) == 1:
+                    return int(mgr.blocks[0].values.__array_interface__["data"][0])
+            except Exception:  # noqa: BLE001  (pandas internals: best effort)
+                pass
+            return 0
+
+        rows = np.linspace(0, max(0, data_search.shape[0] - 1), num=min(256, max(1, data_search.shape[0])), dtype=np.int64)
+        w_crc = 0
+        for net in [self.root_model] + list(self.internal_models.values()):
+            for W, b in linear_layers(net.model):
+                w_crc = zlib.crc32(np.ascontiguousarray(b).view(np.uint8), zlib.crc32(np.ascontiguousarray(W).view(np.uint8), w_crc))
+        key = (id(data_search), id(data_navigation), _addr(data_search), tuple(data_search.shape),
+               _crc(data_search.iloc[rows].to_numpy(dtype=np.float32)) if data_search.shape[0] else 0,
+               _crc(data_navigation.index.to_numpy()), dp.shape, _crc(dp), w_crc,
+               tuple(tuple(int(v) for v in p) for p in self.internal_models), tuple(n_categories), device, metric)
         if self._engine is not None and key == self._engine_key:
             return self._engine
         self.close()

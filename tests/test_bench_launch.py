@@ -1,0 +1,31 @@
+"""`python bench.py --gpus N` must be a valid command on its own: with WORLD_SIZE unset the bench starts
+its N ranks as a child torchrun BEFORE touching the GPU, forwards rank 0's JSON line and the children's exit code.
+No GPU here: LMI_BENCH_LAUNCH_CHECK=1 makes the ranks do the rendezvous + one gloo all-reduce only.  The whole
+bench through the same path, on the card, is `tests/test_gpu_sharded.py::test_bench_self_launch_two_ranks_gloo`."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(gpus, extra_env=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update({"LMI_BENCH_LAUNCH_CHECK": "1", "OMP_NUM_THREADS": "1"}, **(extra_env or {}))
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "1", "--warmup", "0"],
+                          env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_gpus2_self_launches_and_forwards_json():
+    r = _run(2)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    assert json.loads(lines[0]) == {"launch_check": True, "world": 2, "sum": 3}
+
+
+def test_bench_child_failure_is_the_exit_code():
+    r = _run(2, {"LMI_BENCH_LAUNCH_CHECK_FAIL_RANK": "1"})
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

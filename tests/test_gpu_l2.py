@@ -93,3 +93,48 @@ def test_l2_through_the_li_api(oracle):
     do_ip, no_ip, _ = oracle.search(layers, Qn, Xs * np.float32(1.7), Qs, dp, 3, 10, nthreads=4)
     np.testing.assert_array_equal(n_ip, no_ip)
     li.close()
+
+
+def test_l2_index_survives_save_and_load(oracle, tmp_path):
+    """the metric is part of the on-disk index -- an L2 index reloads as an L2 index (meta.json "metric"),
+    and a version-1 directory (no such key) still loads as inner product."""
+    import json
+
+    import pandas as pd
+
+    from helpers import inputs_for, layers_from, load_golden
+    from learnedmetricindex_amd.index_io import load_index, save_index
+    from learnedmetricindex_amd.li.LearnedIndex import LearnedIndex
+    from learnedmetricindex_amd.li.model import network_from_layers
+
+    g = load_golden("G1")
+    Xn, Qn, Xs, Qs = inputs_for("G1", g)
+    layers = layers_from(g)
+    li = LearnedIndex(network_from_layers(layers), {}, [(i,) for i in range(12)])
+    X = Xs * np.float32(1.7)
+    df = pd.DataFrame(X)
+    df.index += 1
+    dp = g["data_prediction"].astype(np.int64)
+    d, n, _ = li.search(df, Qn, df, Qs, dp, [12], 3, 10, metric="l2")
+    save_index(str(tmp_path / "idx"), li, [12])
+    li.close()
+    meta = json.load(open(tmp_path / "idx" / "meta.json"))
+    assert meta["metric"] == "l2" and meta["version"] == 2
+    li2, ncat = load_index(str(tmp_path / "idx"))
+    assert li2._engine.metric == "l2" and ncat == [12]
+    d2, n2, _ = li2.search_resident(Qn, Qs, [12], 3, 10)
+    np.testing.assert_array_equal(n2, n)
+    np.testing.assert_array_equal(d2, d)
+    do, no, _ = oracle.search(layers, Qn, X, Qs, dp, 3, 10, nthreads=4, metric="l2")
+    np.testing.assert_array_equal(n2, no)
+    li2.close()
+    # a version-1 directory: no "metric" key -> inner product
+    del meta["metric"]
+    meta["version"] = 1
+    json.dump(meta, open(tmp_path / "idx" / "meta.json", "w"))
+    li3, _ = load_index(str(tmp_path / "idx"))
+    assert li3._engine.metric == "ip"
+    d3, n3, _ = li3.search_resident(Qn, Qs, [12], 3, 10)
+    do_ip, no_ip, _ = oracle.search(layers, Qn, X, Qs, dp, 3, 10, nthreads=4)
+    np.testing.assert_array_equal(n3, no_ip)
+    li3.close()

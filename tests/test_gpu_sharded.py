@@ -116,3 +116,28 @@ def test_library_rccl_exchange_world1(oracle):
     np.testing.assert_array_equal(d.cpu().numpy().astype(np.float64), do)
     _capi.Index.comm_destroy(comm)
     idx.close()
+
+
+def test_bench_self_launch_two_ranks_gloo():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset: the bench starts its ranks itself (child torchrun, before any
+    GPU call in the parent) and runs the whole N > 1 path -- owned-only ingest, both collective layouts, the merge --
+    here with the two ranks sharing the one card and the collectives over gloo (LMI_BENCH_BACKEND=gloo)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["LMI_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--n", "300000", "--nq", "2000",
+                        "--steps", "3", "--warmup", "1", "--epochs", "40", "--train-rows", "50000"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["value"] > 0
+    assert j["sharded_alt_mode"]["value"] > 0 and len(j["per_rank"]) == 2
+    assert {p["rank"] for p in j["per_rank"]} == {0, 1}
+    assert j["recall_at_10"] is not None and j["recall_at_10"] > 0.9
