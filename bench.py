@@ -370,7 +370,9 @@ def launch_ranks(n: int, argv) -> int:
         s_.bind(("127.0.0.1", 0))
         port = s_.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           "--", os.path.abspath(__file__)] + list(argv)   # "--": the launcher's argparse would otherwise claim a bench flag
+                                                            # that is a prefix of one of its own (--n -> --nnodes, ...)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
     env.setdefault("OMP_NUM_THREADS", "4")

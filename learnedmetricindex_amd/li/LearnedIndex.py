@@ -51,6 +51,8 @@ def _feature_columns(df: pd.DataFrame) -> list:
 
 class LearnedIndex(Logger):
     _WORKSPACE_BYTES = 6 << 30  # per-call device workspace budget of one search chunk
+    _NAV_QUEUE_BYTES = 4 << 30  # multi-level walk: per-query priority queues hold one 8-byte entry per child of every node
+                                # (lmi_nav_order refuses 2^31 entries); larger batches are walked in query chunks
 
     def __init__(self, root_model: NeuralNetwork, internal_models: Dict[Tuple, NeuralNetwork],
                  bucket_paths: List[Tuple]):
@@ -64,6 +66,7 @@ class LearnedIndex(Logger):
         self._engine_key = None
         self._path_ids = None
         self._entry_paths = None
+        self._nav_cap = 0
 
     def __getstate__(self):  # picklable like the reference object (search.py:234-241)
         state = dict(self.__dict__)
@@ -79,6 +82,7 @@ class LearnedIndex(Logger):
         self.__dict__.setdefault("_engine_key", None)
         self.__dict__.setdefault("_path_ids", None)
         self.__dict__.setdefault("_entry_paths", None)
+        self.__dict__.setdefault("_nav_cap", 0)
 
     # ------------------------------------------------------------------------------------------
     def invalidate(self) -> None:
@@ -215,6 +219,8 @@ class LearnedIndex(Logger):
         # The prefilter's per-call workspace is ~8.7 KiB per (query, bucket) slot (candidate buffers): large
         # batches x many buckets are answered in query chunks that keep it under _WORKSPACE_BYTES.
         step = max(1, min(nq, self._WORKSPACE_BYTES // (8900 * max(1, n_buckets))))
+        if len(n_categories) > 1:
+            step = min(step, self._nav_chunk())
         parts_d, parts_n = [], []
         for lo in range(0, nq, step):
             hi = min(nq, lo + step)
@@ -269,6 +275,12 @@ class LearnedIndex(Logger):
             offset.append(len(child_model))
         eng.nav_set_tree(offset, child_model, child_bucket)
         self._entry_paths = np.asarray(entry_path, dtype=np.int32).reshape(-1, n_levels)
+        self._nav_cap = len(child_model)
+
+    def _nav_chunk(self) -> int:
+        """Queries per lmi_nav_order call: queue memory under _NAV_QUEUE_BYTES and under the call's 2^31-entry limit."""
+        cap = max(1, getattr(self, "_nav_cap", 0) or len(self._entry_paths))
+        return max(1, min(self._NAV_QUEUE_BYTES // (8 * cap), ((1 << 31) - 1) // cap))
 
     @log_runtime(INFO, "Precomputed bucket order time: {}")
     def _precompute_bucket_order(self, queries_navigation: npt.NDArray[np.float32], n_buckets: int,
@@ -286,7 +298,10 @@ class LearnedIndex(Logger):
             bucket_order[:, :, 0] = eng.mlp_topk(qn, n_buckets)
             return bucket_order, float(eng.timings()[_capi.T_INFERENCE]) * 1e-3
         assert self._engine is not None, "multi-level navigation needs the resident index: call prepare() first"
-        _, entries = self._engine.nav_order(qn, n_buckets)
-        found = entries >= 0
-        bucket_order[found] = self._entry_paths[entries[found]]
-        return bucket_order, float(self._engine.timings()[_capi.T_INFERENCE]) * 1e-3
+        seconds, step = 0.0, self._nav_chunk()
+        for lo in range(0, n_queries, step):
+            _, entries = self._engine.nav_order(qn[lo: lo + step], n_buckets)
+            seconds += float(self._engine.timings()[_capi.T_INFERENCE]) * 1e-3
+            found = entries >= 0
+            bucket_order[lo: lo + step][found] = self._entry_paths[entries[found]]
+        return bucket_order, seconds

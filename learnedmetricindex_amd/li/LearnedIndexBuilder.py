@@ -1,14 +1,17 @@
-"""Index construction (reference: li/LearnedIndexBuilder.py:21-352) -- offline, out of the query
-hot path, kept API-compatible: `LearnedIndexBuilder(data, config).build()`
-returns `(LearnedIndex, data_prediction int64[N, n_levels], n_buckets, build_t, cluster_t)`.
+"""Index construction -- offline, out of the query hot path; API as the reference's
+(li/LearnedIndexBuilder.py:21-107): `LearnedIndexBuilder(data, config).build()` returns
+`(LearnedIndex, data_prediction int64[N, n_levels], n_buckets, build_t, cluster_t)`.
 
-Per node: k-means labels -> MLP trained until it predicts every category (the reference's rule,
-:176-194) -> objects are placed by argmax MLP(x) (NOT by their k-means label, :76, :270-274).  The
-training loop is torch autograd on the GPU; object placement (`NeuralNetwork.predict` over all N) runs
-through the HIP MLP kernel."""
+Structure (this build's own): the tree is grown level by level from a work-list of `_Node`s.  A node is a path
+prefix plus the positions of the objects placed under it; fitting a node = cluster its vectors, train its MLP in
+rounds until every category is predicted for at least one object (the reference's stopping rule, :176-194), then
+place the node's objects by argmax MLP(x) -- NOT by their k-means label (:76, :270-274).  Placement of level l
+produces the work-list of level l + 1.  Training is torch autograd on the GPU (mini-batches drawn without DataFrame
+label games: positions, not labels, index the tensors); placement runs through the HIP MLP kernel
+(`NeuralNetwork.predict`).  What callers of the reference see is unchanged: `root_model`, `internal_models`
+(path padded with EMPTY_VALUE -> model, in breadth-first lexicographic order), `bucket_paths`."""
 import time
-from itertools import product, takewhile
-from logging import DEBUG
+from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -20,11 +23,35 @@ import torch.utils.data
 from .BuildConfiguration import BuildConfiguration
 from .LearnedIndex import LearnedIndex
 from .Logger import Logger
-from .model import LIDataset, ModelParameters, NeuralNetwork, data_X_to_torch
+from .model import ModelParameters, NeuralNetwork
 from .PriorityQueue import EMPTY_VALUE
-from .utils import filter_path_idxs, log_runtime
 
-MAX_TRAINING_ROUNDS = 1_000  # LearnedIndexBuilder.py:191
+TRAINING_ROUND_LIMIT = 1_000   # rounds of `epochs` epochs before a node is declared not to converge (:186-194)
+MINI_BATCH = 256               # the reference's DataLoader batch size (:170-174)
+
+
+@dataclass
+class _Node:
+    prefix: Tuple[int, ...]       # categories chosen at levels 0 .. level-1; () is the root
+    rows: np.ndarray              # positions (0-based) of the objects under this node
+
+    @property
+    def level(self) -> int:
+        return len(self.prefix)
+
+
+class _PositionBatches(torch.utils.data.Dataset):
+    """(x, y) pairs of one node, indexed by position; the loader below shuffles positions each epoch."""
+
+    def __init__(self, x: np.ndarray, y: np.ndarray):
+        self.x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+        self.y = torch.from_numpy(np.ascontiguousarray(y)).long()
+
+    def __len__(self) -> int:
+        return self.x.shape[0]
+
+    def __getitem__(self, i):
+        return self.x[i], self.y[i]
 
 
 class LearnedIndexBuilder(Logger):
@@ -37,96 +64,77 @@ class LearnedIndexBuilder(Logger):
 
     # ------------------------------------------------------------------------------------------
     def build(self) -> Tuple[LearnedIndex, npt.NDArray[np.int64], int, float, float]:
-        started = time.time()
-        n_levels = self.config.n_levels
-        data_prediction = np.full((self.data.shape[0], n_levels), EMPTY_VALUE, dtype=np.int64)
-        self.logger.debug("Training the root model.")
-        self.root_model, cluster_t = self._train_model(self.data, self.config.level_configurations[0])
-        data_prediction[:, 0] = self.root_model.predict(data_X_to_torch(self.data))
-        if n_levels == 1:
-            # one bucket per predicted category (LearnedIndexBuilder.py:78-88)
-            self.bucket_paths = [(i,) for i in range(len(np.unique(data_prediction[:, 0])))]
+        t0 = time.time()
+        cfg = self.config
+        depth = cfg.n_levels
+        vectors = np.ascontiguousarray(self.data.to_numpy(dtype=np.float32))
+        placement = np.full((vectors.shape[0], depth), EMPTY_VALUE, dtype=np.int64)
+        self.internal_models, self.bucket_paths = {}, []
+        clustering_seconds = 0.0
+        frontier = [_Node((), np.arange(vectors.shape[0]))]
+        for level in range(depth):
+            params = cfg.level_configurations[level]
+            self.logger.debug("level %d: %d node(s) to fit", level, len(frontier))
+            next_frontier: List[_Node] = []
+            for node in frontier:
+                assert node.rows.size, f"node {self._dotted(node.prefix)} received no objects: nothing to train on"
+                net, chosen, secs = self._fit(vectors[node.rows], params)
+                clustering_seconds += secs
+                placement[node.rows, level] = chosen
+                if level == 0:
+                    self.root_model = net
+                else:
+                    self.internal_models[self._padded(node.prefix, depth)] = net
+                if level == depth - 1:
+                    # a bucket per category the node's objects were actually placed in (:78-88, :276-278)
+                    n_used = len(np.unique(chosen))
+                    self.bucket_paths.extend(node.prefix + (c,) for c in range(n_used))
+                else:
+                    # every category of the configured fan-out becomes a node of the next level (:330-352)
+                    next_frontier.extend(_Node(node.prefix + (c,), node.rows[chosen == c])
+                                         for c in range(cfg.n_categories[level]))
+            frontier = next_frontier
+        index = LearnedIndex(self.root_model, self.internal_models, self.bucket_paths)
+        return index, placement, len(self.bucket_paths), time.time() - t0, clustering_seconds
+
+    # ------------------------------------------------------------------------------------------
+    def _fit(self, x: np.ndarray, params: ModelParameters) -> Tuple[NeuralNetwork, np.ndarray, float]:
+        """One node: (trained classifier, argmax category of each of its objects, clustering seconds)."""
+        cluster, model_type, epochs, lr, fan_out = params
+        t = time.time()
+        if x.shape[0] < 2:
+            labels = np.zeros(x.shape[0], dtype=np.int64)
         else:
-            self.logger.debug(f"Training {self.config.n_categories[:-1]} internal models.")
-            cluster_t += self._train_internal_models(self.data, data_prediction, self.config)
-        return self._create_index(), data_prediction, len(self.bucket_paths), time.time() - started, cluster_t
+            # a node with fewer objects than categories asks for fewer clusters (:282-304)
+            want = fan_out if x.shape[0] >= fan_out else max(x.shape[0] // 5, 2)
+            _, labels = cluster(x, want, None)
+        secs = time.time() - t
+        n_classes = len(np.unique(labels))
+        if n_classes != fan_out:
+            self.logger.debug("clustering produced %d of %d categories; training on %d", n_classes, fan_out, n_classes)
+        batches = torch.utils.data.DataLoader(_PositionBatches(x, labels), batch_size=MINI_BATCH, shuffle=True)
+        net = NeuralNetwork(input_dim=x.shape[1], output_dim=n_classes, lr=lr, model_type=model_type)
+        for round_no in range(1, TRAINING_ROUND_LIMIT + 1):
+            net.train_batch(batches, epochs=epochs, logger=self.logger)
+            chosen = net.predict(x)
+            if len(np.unique(chosen)) == n_classes:
+                if round_no > 1:
+                    self.logger.debug("needed %d epochs (%d rounds of %d)", round_no * epochs, round_no, epochs)
+                return net, chosen, secs
+        raise RuntimeError(f"a node's model still leaves categories empty after {TRAINING_ROUND_LIMIT} training rounds")
 
-    def _create_index(self) -> LearnedIndex:
-        assert self.root_model is not None, "The root model is not trained."
-        return LearnedIndex(self.root_model, self.internal_models, self.bucket_paths)
+    # ---- path helpers ---------------------------------------------------------------------------
+    @staticmethod
+    def _padded(prefix: Tuple[int, ...], depth: int) -> Tuple[int, ...]:
+        return tuple(prefix) + (EMPTY_VALUE,) * (depth - len(prefix))
 
-    # ------------------------------------------------------------------------------------------
-    @log_runtime(DEBUG, "Trained the model in: {}")
-    def _train_model(self, data: pd.DataFrame, model_parameters: ModelParameters) -> Tuple[NeuralNetwork, float]:
-        """One node: cluster, then train in rounds of `epochs` until every category is predicted for
-        at least one object; RuntimeError after 1000 rounds (LearnedIndexBuilder.py:120-201)."""
-        clustering_algorithm, model_type, epochs, lr, n_categories = model_parameters
-        _, labels, cluster_t = self._cluster(data, clustering_algorithm, n_categories)
-        found = len(np.unique(labels))
-        if found != n_categories:
-            self.logger.debug("Clustering algorithm did not return %d clusters, got %d.", n_categories, found)
-            n_categories = found
-        loader = torch.utils.data.DataLoader(
-            dataset=LIDataset(data, labels), batch_size=256,
-            sampler=torch.utils.data.SubsetRandomSampler(data.index.values.tolist()))  # 1-based labels
-        everything = data_X_to_torch(data)
-        model = NeuralNetwork(input_dim=data.shape[1], output_dim=n_categories, lr=lr, model_type=model_type)
-        for rounds in range(1, MAX_TRAINING_ROUNDS + 2):
-            if rounds > MAX_TRAINING_ROUNDS:
-                raise RuntimeError("The model did not converge after 1000 iterations.")
-            model.train_batch(loader, epochs=epochs, logger=self.logger)
-            if len(np.unique(model.predict(everything))) == n_categories:
-                break
-        if rounds > 1:
-            self.logger.debug(f"Trained for {rounds * epochs} epochs instead of {epochs}.")
-        return model, cluster_t
+    @staticmethod
+    def _dotted(path: Tuple[int, ...]) -> str:
+        """(1, 2, -1, -1) -> "1.2" (the reference's serialised form, :306-316)."""
+        return ".".join(str(v) for v in path if v != EMPTY_VALUE) or "<root>"
 
-    def _train_internal_models(self, data: pd.DataFrame, data_prediction: npt.NDArray[np.int64],
-                               config: BuildConfiguration) -> float:
-        """Levels 1..n-1, one model per internal path; fills data_prediction in place and appends
-        the bucket paths of the last level (LearnedIndexBuilder.py:203-280)."""
-        assert self.root_model is not None, "The root model is not trained, call `_train_root_model` first."
-        cluster_t = 0.0
-        for level in range(1, config.n_levels):
-            self.logger.debug(f"Training level {level}.")
-            for path in self._generate_internal_node_paths(level, config.n_levels, config.n_categories):
-                rows = filter_path_idxs(data_prediction, path)
-                assert rows.shape[0] != 0, "There are no data points associated with the given path."
-                subset = data.loc[rows + 1]  # DataFrame labels are 1-based
-                labels_backup = subset.index.values
-                # the node's objects are re-labelled 1..m for the sampler, then restored
-                model, t = self._train_model(subset.set_index(pd.Index(range(1, subset.shape[0] + 1))),
-                                             config.level_configurations[level])
-                self.internal_models[path] = model
-                cluster_t += t
-                predictions = model.predict(data_X_to_torch(subset))
-                data_prediction[labels_backup - 1, level] = predictions
-                if level == config.n_levels - 1:
-                    self.bucket_paths.extend(path[:-1] + (i,) for i in range(len(np.unique(predictions))))
-        return cluster_t
-
-    def _cluster(self, data: pd.DataFrame, clustering_algorithm, n_clusters: int):
-        """(fitted object, labels, seconds); tiny nodes get fewer clusters (LearnedIndexBuilder.py:282-304)."""
-        s = time.time()
-        if data.shape[0] < 2:
-            return None, np.array([0] * data.shape[0]), time.time() - s
-        if data.shape[0] < n_clusters:
-            n_clusters = max(data.shape[0] // 5, 2)
-        fitted, labels = clustering_algorithm(np.array(data), n_clusters, None)
-        return fitted, labels, time.time() - s
-
-    # ------------------------------------------------------------------------------------------
-    def _serialize_path(self, path: Tuple) -> str:
-        """(1, 2, -1, -1) -> "1.2" (LearnedIndexBuilder.py:306-316)."""
-        return ".".join(str(v) for v in takewhile(lambda v: v != EMPTY_VALUE, path))
-
-    def _deserialize_path(self, path: str, n_levels: int) -> Tuple:
-        """"1.2", 4 -> (1, 2, -1, -1) (LearnedIndexBuilder.py:318-328)."""
-        levels = [int(v) for v in path.split(".")]
-        return tuple(levels + [EMPTY_VALUE] * (n_levels - len(levels)))
-
-    def _generate_internal_node_paths(self, level: int, n_levels: int, n_categories: List[int]) -> List[Tuple]:
-        """All paths of internal nodes at `level`, padded with EMPTY_VALUE (LearnedIndexBuilder.py:330-352)."""
-        heads = product(*(range(n_categories[lvl]) for lvl in range(level)))
-        pad = (EMPTY_VALUE,) * (n_levels - level)
-        return [h + pad for h in heads]
+    @staticmethod
+    def _from_dotted(text: str, depth: int) -> Tuple[int, ...]:
+        """"1.2", 4 -> (1, 2, -1, -1) (:318-328)."""
+        head = tuple(int(v) for v in text.split("."))
+        return head + (EMPTY_VALUE,) * (depth - len(head))

@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _run(gpus, extra_env=None):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update({"LMI_BENCH_LAUNCH_CHECK": "1", "OMP_NUM_THREADS": "1"}, **(extra_env or {}))
-    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "1", "--warmup", "0"],
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "1", "--warmup", "0",
+                           "--n", "1000", "--nq", "10", "--nb", "2"],   # --n / --nb: prefixes of torchrun's own options
                           env=env, capture_output=True, text=True, timeout=300)
 
 
