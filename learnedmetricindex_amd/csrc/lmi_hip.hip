@@ -3,6 +3,7 @@
 // weights and the per-call workspaces; enqueues the kernels of lmi_kernels.h on one HIP stream.
 #include "lmi_kernels.h"
 #include "lmi_prefilter.h"
+#include "lmi_pass2.h"
 #include "lmi_mlp_fused.h"
 #include "lmi_rescore.h"
 
@@ -143,6 +144,8 @@ struct lmi_index {
     bool rescore_streamed = true;  // lmi_rescore.h (LMI_RESCORE_SIMPLE=1 in the environment: select_rescore_kernel)
     int last_nslots = 0, last_nb = 0;
     bool last_fast = false;
+    bool pf_v2 = true;            // LMI_PF_V1=1: the round-2 prefilter kernels (lmi_prefilter.h) instead of lmi_pass2.h (A/B)
+    bool pf_qbound = true;        // LMI_PF_QBOUND=0: per-bucket bounds only (query_bound_kernel off)
     bool debug_emit_all = false;  // lmi_debug_emit_all
 
     // ---- per-call workspaces ----
@@ -211,6 +214,8 @@ extern "C" LMI_API int lmi_create(int device, lmi_index** out) {
     }
     if (const char* e = getenv("LMI_RESCORE_SIMPLE")) h->rescore_streamed = !(e[0] && e[0] != '0');
     if (const char* e = getenv("LMI_PF_NO_REDO")) h->pf_redo = !(e[0] && e[0] != '0');
+    if (const char* e = getenv("LMI_PF_V1")) h->pf_v2 = !(e[0] && e[0] != '0');
+    if (const char* e = getenv("LMI_PF_QBOUND")) h->pf_qbound = e[0] && e[0] != '0';
     // per handle = per device (a process may hold handles on several devices; the attribute is per device)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -951,7 +956,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     CHK(h->part_base.reserve((L + 1) * 8));
     CHK(h->stats.reserve(32));
     CHK(h->head.reserve(128));
-    const size_t grp_ints = (size_t)NGRP * L + (size_t)NGRP * (L + 1) + 2 * NGRP + L + (L + 1);
+    const size_t grp_ints = (size_t)NGRP * L + 2 * (size_t)NGRP * (L + 1) + 3 * NGRP + L + (L + 1);
     CHK(h->grp.reserve(grp_ints * 4));
     CHK(h->slot_local.reserve((size_t)nslots * 4));
     CHK(h->slot_col.reserve((size_t)nslots * 4));
@@ -977,7 +982,11 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     R.grp_total = R.grp_n + NGRP;
     R.order_tmp = R.grp_total + NGRP;
     R.qt_base = R.order_tmp + L;
-    R.tile_cb = (h->prefilter && h->have16) ? 4 * PF_NG : 4;
+    R.grp_base1 = R.qt_base + (L + 1);
+    R.grp_total1 = R.grp_base1 + (size_t)NGRP * (L + 1);
+    const bool v2 = (h->prefilter && h->have16) && h->pf_v2;
+    R.tile_cb = v2 ? P2_MAXCB : (h->prefilter && h->have16) ? 4 * PF_NG : 4;
+    R.sample_items = v2 ? 1 : 0;
 
     const size_t ncols = (size_t)ncb_bound * 32;
     int pf_parts = 4;
@@ -1006,8 +1015,9 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         for (int b = 0; b < L; ++b) { owned_rows += h->h_nb_rows[b]; owned_buckets += h->h_nb_rows[b] > 0; }
         const double pairs_est = (double)nslots * (double)owned_rows / (double)std::max<long long>(1, h->N) / (32.0 * 4 * PF_NG) + (double)owned_buckets;
         pf_parts = pairs_est * 4 >= 4.0 * h->num_cus ? 4 : pairs_est * 8 >= 4.0 * h->num_cus ? 8 : PF_PARTS_MAX;
-        CHK(h->pf_bound.reserve(ncols * pf_parts * 4 * PF_LK * 4 + 4096));  // + room for the developer builds' phase stamps
-        fill(h->pf_bound.p, (long long)(ncols * pf_parts * 4 * PF_LK), 0xFF800000u /* -inf */);
+        const size_t bound_words = v2 ? ncols * P2_NSL * 16 : ncols * pf_parts * 4 * PF_LK;
+        CHK(h->pf_bound.reserve(bound_words * 4 + 4096));  // + room for the developer builds' phase stamps
+        fill(h->pf_bound.p, (long long)bound_words, 0xFF800000u /* -inf */);
         fill(h->cand_cnt.p, (long long)ncols, 0u);
         fill(h->stats.as<long long>() + 2, 4, 0u);
         CHK(h->redo.reserve((size_t)(1 + L) * 4 + ncols));
@@ -1023,7 +1033,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     // the work queues (one 1 024-thread block, ~20 us) are only read by the scan kernels: built on the side stream while
     // this one packs the queries
     CHK(side_fork(h));
-    route_group_kernel<<<1, 1024, (size_t)L * 20, h->side>>>(L, R);
+    route_group_kernel<<<1, 1024, (size_t)L * 24, h->side>>>(L, R);
     HIPCHK(hipGetLastError());
     route_fill_kernel<<<cdiv(nslots, 256), 256, 0, h->stream>>>(d_order, h->slot_local.as<int>(), nslots, nb,
                                                                R.cb_start, h->colmap.as<int>(), h->slot_col.as<int>());
@@ -1092,6 +1102,9 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         F.grp_total = R.grp_total;
         F.qt_base = R.qt_base;
         F.by_work = R.order_tmp;
+        F.grp_base1 = R.grp_base1;
+        F.grp_total1 = R.grp_total1;
+        F.ncols = (long long)ncols;
         F.head = S.head;
         F.parts = pf_parts;
         F.bound = h->pf_bound.as<float>();
@@ -1101,18 +1114,29 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         F.cand_row = h->cand_row.as<unsigned>();
         F.cand_s = h->cand_s.as<float>();
         F.redo_count = nullptr; F.redo_bucket = nullptr; F.redo_col = nullptr;
-        h->stamps_off = (ncols * pf_parts * 4 * PF_LK * 4 + 255) / 256 * 256;
+        h->stamps_off = ((v2 ? ncols * P2_NSL * 16 : ncols * pf_parts * 4 * PF_LK) * 4 + 255) / 256 * 256;
         F.stamps = reinterpret_cast<unsigned long long*>(static_cast<char*>(h->pf_bound.p) + h->stamps_off);
-#if defined(LMI_PF_STAMPS)
+#if defined(LMI_PF_STAMPS) || defined(LMI_P2_STAMPS)
         HIPCHK(hipMemsetAsync(F.stamps, 0, 2 * 8 * 12 * 8, h->stream));
 #endif
         constexpr int PF_BLOCKS_PER_CU = PF_NG == 1 ? 2 : 1;
+        if (v2) {
+            pass2_kernel<true><<<h->num_cus, 64 * P2_WAVES, 0, h->stream>>>(F);   // pass 1: slot maxima of the sampled tiles
+            HIPCHK(hipGetLastError());
+            bound_merge2_kernel<<<cdiv((long long)ncols, 256), 256, 0, h->stream>>>(F.bound, (long long)ncols, F.bound1);
+            HIPCHK(hipGetLastError());
+            if (h->pf_qbound && nb > 1 && kout <= KPB) {   // the caller keeps the k <= 10 best over all ranks: one bound per query
+                query_bound_kernel<<<cdiv(nq, 256), 256, 0, h->stream>>>(h->slot_col.as<int>(), nq, nb, F.eps2, F.bound1);
+                HIPCHK(hipGetLastError());
+            }
+        } else {
         prefilter_kernel<true, PF_NG><<<h->num_cus * PF_BLOCKS_PER_CU, 256 * PF_NG, 0, h->stream>>>(F);   // pass 1: bounds from a sample
         HIPCHK(hipGetLastError());
 if (pf_parts <= 4) bound_merge_kernel<16><<<cdiv((long long)ncols * 16, 256), 256, 0, h->stream>>>(F.bound, (long long)ncols, F.bound1);
         else if (pf_parts <= 8) bound_merge_kernel<32><<<cdiv((long long)ncols * 32, 256), 256, 0, h->stream>>>(F.bound, (long long)ncols, F.bound1);
         else bound_merge_kernel<64><<<cdiv((long long)ncols * 64, 256), 256, 0, h->stream>>>(F.bound, (long long)ncols, F.bound1);
         HIPCHK(hipGetLastError());
+        }
         if (h->debug_emit_all) {  // test hook: bound = -inf, every row of the bucket is a candidate
             FillRanges D;
             D.count = 1; D.p[0] = reinterpret_cast<unsigned*>(F.bound1); D.n[0] = (long long)ncols; D.v[0] = 0xFF800000u;
@@ -1123,7 +1147,8 @@ if (pf_parts <= 4) bound_merge_kernel<16><<<cdiv((long long)ncols * 16, 256), 25
 
         // pass 2: candidates.  The query-resident form (opt-in: measured slower) needs a col-block's
         // fragments to fit a wave's registers (d <= 768)
-        prefilter_kernel<false, PF_NG><<<h->num_cus * PF_BLOCKS_PER_CU, 256 * PF_NG, 0, h->stream>>>(F);
+        if (v2) pass2_kernel<false><<<h->num_cus, 64 * P2_WAVES, 0, h->stream>>>(F);
+        else prefilter_kernel<false, PF_NG><<<h->num_cus * PF_BLOCKS_PER_CU, 256 * PF_NG, 0, h->stream>>>(F);
         HIPCHK(hipGetLastError());
         CHK(record(h, 6));
         if (h->pf_redo && !h->debug_emit_all) {
@@ -1138,7 +1163,8 @@ if (pf_parts <= 4) bound_merge_kernel<16><<<cdiv((long long)ncols * 16, 256), 25
             PrefilterParams F2 = F;
             F2.head = F.head + 16;
             F2.redo_count = rc; F2.redo_bucket = rb; F2.redo_col = rcol;
-            prefilter_kernel<false, PF_NG><<<h->num_cus * PF_BLOCKS_PER_CU, 256 * PF_NG, 0, h->stream>>>(F2);
+            if (v2) pass2_kernel<false><<<h->num_cus, 64 * P2_WAVES, 0, h->stream>>>(F2);
+            else prefilter_kernel<false, PF_NG><<<h->num_cus * PF_BLOCKS_PER_CU, 256 * PF_NG, 0, h->stream>>>(F2);
             HIPCHK(hipGetLastError());
         }
         RescoreParams Q;

@@ -309,8 +309,31 @@ struct RouteArrays {
     int* grp_total;       // [NGRP]      items in the group
     int* order_tmp;       // [L] buckets sorted by work, heaviest first
     int* qt_base;         // [L+1] prefix of the query-tile counts of order_tmp[0..] (prefilter pass-1 items)
-    int tile_cb;          // col-blocks per query tile: 4 (exact scan, prefilter NG 1) or 8 (prefilter NG 2)
+    int* grp_base1;       // [NGRP][L+1] the same prefix for the pass-1 items (query tiles x sampled tiles) of lmi_pass2.h
+    int* grp_total1;      // [NGRP]
+    int tile_cb;          // col-blocks per query tile: 4 (exact scan), 12 (prefilter: lmi_pass2.h), 8 (the round-2 prefilter kernel)
+    int sample_items;     // 1: qt_base counts pass-1 items of lmi_pass2.h = query tiles x SAMPLED 256-row tiles of the bucket
 };
+
+// ---- prefilter pass 1: which tiles of a bucket are sampled (shared by the routing kernels and lmi_prefilter.h / lmi_pass2.h) ----
+#ifndef LMI_PF_SAMPLE_ROWS
+#define LMI_PF_SAMPLE_ROWS 2000  // a bucket is sampled at stride s only if it has >= this many rows per unit of s (1300..3500: within 1 %)
+#endif
+#ifndef LMI_PF_SAMPLE
+#define LMI_PF_SAMPLE 16
+#endif
+constexpr int PF_SAMPLE = LMI_PF_SAMPLE;  // pass 1 looks at every PF_SAMPLE-th tile of a large bucket ...
+// ... and at every 8th, 4th, 2nd or every tile of buckets below LMI_PF_SAMPLE_ROWS x the stride
+__device__ __forceinline__ int sample_stride(int n_b) {
+    int s = PF_SAMPLE;
+    while (s > 1 && n_b < LMI_PF_SAMPLE_ROWS * s) s >>= 1;
+    return s;
+}
+__device__ __forceinline__ int sample_tiles256(int n_b) {  // sampled 256-row tiles of a bucket
+    const int nt = (((n_b + 31) >> 5) + 7) / 8;
+    const int s = sample_stride(n_b);
+    return (nt + s - 1) / s;
+}
 
 // query tiles of a bucket with m routed queries: its col-blocks over tiles of tile_cb (tile_cb 4: ceil(m / 128))
 __device__ __forceinline__ int query_tiles(int m, int tile_cb) { return (((m + 31) >> 5) + tile_cb - 1) / tile_cb; }
@@ -399,12 +422,14 @@ __global__ __launch_bounds__(1024) void route_group_kernel(int L, RouteArrays R)
     int* m_s = reinterpret_cast<int*>(work_s + L);
     int* items_s = m_s + L;
     int* order_s = items_s + L;
+    int* items1_s = order_s + L;
     const int t = threadIdx.x;
     for (int b = t; b < L; b += 1024) {
         const int m = R.m[b];
         m_s[b] = m;
         work_s[b] = (long long)m * R.nb_rows[b];
         items_s[b] = query_tiles(m, R.tile_cb) * R.nch[b];
+        items1_s[b] = m > 0 ? query_tiles(m, R.tile_cb) * sample_tiles256(R.nb_rows[b]) : 0;
     }
     __syncthreads();
     // rank of every bucket by (work desc, id asc); work = queries x rows is a fine proxy
@@ -422,7 +447,10 @@ __global__ __launch_bounds__(1024) void route_group_kernel(int L, RouteArrays R)
     // prefix (a serial scan by one thread was the kernel's critical path)
     for (int i = t; i <= L; i += 1024) {
         int q = 0;
-        for (int j = 0; j < i; ++j) q += query_tiles(m_s[order_s[j]], R.tile_cb);
+        for (int j = 0; j < i; ++j) {
+            const int bj = order_s[j];
+            q += query_tiles(m_s[bj], R.tile_cb) * (R.sample_items ? sample_tiles256(R.nb_rows[bj]) : 1);
+        }
         R.qt_base[i] = q;
         if (i < L) R.order_tmp[i] = order_s[i];
     }
@@ -431,9 +459,9 @@ __global__ __launch_bounds__(1024) void route_group_kernel(int L, RouteArrays R)
     // over its <= L/8 earlier members.  (Exact LPT is serial: 54-73 us at L = 120 whichever way it was
     // written -- scratch arrays, a wave butterfly, select chains; the snake's queue loads differ by a few
     // per cent and draining queues steal anyway.)
-    __shared__ int active_s, total_s[NGRP];
+    __shared__ int active_s, total_s[NGRP], total1_s[NGRP];
     if (t == 0) active_s = 0;
-    if (t < NGRP) { total_s[t] = 0; R.grp_base[t * (L + 1)] = 0; }
+    if (t < NGRP) { total_s[t] = 0; total1_s[t] = 0; R.grp_base[t * (L + 1)] = 0; if (R.sample_items) R.grp_base1[t * (L + 1)] = 0; }
     __syncthreads();
     {
         int mine = 0;
@@ -446,11 +474,19 @@ __global__ __launch_bounds__(1024) void route_group_kernel(int L, RouteArrays R)
         const int b = order_s[i];
         const int r = i / NGRP, ph = i % NGRP;
         const int g = (r & 1) ? NGRP - 1 - ph : ph;
-        int prefix = 0;
-        for (int rr = 0; rr < r; ++rr) prefix += items_s[order_s[rr * NGRP + ((rr & 1) ? NGRP - 1 - g : g)]];
+        int prefix = 0, prefix1 = 0;
+        for (int rr = 0; rr < r; ++rr) {
+            const int ob = order_s[rr * NGRP + ((rr & 1) ? NGRP - 1 - g : g)];
+            prefix += items_s[ob];
+            prefix1 += items1_s[ob];
+        }
         R.grp_bucket[g * L + r] = b;
         R.grp_base[g * (L + 1) + r + 1] = prefix + items_s[b];
         atomicAdd(&total_s[g], items_s[b]);
+        if (R.sample_items) {
+            R.grp_base1[g * (L + 1) + r + 1] = prefix1 + items1_s[b];
+            atomicAdd(&total1_s[g], items1_s[b]);
+        }
     }
     __syncthreads();
     if (t < NGRP) {
@@ -458,6 +494,7 @@ __global__ __launch_bounds__(1024) void route_group_kernel(int L, RouteArrays R)
         const int ph = (rows & 1) ? NGRP - 1 - t : t;  // this queue's position in the partial last row
         R.grp_n[t] = rows + (ph < rem ? 1 : 0);
         R.grp_total[t] = total_s[t];
+        if (R.sample_items) R.grp_total1[t] = total1_s[t];
     }
 }
 

@@ -1,0 +1,628 @@
+// lmi_pass2.h -- the prefilter's scan kernel, round-3 form (gfx950): ONE query tile per bucket chunk.
+//
+// What changed against prefilter_kernel (lmi_prefilter.h, rounds 1-2) and why.  That kernel gave a wave 64 vectors x <= 128
+// queries; a bucket's ~345 routed queries = 11 col-blocks became TWO query tiles (6 + 5), so every vector stage was fetched
+// and staged twice, a stage carried 12 MFMAs per wave against fixed costs of one barrier + 4 LDS-DMA pieces + 10 fragment
+// reads, and the queries' fragments were re-staged for every 256 vectors: 51 GB went through L2 -> LDS per 10 000-query
+// batch for 15.4 GB of index (profiles/r02_pass2_stamps.txt: 26 % of the older wave group's time parked at the barrier,
+// stages under-filled; 0.42 of the HBM roofline).
+// Here a block tile is 256 vectors x <= 384 queries and a WAVE owns one 32-vector row-block x ALL (<= 12) col-blocks:
+//   * a bucket chunk is one tile (up to 384 queries): its vectors are fetched and staged once; the queries' fragments are
+//     re-staged per 256 vectors as before but for one tile instead of two: L2 -> LDS bytes per flop fall by 1.4 x;
+//   * every wave does the same work for any number of col-blocks (NCB MFMAs per k-group): no under-filled group, no
+//     duplicate pieces; a 32-deep stage carries 2 NCB MFMAs per wave (24 at 12 col-blocks) per barrier;
+//   * a wave reads only ITS row-block's vector fragments (1 read per k-group, staged by itself: no other wave depends on
+//     them) + the NCB query fragments: 13 ds_read_b128 per 12 MFMAs = 54 % of the LDS read bandwidth;
+//   * 192 accumulator registers + 2 A fragments + a ring of 4 B fragments: the thresholds live in LDS, not in registers.
+// The B-fragment reads run D = 3 fragments ahead of the MFMAs as ONE stream that continues across the stage barrier: the
+// last D MFMAs of a stage are issued after the next stage's barrier, interleaved with its first reads (a stage's first
+// fragment would otherwise be waited for by both waves of a SIMD at once, MFMA pipe idle).
+// Pass 1 (SAMPLE) = the same tile on sampled tiles only; one item per (bucket, query tile, sampled tile); per lane and
+// col-block the MAXIMUM of its 16 scores is all it keeps: the slot maxima of a column come from disjoint rows, so the 10th
+// largest of them is the 10th best of a subset of the bucket = a valid lower bound of That (lmi_prefilter.h, header).
+#pragma once
+#include <type_traits>
+
+#include "lmi_prefilter.h"
+
+namespace lmi {
+
+constexpr int P2_G = 2;                                                  // k16-groups per stage (32 k)
+constexpr int P2_MAXCB = 12;                                             // col-blocks per tile
+constexpr int P2_WAVES = 8;
+constexpr int P2_TILE_RB = P2_WAVES;                                     // row-blocks per tile (256 vectors)
+constexpr int P2_A_BYTES = P2_WAVES * P2_G * 1024;                       // 16 KiB: the stage's vector fragments
+constexpr int P2_SLOT_BYTES = P2_A_BYTES + P2_MAXCB * P2_G * 1024;       // 40 KiB per ring slot
+constexpr int P2_RING = 3;
+constexpr int P2_NSL = 16;   // pass 1: lists per column (sampled tile j -> list j % P2_NSL), each 16 slot maxima
+constexpr int P2_LIST = 64 + 1;
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));   // asm operands must be vector types, not HIP's uint2 / uint4 structs
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+__device__ __forceinline__ int p2_sample_tiles(int n_b) { return sample_tiles256(n_b); }
+static_assert(P2_TILE_RB == 8, "sample_tiles256 counts 256-row tiles");
+
+// In-kernel phase timing (developer builds, -DLMI_P2_STAMPS; tools/p2_stamps.py): shader-clock cycles per wave and phase,
+// summed into P.stamps as u64 [8 waves][12]: 0 landed-wait (vmcnt), 1 barrier, 2 stage (reads + MFMAs + DMA issue),
+// 3 epilogue, 4 item start, 5 item end, 7 = tiles.
+#ifdef LMI_P2_STAMPS
+#ifndef LMI_P2_STAMPS_SAMPLE
+#define LMI_P2_STAMPS_SAMPLE 0
+#endif
+#define P2_STAMP(PH) if (SAMPLE == (LMI_P2_STAMPS_SAMPLE != 0)) { const unsigned long long t_ = __builtin_readcyclecounter(); st_acc[PH] += t_ - st_last; st_last = t_; }
+#else
+#define P2_STAMP(PH)
+#endif
+// a stamp is s_memtime + s_waitcnt lgkmcnt(0): three per stage drain the fragment read-ahead and cost a third of the kernel's
+// time (measured); the default stamped build stamps once per tile phase, -DLMI_P2_STAMPS_FINE adds the per-stage ones
+#if defined(LMI_P2_STAMPS) && defined(LMI_P2_STAMPS_FINE)
+#define P2_STAMP_FINE(PH) P2_STAMP(PH)
+#else
+#define P2_STAMP_FINE(PH)
+#endif
+
+template <int NCB, bool SAMPLE>
+struct Tile2 {
+    static constexpr int G = P2_G;
+    static constexpr int Q = G * NCB;                       // B fragments = MFMAs per stage and wave
+    static constexpr int BR = 6;                            // B-fragment register ring: fragment q of the stage in ring slot s sits in
+                                                            // register (s Q + q) mod 6 -- 3 Q = 6 NCB is a multiple of 6, so the numbering
+                                                            // runs on through the three unrolled stages and closes at the loop's back edge
+    static constexpr int D = NCB < BR - 1 ? NCB : BR - 1;   // read-ahead (fragments); the last D MFMAs of a stage are deferred
+    // LDS-DMA is issued by the YOUNGER half of the block only (waves 4..7: "loaders").  The two waves of a SIMD run a stage one
+    // after the other (the matrix pipe goes to the older wave until it has issued all of its MFMAs: stamps, profiles/r03_*), so
+    // a piece issued by the older wave (~50 cycles each, in order with its MFMAs) stalls the pipe, while the younger wave issues
+    // the whole stage's pieces at the stage's start, in the shadow of its partner's MFMAs.  Loader lw = w - 4 stages
+    // row-blocks lw, lw + 4 and col-blocks lw, lw + 4, lw + 8 (past the tile: the last col-block again), both k-groups.
+    static constexpr int PBL = NCB <= 4 ? 2 : NCB <= 8 ? 4 : 6;
+    static constexpr int PW = 2 * G + PBL;                  // pieces per loader wave and stage (constant: the vmcnt literal)
+    static constexpr int QA = NCB > D + 1 ? NCB - D - 1 : 0;  // A fragment of k-group 1 is requested after MFMA QA
+    static_assert(G == 2, "written out for two k-groups per stage");
+
+    const PrefilterParams& P;
+    unsigned ring;       // LDS byte address of the ring
+    uint4* ring_p;       // the same as a pointer (DMA destinations)
+    uint2* sList;        // [8 waves][P2_LIST] candidate compaction lists (pass 2)
+    float* sThr;         // [P2_MAXCB * 32] emission thresholds of the tile's columns (pass 2)
+    uint4* sPend;        // [8 waves][64] (column, row, score) of the candidate whose position atomic is in flight (pass 2)
+    int lane, w;
+    unsigned lds_lane;   // ring + lane * 16
+    f32x16 acc[NCB];
+    half8 a[2];          // vector fragment of k-group 0 / 1
+    half8 b[BR];         // query-fragment ring
+    unsigned pend_pos;
+#ifdef LMI_P2_STAMPS
+    unsigned long long st_acc[12], st_last;
+#endif
+
+    static constexpr int breg(int slot, int q) { return (slot * Q + q) % BR; }
+    // LDS reads issued after B(q)'s and before MFMA q waits for it: the younger B fragments + k-group 1's A fragment
+    static constexpr int younger(int q) {
+#if defined(LMI_ABL_NOLDSB) || defined(LMI_ABL_NOLGKM) || defined(LMI_ABL_NOLDS)
+        return 15;   // timing-only ablations: never wait for a fragment
+#endif
+        int nb = (q + D - 1 < Q - 1 ? q + D - 1 : Q - 1) - q;
+        if (q >= QA + 1 && q <= QA + D - 1) nb += 1;
+        return nb;
+    }
+
+    template <int OFF>
+    static __device__ __forceinline__ void lds_rd(half8& r, unsigned addr) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+    }
+    template <int N>
+    static __device__ __forceinline__ void lgkm_wait(half8& x, half8& y) {
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(y) : "n"(N) : "memory");
+    }
+
+    template <int SLOT, int QI>
+    __device__ __forceinline__ void mfma_q() {
+        constexpr int g = QI / NCB, n = QI % NCB;
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[g], b[breg(SLOT, QI)], acc[n], 0, 0, 0);
+    }
+    // the tile's first k-group starts the accumulators at 0 (srcC = the inline constant: no clearing pass, no zero registers)
+    template <int SLOT, int QI>
+    __device__ __forceinline__ void mfma_q0() {
+        constexpr int n = QI % NCB;
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[breg(SLOT, QI)], zero, 0, 0, 0);
+    }
+    template <int SLOT, int QI>
+    __device__ __forceinline__ void read_b() {  // query fragment QI of the stage in ring slot SLOT
+        constexpr int g = QI / NCB, n = QI % NCB;
+#ifdef LMI_ABL_NOLDSB   // timing-only ablation: a quarter of the query-fragment reads (garbage results)
+        if constexpr (QI % 4 != 0) { asm volatile("" : "+v"(b[breg(SLOT, QI)])); return; }
+#endif
+#ifdef LMI_ABL_NOLDS    // timing-only ablation: no fragment reads at all
+        asm volatile("" : "+v"(b[breg(SLOT, QI)])); return;
+#endif
+        lds_rd<P2_A_BYTES + (n * G + g) * 1024>(b[breg(SLOT, QI)], lds_lane + SLOT * P2_SLOT_BYTES);
+    }
+    template <int SLOT, int GI>
+    __device__ __forceinline__ void read_a() {
+#ifdef LMI_ABL_NOLDS
+        asm volatile("" : "+v"(a[GI])); return;
+#endif
+        lds_rd<GI * 1024>(a[GI], lds_lane + SLOT * P2_SLOT_BYTES + (unsigned)w * (G * 1024));
+    }
+
+#ifndef LMI_P2_LOADER_OLD
+#define LMI_P2_LOADER_OLD 0   // 1 (A/B): the OLDER half (waves 0..3) issues the LDS-DMA instead
+#endif
+    __device__ __forceinline__ bool is_loader() const { return LMI_P2_LOADER_OLD ? w < 4 : w >= 4; }
+    struct Stream {        // wave-uniform source pointers of the NEXT stage to load (loaders)
+        const uint4* a0;   // row-block lw of the tile, k-group pair t
+        const uint4* a1;   // row-block lw + 4
+        const uint4* b0;   // col-block lw (clamped)
+        int d1, d2;        // offsets (uint4) of col-blocks lw + 4, lw + 8 (clamped to the tile's last) from b0
+    };
+    template <int DST>
+    __device__ __forceinline__ void dma_all(const Stream& S) {
+#ifdef LMI_ABL_NOLOAD
+        return;
+#endif
+        uint4* slot = ring_p + DST * (P2_SLOT_BYTES / 16);
+        const int lw = w & 3;
+        glds16o<0, LMI_PF_A_AUX>(reinterpret_cast<const float4*>(S.a0 + lane), reinterpret_cast<float4*>(slot + lw * (G * 64)));
+        glds16o<1024, LMI_PF_A_AUX>(reinterpret_cast<const float4*>(S.a0 + lane), reinterpret_cast<float4*>(slot + lw * (G * 64)));
+        glds16o<0, LMI_PF_A_AUX>(reinterpret_cast<const float4*>(S.a1 + lane), reinterpret_cast<float4*>(slot + (lw + 4) * (G * 64)));
+        glds16o<1024, LMI_PF_A_AUX>(reinterpret_cast<const float4*>(S.a1 + lane), reinterpret_cast<float4*>(slot + (lw + 4) * (G * 64)));
+        const int cb0 = lw < NCB ? lw : NCB - 1;
+        glds16o<0>(reinterpret_cast<const float4*>(S.b0 + lane), reinterpret_cast<float4*>(slot + P2_A_BYTES / 16 + cb0 * (G * 64)));
+        glds16o<1024>(reinterpret_cast<const float4*>(S.b0 + lane), reinterpret_cast<float4*>(slot + P2_A_BYTES / 16 + cb0 * (G * 64)));
+        if constexpr (PBL >= 4) {
+            const int cb1 = lw + 4 < NCB ? lw + 4 : NCB - 1;
+            glds16o<0>(reinterpret_cast<const float4*>(S.b0 + S.d1 + lane), reinterpret_cast<float4*>(slot + P2_A_BYTES / 16 + cb1 * (G * 64)));
+            glds16o<1024>(reinterpret_cast<const float4*>(S.b0 + S.d1 + lane), reinterpret_cast<float4*>(slot + P2_A_BYTES / 16 + cb1 * (G * 64)));
+        }
+        if constexpr (PBL >= 6) {
+            const int cb2 = lw + 8 < NCB ? lw + 8 : NCB - 1;
+            glds16o<0>(reinterpret_cast<const float4*>(S.b0 + S.d2 + lane), reinterpret_cast<float4*>(slot + P2_A_BYTES / 16 + cb2 * (G * 64)));
+            glds16o<1024>(reinterpret_cast<const float4*>(S.b0 + S.d2 + lane), reinterpret_cast<float4*>(slot + P2_A_BYTES / 16 + cb2 * (G * 64)));
+        }
+    }
+
+    // One stage: ring slot SLOT computes, the pieces of stage (+2) go to slot DST.  `pend`: the previous stage left its last
+    // D MFMAs (operands in a[1], b[]) to be issued here; `last`: this stage issues all of its own (tile end / dead stage next).
+    // (Tried and dropped, profiles/r03_pass2_experiments.txt: an LDS counter with split arrive / wait instead of s_barrier, so
+    // that the last arriver never stalls -- the polling waves' detection latency cost more than the barrier's round trip:
+    // K loop of a tile 43.9 k -> 55.4 k cycles.)
+    template <int SLOT, int DST>
+    __device__ __forceinline__ void stage(const Stream& S, bool loader, bool pend, bool last, bool first) {
+        constexpr int PS = (SLOT + P2_RING - 1) % P2_RING;   // the previous stage's slot: its fragments' register numbering
+        if (loader) dma_all<DST>(S);
+        read_a<SLOT, 0>();
+        static_for<0, D>([&](auto i) {
+            constexpr int I = decltype(i)::value;
+            if (pend) mfma_q<PS, Q - D + I>();
+            read_b<SLOT, I>();
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, Q - D>([&](auto qi) {
+            constexpr int q = decltype(qi)::value;
+            lgkm_wait<younger(q)>(a[q / NCB], b[breg(SLOT, q)]);
+            if constexpr (SLOT == 0 && q < NCB) {
+                if (first) mfma_q0<SLOT, q>(); else mfma_q<SLOT, q>();
+            } else {
+                mfma_q<SLOT, q>();
+            }
+            if constexpr (q == QA) read_a<SLOT, 1>();
+            read_b<SLOT, q + D>();
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if constexpr (QA >= Q - D) read_a<SLOT, 1>();  // tiny tiles: the steady loop above is shorter than QA
+        if (last) {
+            static_for<Q - D, Q>([&](auto qi) {
+                constexpr int q = decltype(qi)::value;
+                lgkm_wait<0>(a[q / NCB], b[breg(SLOT, q)]);
+                if constexpr (SLOT == 0 && q < NCB) {   // (one-stage tiles of one or two col-blocks)
+                    if (first) mfma_q0<SLOT, q>(); else mfma_q<SLOT, q>();
+                } else {
+                    mfma_q<SLOT, q>();
+                }
+            });
+        }
+    }
+
+    // Nothing derived from the lane number stays live across the K loop (192 accumulators + 28 operand registers + 3
+    // addresses fill the file; a spilled value is a scratch reload = vector memory = `s_waitcnt vmcnt(0)` = the ring's
+    // look-ahead drained): the epilogues recompute it behind an opaque zero.
+    static __device__ __forceinline__ int lane_id() {
+        unsigned z = 0u;
+        asm volatile("" : "+v"(z));
+        return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+    }
+    // A candidate's position atomic (previous tile) is OLDER than every LDS-DMA piece of the tile that has run since (24
+    // stages x PW pieces): once at most the two stages in flight are outstanding it has returned.  Written as asm so that
+    // hipcc does not put `s_waitcnt vmcnt(0)` in front of the first use.  Column, row and score of that candidate wait in
+    // the wave's LDS table (entry = lane), not in registers; LDS is touched by asm only (hipcc orders every LDS access it
+    // sees behind ALL pending LDS-DMA).
+    __device__ __forceinline__ void flush_pending(int ln) {
+        // (a wave that loads nothing has only its own candidate traffic outstanding: it waits for all of it)
+        if (is_loader()) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(pend_pos) : "n"(2 * PW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(pend_pos) :: "memory");
+        if (pend_pos < (unsigned)PF_CAP) {
+            u32x4 e;
+            const unsigned pa = (unsigned)reinterpret_cast<uintptr_t>(sPend + w * 64) + (unsigned)ln * 16u;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(e) : "v"(pa) : "memory");
+            P.cand_row[(size_t)e.x * PF_CAP + pend_pos] = e.y;
+            P.cand_s[(size_t)e.x * PF_CAP + pend_pos] = __uint_as_float(e.z);
+        }
+        pend_pos = 0xffffffffu;
+    }
+
+    // pass 2: rows with shat >= threshold -> the slot's candidate buffer (compaction through a wave-private LDS list, one
+    // position atomic per candidate whose stores go out at the NEXT tile end; > 64 candidates in the tile: direct path)
+    __device__ __forceinline__ void epilogue_emit(int rb_tile0, int n_b, size_t col0) {
+        const int ln = lane_id();
+        const int hh = ln >> 5, cc = ln & 31;
+        flush_pending(ln);
+        const unsigned row0 = (unsigned)((rb_tile0 + w) * 32);
+        if (row0 + 32u > (unsigned)n_b) {  // wave-uniform: the bucket's ragged end (zero-padded / clamped rows never pass)
+            int lim = n_b - (int)row0 - 4 * hh;   // lane's rows (r & 3) + 8 (r >> 2) at or past `lim` are beyond the bucket
+#pragma unroll
+            for (int n = 0; n < NCB; ++n) {
+                asm volatile("" : "+v"(lim));    // opaque per col-block: sixteen hoisted lane masks would cost 32 SGPRs in the K loop
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if ((r & 3) + 8 * (r >> 2) >= lim) acc[n][r] = __builtin_nanf("");
+            }
+        }
+        const unsigned list_addr = (unsigned)reinterpret_cast<uintptr_t>(sList + w * P2_LIST);   // wave-uniform
+        int tot = 0;  // wave-uniform
+        unsigned kb = (unsigned)((cc << 8) | (4 * hh));
+        const unsigned thr_addr = (unsigned)reinterpret_cast<uintptr_t>(sThr) + (unsigned)cc * 4u;
+        // all thresholds first (the operand registers of the K loop are free now): one LDS latency instead of NCB
+        float thr[NCB];
+#pragma unroll
+        for (int n = 0; n < NCB; ++n) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(thr[n]) : "v"(thr_addr), "n"(n * 128) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int n = 0; n < NCB; ++n) asm volatile("" : "+v"(thr[n]));   // defined from here on
+#pragma unroll
+        for (int n = 0; n < NCB; ++n) {
+            // a col-block without any passing score (the common case once the bounds are tight) costs 8 v_max3 + 1 compare:
+            // the per-register pass below runs for col-blocks with a hit only.  v_max3 returns the other operands for a NaN.
+            float m0, m1, m2, m3, m4;
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m0) : "v"(acc[n][0]), "v"(acc[n][1]), "v"(acc[n][2]));
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m1) : "v"(acc[n][3]), "v"(acc[n][4]), "v"(acc[n][5]));
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m2) : "v"(acc[n][6]), "v"(acc[n][7]), "v"(acc[n][8]));
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m3) : "v"(acc[n][9]), "v"(acc[n][10]), "v"(acc[n][11]));
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m4) : "v"(acc[n][12]), "v"(acc[n][13]), "v"(acc[n][14]));
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m0) : "v"(m0), "v"(m1), "v"(acc[n][15]));
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m2) : "v"(m2), "v"(m3), "v"(m4));
+            asm("v_max_f32 %0, %1, %2" : "=v"(m0) : "v"(m0), "v"(m2));
+            bool any = m0 >= thr[n];
+#ifdef LMI_ABL_NOEMIT
+            any = any && thr[n] == 12345.678f;
+#endif
+            if (__builtin_expect(__ballot(any) == 0ull, 1)) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool pass = acc[n][r] >= thr[n];  // thr = +inf for idle columns, NaN scores never pass
+                const unsigned long long mask = __ballot(pass);
+                if (__builtin_expect(mask != 0ull, 0)) {
+                    if (pass) {
+                        const int my = tot + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                        const unsigned key = kb + (unsigned)(((n * 32) << 8) | ((r & 3) + 8 * (r >> 2)));
+                        const unsigned la = list_addr + (unsigned)min(my, 64) * 8u;
+                        const unsigned sb = __float_as_uint(acc[n][r]);
+                        const u32x2 ent = {key, sb};
+                        asm volatile("ds_write_b64 %0, %1" :: "v"(la), "v"(ent) : "memory");
+                    }
+                    tot += (int)__popcll(mask);
+                }
+            }
+        }
+        if (tot > 0 && tot <= 64) {
+            if (ln < tot) {
+                u32x2 e;
+                const unsigned la = list_addr + (unsigned)ln * 8u;
+                asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(e) : "v"(la) : "memory");
+                const unsigned pcol = (unsigned)(col0 + (e.x >> 8));
+                const u32x4 pe = {pcol, row0 + (e.x & 255u), e.y, 0u};
+                const unsigned pa = (unsigned)reinterpret_cast<uintptr_t>(sPend + w * 64) + (unsigned)ln * 16u;
+                asm volatile("ds_write_b128 %0, %1" :: "v"(pa), "v"(pe) : "memory");
+#ifdef LMI_ABL_NOATOMIC
+                pend_pos = (unsigned)ln;
+#else
+                const unsigned* cnt_addr = P.cand_cnt + pcol;
+                const unsigned one = 1u;
+                asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(pend_pos) : "v"(cnt_addr), "v"(one) : "memory");
+#endif
+            }
+        } else if (tot > 64) {
+#pragma unroll
+            for (int n = 0; n < NCB; ++n) {
+                const float thr = sThr[n * 32 + cc];
+                unsigned rowh = row0 + 4u * (unsigned)hh;
+                asm volatile("" : "+v"(rowh));   // the 16 row numbers are formed where they are used, not kept across the K loop
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (acc[n][r] >= thr) {
+                        const size_t col = col0 + n * 32 + cc;
+                        const unsigned pos = atomicAdd(P.cand_cnt + col, 1u);
+                        if (pos < (unsigned)PF_CAP) {
+                            P.cand_row[col * PF_CAP + pos] = rowh + (unsigned)((r & 3) + 8 * (r >> 2));
+                            P.cand_s[col * PF_CAP + pos] = acc[n][r];
+                        }
+                    }
+            }
+        }
+    }
+
+    // pass 1: per lane and col-block the maximum of its 16 scores -> bound[col][list][w * 2 + h]
+    __device__ __forceinline__ void epilogue_sample(int rb_tile0, int n_b, size_t col0, int m_left, int list_j, bool use_atomic) {
+        const int ln = lane_id();
+        const int h = ln >> 5, c = ln & 31;
+        const unsigned row0 = (unsigned)((rb_tile0 + w) * 32);
+        const bool ragged = row0 + 32u > (unsigned)n_b;
+        int lim = ragged ? n_b - (int)row0 - 4 * h : 64;
+#pragma unroll
+        for (int n = 0; n < NCB; ++n) {
+            if (ragged) {
+                asm volatile("" : "+v"(lim));
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if ((r & 3) + 8 * (r >> 2) >= lim) acc[n][r] = -INFINITY;
+            }
+            float m0, m1, m2, m3, m4;
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m0) : "v"(acc[n][0]), "v"(acc[n][1]), "v"(acc[n][2]));
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m1) : "v"(acc[n][3]), "v"(acc[n][4]), "v"(acc[n][5]));
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m2) : "v"(acc[n][6]), "v"(acc[n][7]), "v"(acc[n][8]));
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m3) : "v"(acc[n][9]), "v"(acc[n][10]), "v"(acc[n][11]));
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m4) : "v"(acc[n][12]), "v"(acc[n][13]), "v"(acc[n][14]));
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m0) : "v"(m0), "v"(m1), "v"(acc[n][15]));
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m2) : "v"(m2), "v"(m3), "v"(m4));
+            asm("v_max_f32 %0, %1, %2" : "=v"(m0) : "v"(m0), "v"(m2));
+            const float mx = m0;
+            if (n * 32 + c < m_left) {
+                // lists are COLUMN-minor: [list][slot = w * 2 + h][column] -- a wave's store is two runs of 32 consecutive floats
+                float* dst = P.bound + ((size_t)(list_j * 16 + w * 2 + h)) * (size_t)P.ncols + (col0 + n * 32 + c);
+                if (!use_atomic) *dst = mx;
+                else {  // more sampled tiles than lists: monotone float max through the order-preserving integer image
+                    if (mx >= 0.0f) atomicMax(reinterpret_cast<int*>(dst), __float_as_int(mx));
+                    else atomicMin(reinterpret_cast<unsigned*>(dst), __float_as_uint(mx));
+                }
+            }
+        }
+    }
+
+    // The tile = col-blocks [cbt0, cbt0 + NCB) of bucket b.  !SAMPLE: `ch` = chunk of the bucket, every tile of it;
+    // SAMPLE: `ch` = sampled tile j of the bucket (tile j * stride), one tile.
+    __device__ __forceinline__ void run(int b, int cbt0, int ch) {
+#ifdef LMI_P2_STAMPS
+        for (int i = 0; i < 12; ++i) st_acc[i] = 0;
+        st_last = __builtin_readcyclecounter();
+#endif
+        const int tid = threadIdx.x;
+        lane = tid & 63;
+        w = __builtin_amdgcn_readfirstlane(tid >> 6);
+        lds_lane = ring + (unsigned)lane * 16u;
+        const int KG = P.KG16, NS = KG / G;
+        const int n_b = P.nb_rows[b];
+        const int nrb_b = (n_b + 31) >> 5;
+        const int stride = SAMPLE ? sample_stride(n_b) : 1;
+        const int rb0 = SAMPLE ? ch * stride * P2_TILE_RB : ch * P.chunk_rb;
+        const int nrb_all = SAMPLE ? min(P2_TILE_RB, nrb_b - rb0) : min(P.chunk_rb, nrb_b - rb0);
+        const int nvt = (nrb_all + P2_TILE_RB - 1) / P2_TILE_RB;
+        const int cb_tile = P.cb_start[b] + cbt0;
+        const int m_left = P.m[b] - cbt0 * 32;   // live columns of the tile from its first one
+        const size_t col0 = (size_t)cb_tile * 32;
+        const uint4* aslab = P.slab16 + ((size_t)P.rb_start[b] * KG) * 64;
+        const size_t rb_stride = (size_t)KG * 64;
+        const int rb_last = nrb_b - 1;
+        const bool loader = is_loader();
+        const int lw = w & 3;
+        const int cbl0 = lw < NCB ? lw : NCB - 1, cbl1 = lw + 4 < NCB ? lw + 4 : NCB - 1, cbl2 = lw + 8 < NCB ? lw + 8 : NCB - 1;
+        const uint4* bbase0 = P.qfrag16 + ((size_t)(cb_tile + cbl0) * KG) * 64;
+        if (!SAMPLE) {
+            // thresholds of the tile's columns -> LDS (the caller's barrier made sThr free; the first stage's barrier publishes it)
+            for (int i = tid; i < NCB * 32; i += 64 * P2_WAVES) {
+                const bool wanted = i < m_left && (!P.redo_col || P.redo_col[col0 + i]);
+                sThr[i] = wanted ? P.bound1[col0 + i] - P.eps2[col0 + i] : INFINITY;
+            }
+        }
+        pend_pos = 0xffffffffu;
+        int vt_n = 0, t_n = 0;
+        Stream S;
+        S.a0 = aslab + (size_t)min(rb0 + lw, rb_last) * rb_stride;
+        S.a1 = aslab + (size_t)min(rb0 + lw + 4, rb_last) * rb_stride;
+        S.b0 = bbase0;
+        S.d1 = (cbl1 - cbl0) * KG * 64;
+        S.d2 = (cbl2 - cbl0) * KG * 64;
+        const int NSR = (NS + P2_RING - 1) / P2_RING * P2_RING;
+#define P2_ADVANCE                                                                               \
+        if (++t_n < NS) { S.a0 += G * 64; S.a1 += G * 64; S.b0 += G * 64; }                      \
+        else if (t_n == NSR) {                                                                   \
+            t_n = 0;                                                                             \
+            if (vt_n + 1 < nvt) {                                                                \
+                ++vt_n; S.b0 = bbase0;                                                           \
+                S.a0 = aslab + (size_t)min(rb0 + vt_n * P2_TILE_RB + lw, rb_last) * rb_stride;   \
+                S.a1 = aslab + (size_t)min(rb0 + vt_n * P2_TILE_RB + lw + 4, rb_last) * rb_stride; \
+            }                                                                                    \
+        }
+#ifdef LMI_ABL_NOWAIT
+#define P2_WAIT_LANDED
+#else
+#define P2_WAIT_LANDED asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PW) : "memory");
+#endif
+#ifdef LMI_ABL_NOBAR
+#define P2_BARRIER asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+#define P2_BARRIER asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier();
+#endif
+#define P2_STEP(SLOT, LIVE, LAST)                                                                \
+        P2_WAIT_LANDED                                                                           \
+        P2_STAMP_FINE(0)                                                                         \
+        P2_BARRIER                                                                               \
+        P2_STAMP_FINE(1)                                                                         \
+        if (LIVE) {                                                                              \
+            stage<SLOT, (SLOT + P2_RING - 1) % P2_RING>(S, loader, pend, (LAST), SLOT == 0 && t == 0); \
+            pend = !(LAST);                                                                      \
+        } else {                                                                                 \
+            if (loader) dma_all<(SLOT + P2_RING - 1) % P2_RING>(S);                              \
+        }                                                                                        \
+        P2_ADVANCE                                                                               \
+        P2_STAMP_FINE(2)
+        P2_STAMP(4)
+        if (nvt > 0) {
+            if (loader) dma_all<0>(S);
+            P2_ADVANCE
+            if (loader) dma_all<1>(S);
+            P2_ADVANCE
+        }
+        for (int vt = 0; vt < nvt; ++vt) {
+            bool pend = false;
+            for (int t = 0; t < NSR; t += P2_RING) {
+                P2_STEP(0, true, t + 1 >= NS)
+                P2_STEP(1, t + 1 < NS, t + 2 >= NS)
+                P2_STEP(2, t + 2 < NS, t + 3 >= NS)
+            }
+            P2_STAMP(2)   // (coarse builds: the whole K loop of the tile, waits and barriers included)
+            if (SAMPLE) epilogue_sample(rb0 + vt * P2_TILE_RB, n_b, col0, m_left, ch % P2_NSL, ch >= P2_NSL);
+            else epilogue_emit(rb0 + vt * P2_TILE_RB, n_b, col0);
+            P2_STAMP(3)
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the look-ahead before the LDS is reused
+        __syncthreads();
+        P2_STAMP(5)
+#ifdef LMI_P2_STAMPS
+        if (SAMPLE == (LMI_P2_STAMPS_SAMPLE != 0)) {
+            st_acc[7] = (unsigned long long)nvt;
+            if (lane == 0) {
+                unsigned long long* g = P.stamps + w * 12;
+                for (int i = 0; i < 12; ++i) atomicAdd(g + i, st_acc[i]);
+            }
+        }
+#endif
+#undef P2_STEP
+#undef P2_ADVANCE
+#undef P2_WAIT_LANDED
+#undef P2_BARRIER
+        if (!SAMPLE) flush_pending(lane_id());
+    }
+};
+
+// 10th largest of a column's P2_NSL x 16 slot maxima (every one the best score of a disjoint set of rows; -inf where no tile
+// wrote).  One thread per column (the lists are column-minor: neighbouring threads read neighbouring floats), a sorted
+// 10-entry register list, values-only; fewer than 10 finite values: -inf (no bound).
+__global__ __launch_bounds__(256) void bound_merge2_kernel(const float* __restrict__ lists, long long ncols, float* __restrict__ bound1) {
+    const long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= ncols) return;
+    float v[KPB];
+#pragma unroll
+    for (int j = 0; j < KPB; ++j) v[j] = -INFINITY;
+#pragma unroll 4
+    for (int i = 0; i < P2_NSL * 16; ++i) {
+        float s = lists[(size_t)i * ncols + col];
+        if (s > v[KPB - 1]) {
+#pragma unroll
+            for (int t = 0; t < KPB; ++t) {  // sorted insert (descending), values only
+                const float hi = fmaxf(v[t], s);
+                s = fminf(v[t], s);
+                v[t] = hi;
+            }
+        }
+    }
+    bound1[col] = v[KPB - 1];
+}
+
+// Query-level bound (k <= 10: the caller merges the ranks to the k <= 10 best of ALL visited buckets, LearnedIndex.py:125-146,
+// so a row below the query's 10th best canonical score T_q over its buckets cannot be returned, whatever its bucket).
+// bound1[col] <= That of the column's bucket, so That - eps' <= the bucket's canonical 10th best <= T_q: L_q = max over the
+// query's columns of (bound1 - eps') is a lower bound of T_q, and a row of bucket b with canonical score >= T_q has
+// shat >= L_q - eps'_b.  The kernel raises every column's bound1 to L_q + eps'_b, so that pass 2's threshold
+// bound1 - 2 eps'_b becomes L_q - eps'_b.  Scores of one query share its scale (and the index's), so they compare across buckets.
+__global__ void query_bound_kernel(const int* __restrict__ slot_col, int nq, int nb, const float* __restrict__ eps2, float* __restrict__ bound1) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    float lq = -INFINITY;
+    for (int r = 0; r < nb; ++r) {
+        const int col = slot_col[q * nb + r];
+        if (col >= 0) lq = fmaxf(lq, bound1[col] - 0.5f * eps2[col]);
+    }
+    if (!(lq > -INFINITY)) return;
+    lq -= fabsf(lq) * 4.8e-7f;  // the few roundings above, generously
+    for (int r = 0; r < nb; ++r) {
+        const int col = slot_col[q * nb + r];
+        if (col >= 0) bound1[col] = fmaxf(bound1[col], lq + 0.5f * eps2[col] * 0.9999f);
+    }
+}
+
+template <bool SAMPLE>
+__global__ __launch_bounds__(64 * P2_WAVES, 1) void pass2_kernel(PrefilterParams P) {
+    __shared__ __attribute__((aligned(16))) uint4 ring[P2_RING * P2_SLOT_BYTES / 16];
+    __shared__ uint2 sList[SAMPLE ? 1 : P2_WAVES * P2_LIST];
+    __shared__ float sThr[SAMPLE ? 1 : P2_MAXCB * 32];
+    __shared__ __attribute__((aligned(16))) uint4 sPend[SAMPLE ? 1 : P2_WAVES * 64];
+    __shared__ int s_item[2];
+    int grp = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & (NGRP - 1));
+    if (!SAMPLE && P.redo_count && *P.redo_count == 0u) return;  // the redo launch of a batch without overflowed columns
+    for (;;) {
+        if (threadIdx.x == 0) {
+            int b = -1, local = 0;
+            do {
+                b = -1;
+                {
+                    // the XCD-affine queues (route_group_kernel): pass 1 has its own prefixes (items = query tiles x SAMPLED tiles)
+                    // and heads; a bucket's items go to the same XCD in both passes: its queries' fragments stay in that L2
+                    unsigned* heads = P.head + (SAMPLE ? 24 : 0);
+                    const int* totals = SAMPLE ? P.grp_total1 : P.grp_total;
+                    const int* bases = SAMPLE ? P.grp_base1 : P.grp_base;
+                    for (int tries = 0; tries < NGRP; ++tries) {
+                        const int tot = totals[grp];
+                        if (__hip_atomic_load(&heads[grp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)tot) {
+                            const int it = (int)atomicAdd(&heads[grp], 1u);
+                            if (it < tot) {
+                                const int* base = bases + grp * (P.L + 1);
+                                int lo = 0, hi = P.grp_n[grp];
+                                while (hi - lo > 1) {
+                                    const int mid = (lo + hi) >> 1;
+                                    if (base[mid] <= it) lo = mid; else hi = mid;
+                                }
+                                b = P.grp_bucket[grp * P.L + lo];
+                                local = it - base[lo];
+                                break;
+                            }
+                        }
+                        grp = (grp + 1) & (NGRP - 1);
+                    }
+                }
+            } while (!SAMPLE && P.redo_bucket && b >= 0 && !P.redo_bucket[b]);
+            s_item[0] = b;
+            s_item[1] = local;
+        }
+        __syncthreads();
+        const int b = s_item[0], local = s_item[1];
+        __syncthreads();
+        if (b < 0) return;
+        // query tiles of the bucket: its col-blocks split evenly over nqt = ceil(col-blocks / 12) tiles
+        const int ncb_b = (P.m[b] + 31) >> 5;
+        const int nqt = (ncb_b + P2_MAXCB - 1) / P2_MAXCB;
+        const int per = (ncb_b + nqt - 1) / nqt;
+        // pass 2: local = chunk * nqt + tile; pass 1: local = tile * (sampled tiles) + sampled tile
+        const int nst = SAMPLE ? p2_sample_tiles(P.nb_rows[b]) : 1;
+        const int qt = SAMPLE ? local / nst : local % nqt, ch = SAMPLE ? local % nst : local / nqt;
+        const int cbt0 = qt * per;
+        const int ncb_tile = min(per, ncb_b - cbt0);
+#define P2_CASE(N) case N: { Tile2<N, SAMPLE> it{P, (unsigned)reinterpret_cast<uintptr_t>(ring), ring, sList, sThr, sPend}; it.run(b, cbt0, ch); break; }
+        switch (ncb_tile) {
+            P2_CASE(1) P2_CASE(2) P2_CASE(3) P2_CASE(4) P2_CASE(5) P2_CASE(6)
+            P2_CASE(7) P2_CASE(8) P2_CASE(9) P2_CASE(10) P2_CASE(11)
+            default: { Tile2<12, SAMPLE> it{P, (unsigned)reinterpret_cast<uintptr_t>(ring), ring, sList, sThr, sPend}; it.run(b, cbt0, ch); break; }
+        }
+#undef P2_CASE
+    }
+}
+
+}  // namespace lmi

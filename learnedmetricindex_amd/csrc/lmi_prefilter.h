@@ -300,19 +300,7 @@ __global__ void slot_bound_kernel(const int* __restrict__ bucket_order, const in
 //                     inter-item traffic: every row with shat >= bound[col] - 2 eps' is appended to
 //                     the slot's candidate buffer.  About 10 * PF_SAMPLE rows per slot pass.
 // ------------------------------------------------------------------------------------------------
-#ifndef LMI_PF_SAMPLE_ROWS
-#define LMI_PF_SAMPLE_ROWS 2000  // a bucket is sampled at stride s only if it has >= this many rows per unit of s (1300..3500: within 1 %)
-#endif
-#ifndef LMI_PF_SAMPLE
-#define LMI_PF_SAMPLE 16
-#endif
-constexpr int PF_SAMPLE = LMI_PF_SAMPLE;  // pass 1 looks at every 16th tile of a large bucket ...
-// ... and at every 8th, 4th, 2nd or every tile of buckets below LMI_PF_SAMPLE_ROWS x the stride (see PreItem::run)
-__device__ __forceinline__ int sample_stride(int n_b) {
-    int s = PF_SAMPLE;
-    while (s > 1 && n_b < LMI_PF_SAMPLE_ROWS * s) s >>= 1;
-    return s;
-}
+// (LMI_PF_SAMPLE, LMI_PF_SAMPLE_ROWS, sample_stride: lmi_kernels.h -- the routing kernels count the sampled tiles too)
 #ifndef LMI_PF_RING2
 #define LMI_PF_RING2 3  // ring slots of the NG 2 pass-2 kernel (3 or 4; A/B on MI355X: 4 is 1-3 % slower, more in flight only raised the load latency)
 #endif
@@ -350,7 +338,10 @@ struct PrefilterParams {
     const int* grp_base;
     const int* grp_n;
     const int* grp_total;
-    unsigned* head;       // [NGRP] pass-2 queue heads; [NGRP] = pass-1 head
+    const int* grp_base1;  // lmi_pass2.h pass 1: the XCD-affine queues of its (bucket, query tile, sampled tile) items
+    const int* grp_total1;
+    long long ncols;       // columns of the batch (stride of the pass-1 lists of lmi_pass2.h)
+    unsigned* head;       // [NGRP] pass-2 queue heads; [NGRP] = pass-1 head ([NGRP..2 NGRP): lmi_pass2.h's pass-1 queues)
     int parts;            // pass-1 items per (bucket, query tile): 4, 8 or 16
     float* bound;         // [columns][parts][4 row-waves][PF_LK] pass 1: the best sampled shat of every 64-row strip
     float* bound1;        // [columns] bound_merge_kernel: 10th best of the union of the parts -> pass 2

@@ -109,6 +109,14 @@ __device__ __forceinline__ void select_tail(const RescoreParams& P, const Select
             nk += (unsigned)__popcll(bal);
         }
     }
+    if (nk == 0u && lane < KPB) {
+        // no candidate at all (a query-level bound above everything this bucket holds, query_bound_kernel): no rescore wave
+        // may come by, so the slot's list is written here -- all padding (it sorts behind every real entry of the query)
+        const int b = P.bucket_order[p];
+        const int rb0 = P.rb_start[b], n_b = P.nb_rows[b];
+        P.rank_d[(size_t)p * KPB + lane] = P.raw ? -3.402823466e+38f : pad_dist(P.qn2);
+        P.rank_id[(size_t)p * KPB + lane] = P.raw ? NOROW : P.ids_slab[(size_t)rb0 * 32 + (n_b - 1)];
+    }
     if (lane == 0) {
         if (nk > (unsigned)RC_KEEP) P.fallback[p] = 1;
         else {

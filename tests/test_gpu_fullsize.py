@@ -86,7 +86,8 @@ def test_c2_full_size_modes_and_oracle(oracle):
         dh, ih = d.cpu().numpy(), i.cpu().numpy().view(np.uint32)
         if pf:
             active, survivors, fallbacks = idx.prefilter_stats()
-            assert active and fallbacks == 0 and survivors >= 10 * nq * NB
+            # (k = 10: the bound is per QUERY -- only the ranks that can reach the query's top 10 keep survivors; at least its 10 best do)
+            assert active and fallbacks == 0 and survivors >= 10 * nq
             _oracle_check(oracle, idx, Qh, order_h, sel, NB, dh, ih)   # the default mode against the oracle
         out.append((dh, ih))
         idx.close()
