@@ -230,6 +230,10 @@ class Workload:
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
         res["scan_stats"] = eng.scan_stats()
         res["pf_stats"] = eng.prefilter_stats()
+        try:   # columns whose candidate buffer overflowed in the last batch (they get a second run of pass 2)
+            res["pf_redo_columns"] = int(eng.debug_peek("pf_redo", 4).view(np.uint32)[0]) if not self.args.exact else 0
+        except Exception:  # noqa: BLE001
+            res["pf_redo_columns"] = None
         return res
 
     def recall(self, out_i, nr):
@@ -539,6 +543,7 @@ def main():
                 "resident_ms_per_step": round(rh["resident_elapsed"] / max(5, args.steps // 2) * 1e3, 4),
                 "bucket_sizes_min_median_max": [int(hs.min()), int(np.median(hs)), int(hs.max())],
                 "survivors_per_slot": round(rh["pf_stats"][1] / max(1, nq * nb), 2), "fallback_slots": int(rh["pf_stats"][2]),
+                "overflowed_columns": rh.get("pf_redo_columns"),
                 "scan_pairs": int(rh["scan_stats"][1]),
                 "phases_ms": {"pf_sample": round(float(rh["phases"][5]), 4), "pf_emit": round(float(rh["phases"][6]), 4),
                               "rescore": round(float(rh["phases"][7]), 4), "fallback": round(float(rh["phases"][8]), 4)}}
@@ -613,7 +618,7 @@ def main():
                        "scan_pairs": int(pairs), "scan_items": int(items)},
             "roofline": roof,
             "prefilter": None if args.exact else {"survivors_per_slot": round(pf_survivors / max(1, nq * nb), 2),
-                                                   "fallback_slots": int(pf_fallbacks)},
+                                                   "fallback_slots": int(pf_fallbacks), "overflowed_columns": res.get("pf_redo_columns")},
             "cpu_baseline": cpu,
             "resident": resident,
             "sharded_alt_mode": alt,

@@ -146,6 +146,7 @@ struct lmi_index {
     bool last_fast = false;
     bool pf_v2 = true;            // LMI_PF_V1=1: the round-2 prefilter kernels (lmi_prefilter.h) instead of lmi_pass2.h (A/B)
     bool pf_qbound = true;        // LMI_PF_QBOUND=0: per-bucket bounds only (query_bound_kernel off)
+    bool pf_primary = true;       // LMI_PF_PRIMARY=0: pass 1 samples every column although one bound per query is used
     bool debug_emit_all = false;  // lmi_debug_emit_all
 
     // ---- per-call workspaces ----
@@ -216,6 +217,7 @@ extern "C" LMI_API int lmi_create(int device, lmi_index** out) {
     if (const char* e = getenv("LMI_PF_NO_REDO")) h->pf_redo = !(e[0] && e[0] != '0');
     if (const char* e = getenv("LMI_PF_V1")) h->pf_v2 = !(e[0] && e[0] != '0');
     if (const char* e = getenv("LMI_PF_QBOUND")) h->pf_qbound = e[0] && e[0] != '0';
+    if (const char* e = getenv("LMI_PF_PRIMARY")) h->pf_primary = e[0] && e[0] != '0';
     // per handle = per device (a process may hold handles on several devices; the attribute is per device)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -950,7 +952,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     for (int b = 0; b < L; ++b) max_nch = std::max(max_nch, h->h_nch[b]);
     const long long part_lists = fast ? 1 : std::max<long long>(1, (long long)nb * max_nch * nq);
 
-    CHK(h->m.reserve(L * 4));
+    CHK(h->m.reserve((size_t)L * 4 * 3));   // m [L] | m0 [L] | the non-primary slots' counter [L]
     CHK(h->cb_start.reserve((L + 1) * 4));
     CHK(h->item_base.reserve((L + 1) * 4));
     CHK(h->part_base.reserve((L + 1) * 8));
@@ -972,6 +974,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     R.nb_rows = h->d_nb_rows.as<int>();
     R.nch = h->d_nch.as<int>();
     R.m = h->m.as<int>();
+    R.m0 = R.m + L;
     R.cb_start = h->cb_start.as<int>();
     R.item_base = h->item_base.as<int>();
     R.part_base = h->part_base.as<long long>();
@@ -987,6 +990,10 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     const bool v2 = (h->prefilter && h->have16) && h->pf_v2;
     R.tile_cb = v2 ? P2_MAXCB : (h->prefilter && h->have16) ? 4 * PF_NG : 4;
     R.sample_items = v2 ? 1 : 0;
+    // one bound per QUERY is enough when the caller keeps the k <= 10 best over all ranks (query_bound_kernel, lmi_pass2.h): pass 1
+    // then samples only each query's primary slot(s) -- a quarter of the columns at n_buckets = 4
+    const bool qbound = v2 && h->pf_qbound && nb > 1 && kout <= KPB;
+    R.primary_nb = (qbound && h->pf_primary) ? nb : 0;
 
     const size_t ncols = (size_t)ncb_bound * 32;
     int pf_parts = 4;
@@ -994,7 +1001,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     Z.count = 0;
     bool fill_ok = true;
     auto fill = [&](void* ptr, long long words, unsigned value) { fill_ok = Z.add(ptr, words, value) && fill_ok; };
-    fill(h->m.p, L, 0u);
+    fill(h->m.p, 3ll * L, 0u);
     fill(h->head.p, 32, 0u);   // [0..8] pass-2 queue heads + the pass-1 head, [16..24) the heads of pass 2's redo launch
     fill(h->colmap.p, (long long)ncols, 0xFFFFFFFFu);
     fill(h->col_thr.p, (long long)ncols, 0xFF800000u /* -inf */);
@@ -1036,7 +1043,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     route_group_kernel<<<1, 1024, (size_t)L * 24, h->side>>>(L, R);
     HIPCHK(hipGetLastError());
     route_fill_kernel<<<cdiv(nslots, 256), 256, 0, h->stream>>>(d_order, h->slot_local.as<int>(), nslots, nb,
-                                                               R.cb_start, h->colmap.as<int>(), h->slot_col.as<int>());
+                                                               R.cb_start, R.m0, h->colmap.as<int>(), h->slot_col.as<int>());
     HIPCHK(hipGetLastError());
     ScanParams S;
     S.slab = h->slab.as<float4>();
@@ -1095,6 +1102,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         F.nb_rows = R.nb_rows;
         F.nch = R.nch;
         F.m = R.m;
+        F.m0 = R.m0;
         F.cb_start = R.cb_start;
         F.grp_bucket = R.grp_bucket;
         F.grp_base = R.grp_base;
@@ -1123,9 +1131,9 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         if (v2) {
             pass2_kernel<true><<<h->num_cus, 64 * P2_WAVES, 0, h->stream>>>(F);   // pass 1: slot maxima of the sampled tiles
             HIPCHK(hipGetLastError());
-            bound_merge2_kernel<<<cdiv((long long)ncols, 256), 256, 0, h->stream>>>(F.bound, (long long)ncols, F.bound1);
+            bound_merge2_kernel<<<cdiv((long long)ncols, 64), 256, 0, h->stream>>>(F.bound, (long long)ncols, F.bound1);
             HIPCHK(hipGetLastError());
-            if (h->pf_qbound && nb > 1 && kout <= KPB) {   // the caller keeps the k <= 10 best over all ranks: one bound per query
+            if (qbound) {   // the caller keeps the k <= 10 best over all ranks: one bound per query
                 query_bound_kernel<<<cdiv(nq, 256), 256, 0, h->stream>>>(h->slot_col.as<int>(), nq, nb, F.eps2, F.bound1);
                 HIPCHK(hipGetLastError());
             }
@@ -1750,6 +1758,7 @@ extern "C" LMI_API int lmi_debug_peek(lmi_index* h, const char* name, void* dst,
     size_t off = 0;
     if (!strcmp(name, "pf_bound")) b = &h->pf_bound;
     if (!strcmp(name, "pf_stamps")) { b = &h->pf_bound; off = h->stamps_off; }
+    if (!strcmp(name, "pf_redo")) b = &h->redo;   // [0]: columns whose candidate buffer overflowed in the last scan (second run of pass 2)
     if (!b) return fail("lmi_debug_peek: unknown buffer '%s'", name);
     if (bytes < 0 || off + (size_t)bytes > b->cap) return fail("lmi_debug_peek: %lld bytes asked of a %zu-byte buffer", (long long)bytes, b->cap);
     if (bytes) HIPCHK(hipMemcpy(dst, static_cast<char*>(b->p) + off, (size_t)bytes, hipMemcpyDeviceToHost));

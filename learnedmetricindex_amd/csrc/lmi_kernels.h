@@ -298,6 +298,8 @@ struct RouteArrays {
     const int* nb_rows;   // [L] objects per bucket (0: empty / not owned)
     const int* nch;       // [L] scan chunks per bucket
     int* m;               // [L] queries routed to the bucket (zeroed before route_count)
+    int* m0;              // [L] of them: PRIMARY slots -- the columns [0, m0) of the bucket, the only ones the prefilter's pass 1
+                          // samples when one bound per query is enough (primary_nb > 0; otherwise m0 == m).  [L..2L): the others' counter
     int* cb_start;        // [L+1] col-block prefix
     int* item_base;       // [L+1] work-item prefix
     long long* part_base; // [L+1] partial-list prefix
@@ -312,6 +314,7 @@ struct RouteArrays {
     int* grp_base1;       // [NGRP][L+1] the same prefix for the pass-1 items (query tiles x sampled tiles) of lmi_pass2.h
     int* grp_total1;      // [NGRP]
     int tile_cb;          // col-blocks per query tile: 4 (exact scan), 12 (prefilter: lmi_pass2.h), 8 (the round-2 prefilter kernel)
+    int primary_nb;       // > 0 (= n_buckets): a slot is primary iff no lower rank of its query holds a bucket of >= 64 rows here
     int sample_items;     // 1: qt_base counts pass-1 items of lmi_pass2.h = query tiles x SAMPLED 256-row tiles of the bucket
 };
 
@@ -329,6 +332,25 @@ __device__ __forceinline__ int sample_stride(int n_b) {
     while (s > 1 && n_b < LMI_PF_SAMPLE_ROWS * s) s >>= 1;
     return s;
 }
+// Pass-1 items of a bucket (lmi_pass2.h): its sampled tiles j = 0, 1, ..; every P1_ALL_EVERY-th of them is run over ALL the
+// bucket's columns (query tiles of m), the others over the primary columns only (query tiles of m0): a primary column is sampled
+// at the full rate, the others at 1 / P1_ALL_EVERY of it -- enough of an own bound that their candidate buffers cannot overflow
+// when the query's bound (query_bound_kernel) turns out loose for their bucket (10 x the stride x P1_ALL_EVERY rows pass).
+constexpr int P1_ALL_EVERY = 2;
+__device__ __forceinline__ int pass1_items(int nst, int nqt_all, int nqt_primary) {
+    const int n_all = (nst + P1_ALL_EVERY - 1) / P1_ALL_EVERY;
+    return n_all * nqt_all + (nst - n_all) * nqt_primary;
+}
+// item `local` of the bucket -> sampled tile j and query tile qt; returns whether the tile runs over all columns
+__device__ __forceinline__ bool pass1_decode(int local, int nqt_all, int nqt_primary, int* j, int* qt) {
+    const int per = nqt_all + (P1_ALL_EVERY - 1) * nqt_primary;   // items of one group of P1_ALL_EVERY sampled tiles
+    const int grp = local / per, rem = local - grp * per;
+    if (rem < nqt_all) { *j = grp * P1_ALL_EVERY; *qt = rem; return true; }
+    const int r2 = rem - nqt_all;
+    *j = grp * P1_ALL_EVERY + 1 + r2 / nqt_primary;
+    *qt = r2 % nqt_primary;
+    return false;
+}
 __device__ __forceinline__ int sample_tiles256(int n_b) {  // sampled 256-row tiles of a bucket
     const int nt = (((n_b + 31) >> 5) + 7) / 8;
     const int s = sample_stride(n_b);
@@ -340,30 +362,47 @@ __device__ __forceinline__ int query_tiles(int m, int tile_cb) { return (((m + 3
 
 // Positions are handed out per block through an LDS histogram (one global atomic per bucket and
 // block instead of one per slot: 40 000 returning atomics on 120 hot words took 66 us).
+// Primary slots (RouteArrays::primary_nb) take the bucket's first columns, the others follow: slot_local = position among its
+// kind, bit 30 set for the others (route_fill_kernel adds m0).
 constexpr int ROUTE_LDS_BUCKETS = 4096;
+constexpr int ROUTE_OTHER = 1 << 30;
 __global__ __launch_bounds__(256) void route_count_kernel(const int* __restrict__ bucket_order, int nslots, int L,
                                                           RouteArrays R, int* __restrict__ slot_local) {
-    __shared__ int cnt_s[ROUTE_LDS_BUCKETS];
+    __shared__ int cnt_s[2 * ROUTE_LDS_BUCKETS];
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     int b = -1;
+    bool other = false;
     if (p < nslots) {
         b = bucket_order[p];
         if (!(b >= 0 && b < L && R.nb_rows[b] > 0)) b = -1;
+        if (b >= 0 && R.primary_nb > 0) {
+            const int r = p % R.primary_nb;
+            for (int j = p - r; j < p; ++j) {   // a lower rank of this query with a bucket large enough to give the query its bound
+                const int bj = bucket_order[j];
+                if (bj >= 0 && bj < L && R.nb_rows[bj] >= 64) other = true;
+            }
+        }
     }
+    int* m1 = R.m0 + L;
     if (L > ROUTE_LDS_BUCKETS) {  // huge fan-out: plain global atomics
-        if (p < nslots) slot_local[p] = b >= 0 ? atomicAdd(&R.m[b], 1) : -1;
+        if (p < nslots) {
+            if (b >= 0) atomicAdd(&R.m[b], 1);
+            slot_local[p] = b < 0 ? -1 : other ? (atomicAdd(&m1[b], 1) | ROUTE_OTHER) : atomicAdd(&R.m0[b], 1);
+        }
         return;
     }
-    for (int i = threadIdx.x; i < L; i += blockDim.x) cnt_s[i] = 0;
+    for (int i = threadIdx.x; i < 2 * L; i += blockDim.x) cnt_s[i] = 0;
     __syncthreads();
-    const int loc = b >= 0 ? atomicAdd(&cnt_s[b], 1) : 0;
+    const int loc = b >= 0 ? atomicAdd(&cnt_s[other ? L + b : b], 1) : 0;
     __syncthreads();
     for (int i = threadIdx.x; i < L; i += blockDim.x) {
-        const int c = cnt_s[i];
-        cnt_s[i] = c > 0 ? atomicAdd(&R.m[i], c) : 0;  // block's base position in bucket i
+        const int c0 = cnt_s[i], c1 = cnt_s[L + i];
+        if (c0 + c1 > 0) atomicAdd(&R.m[i], c0 + c1);
+        cnt_s[i] = c0 > 0 ? atomicAdd(&R.m0[i], c0) : 0;       // block's base position among the bucket's primary slots
+        cnt_s[L + i] = c1 > 0 ? atomicAdd(&m1[i], c1) : 0;      // ... among the others
     }
     __syncthreads();
-    if (p < nslots) slot_local[p] = b >= 0 ? cnt_s[b] + loc : -1;
+    if (p < nslots) slot_local[p] = b < 0 ? -1 : other ? ((cnt_s[L + b] + loc) | ROUTE_OTHER) : cnt_s[b] + loc;
 }
 
 __global__ __launch_bounds__(256) void route_scan_kernel(int L, RouteArrays R) {
@@ -429,7 +468,8 @@ __global__ __launch_bounds__(1024) void route_group_kernel(int L, RouteArrays R)
         m_s[b] = m;
         work_s[b] = (long long)m * R.nb_rows[b];
         items_s[b] = query_tiles(m, R.tile_cb) * R.nch[b];
-        items1_s[b] = m > 0 ? query_tiles(m, R.tile_cb) * sample_tiles256(R.nb_rows[b]) : 0;
+        const int mp = R.sample_items ? R.m0[b] : 0;   // pass 1 runs over the primary columns only
+        items1_s[b] = (R.sample_items && m > 0) ? pass1_items(sample_tiles256(R.nb_rows[b]), query_tiles(m, R.tile_cb), query_tiles(mp, R.tile_cb)) : 0;
     }
     __syncthreads();
     // rank of every bucket by (work desc, id asc); work = queries x rows is a fine proxy
@@ -499,14 +539,15 @@ __global__ __launch_bounds__(1024) void route_group_kernel(int L, RouteArrays R)
 }
 
 __global__ void route_fill_kernel(const int* __restrict__ bucket_order, const int* __restrict__ slot_local,
-                                  int nslots, int nb, const int* __restrict__ cb_start,
+                                  int nslots, int nb, const int* __restrict__ cb_start, const int* __restrict__ m0,
                                   int* __restrict__ colmap, int* __restrict__ slot_col) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= nslots) return;
     int loc = slot_local[p];
     int col = -1;
     if (loc >= 0) {
-        col = cb_start[bucket_order[p]] * 32 + loc;
+        const int b = bucket_order[p];
+        col = cb_start[b] * 32 + ((loc & ROUTE_OTHER) ? m0[b] + (loc & (ROUTE_OTHER - 1)) : loc);
         colmap[col] = p / nb;
     }
     slot_col[p] = col;

@@ -127,6 +127,16 @@ struct Tile2 {
     template <int SLOT, int QI>
     __device__ __forceinline__ void mfma_q() {
         constexpr int g = QI / NCB, n = QI % NCB;
+#ifdef LMI_ABL_MFMA16   // timing-only ablation: the same flops and operand registers issued as two v_mfma_f32_16x16x32_f16 (garbage results)
+        typedef float f32x4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f32x4v c = {acc[n][8 * g + 4 * i], acc[n][8 * g + 4 * i + 1], acc[n][8 * g + 4 * i + 2], acc[n][8 * g + 4 * i + 3]};
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[g], b[breg(SLOT, QI)], c, 0, 0, 0);
+            acc[n][8 * g + 4 * i] = c[0]; acc[n][8 * g + 4 * i + 1] = c[1]; acc[n][8 * g + 4 * i + 2] = c[2]; acc[n][8 * g + 4 * i + 3] = c[3];
+        }
+        return;
+#endif
         acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[g], b[breg(SLOT, QI)], acc[n], 0, 0, 0);
     }
     // the tile's first k-group starts the accumulators at 0 (srcC = the inline constant: no clearing pass, no zero registers)
@@ -399,7 +409,7 @@ struct Tile2 {
 
     // The tile = col-blocks [cbt0, cbt0 + NCB) of bucket b.  !SAMPLE: `ch` = chunk of the bucket, every tile of it;
     // SAMPLE: `ch` = sampled tile j of the bucket (tile j * stride), one tile.
-    __device__ __forceinline__ void run(int b, int cbt0, int ch) {
+    __device__ __forceinline__ void run(int b, int cbt0, int ch, int m_use) {
 #ifdef LMI_P2_STAMPS
         for (int i = 0; i < 12; ++i) st_acc[i] = 0;
         st_last = __builtin_readcyclecounter();
@@ -416,7 +426,7 @@ struct Tile2 {
         const int nrb_all = SAMPLE ? min(P2_TILE_RB, nrb_b - rb0) : min(P.chunk_rb, nrb_b - rb0);
         const int nvt = (nrb_all + P2_TILE_RB - 1) / P2_TILE_RB;
         const int cb_tile = P.cb_start[b] + cbt0;
-        const int m_left = P.m[b] - cbt0 * 32;   // live columns of the tile from its first one
+        const int m_left = m_use - cbt0 * 32;   // live columns of the tile from its first one (pass 1: m or m0, see the kernel)
         const size_t col0 = (size_t)cb_tile * 32;
         const uint4* aslab = P.slab16 + ((size_t)P.rb_start[b] * KG) * 64;
         const size_t rb_stride = (size_t)KG * 64;
@@ -514,17 +524,17 @@ struct Tile2 {
 };
 
 // 10th largest of a column's P2_NSL x 16 slot maxima (every one the best score of a disjoint set of rows; -inf where no tile
-// wrote).  One thread per column (the lists are column-minor: neighbouring threads read neighbouring floats), a sorted
-// 10-entry register list, values-only; fewer than 10 finite values: -inf (no bound).
+// wrote).  A block takes 64 columns; thread (quarter qd, column c) keeps the ten best of lists 4 qd .. 4 qd + 3 (64 values; the
+// lists are column-minor: the 64 threads of a quarter read 64 neighbouring floats), the four partial lists of a column meet in
+// LDS.  Values only; fewer than 10 finite values: -inf (no bound).
 __global__ __launch_bounds__(256) void bound_merge2_kernel(const float* __restrict__ lists, long long ncols, float* __restrict__ bound1) {
-    const long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= ncols) return;
+    __shared__ float part[4][KPB][64];
+    const int c = threadIdx.x & 63, qd = threadIdx.x >> 6;
+    const long long col = (long long)blockIdx.x * 64 + c;
     float v[KPB];
 #pragma unroll
     for (int j = 0; j < KPB; ++j) v[j] = -INFINITY;
-#pragma unroll 4
-    for (int i = 0; i < P2_NSL * 16; ++i) {
-        float s = lists[(size_t)i * ncols + col];
+    auto insert = [&](float s) {
         if (s > v[KPB - 1]) {
 #pragma unroll
             for (int t = 0; t < KPB; ++t) {  // sorted insert (descending), values only
@@ -533,8 +543,22 @@ __global__ __launch_bounds__(256) void bound_merge2_kernel(const float* __restri
                 v[t] = hi;
             }
         }
+    };
+    if (col < ncols) {
+        const float* src = lists + (size_t)(qd * (P2_NSL / 4) * 16) * ncols + col;
+#pragma unroll 8
+        for (int i = 0; i < (P2_NSL / 4) * 16; ++i) insert(src[(size_t)i * ncols]);
     }
-    bound1[col] = v[KPB - 1];
+#pragma unroll
+    for (int j = 0; j < KPB; ++j) part[qd][j][c] = v[j];
+    __syncthreads();
+    if (qd == 0 && col < ncols) {
+#pragma unroll
+        for (int o = 1; o < 4; ++o)
+#pragma unroll
+            for (int j = 0; j < KPB; ++j) insert(part[o][j][c]);
+        bound1[col] = v[KPB - 1];
+    }
 }
 
 // Query-level bound (k <= 10: the caller merges the ranks to the k <= 10 best of ALL visited buckets, LearnedIndex.py:125-146,
@@ -606,20 +630,27 @@ __global__ __launch_bounds__(64 * P2_WAVES, 1) void pass2_kernel(PrefilterParams
         const int b = s_item[0], local = s_item[1];
         __syncthreads();
         if (b < 0) return;
-        // query tiles of the bucket: its col-blocks split evenly over nqt = ceil(col-blocks / 12) tiles
-        const int ncb_b = (P.m[b] + 31) >> 5;
+        // query tiles of the bucket: its col-blocks split evenly over nqt = ceil(col-blocks / 12) tiles.
+        // pass 2: local = chunk * nqt + tile, all columns.  pass 1: pass1_decode -> sampled tile j, query tile; every
+        // P1_ALL_EVERY-th sampled tile runs over all the columns, the others over the primary ones (the bucket's first m0).
+        int qt, ch;
+        bool all_cols = true;
+        if (SAMPLE) {
+            const int nqa = query_tiles(P.m[b], P2_MAXCB), nqp = query_tiles(P.m0[b], P2_MAXCB);
+            all_cols = pass1_decode(local, nqa, nqp, &ch, &qt);
+        }
+        const int m_use = all_cols ? P.m[b] : P.m0[b];
+        const int ncb_b = (m_use + 31) >> 5;
         const int nqt = (ncb_b + P2_MAXCB - 1) / P2_MAXCB;
         const int per = (ncb_b + nqt - 1) / nqt;
-        // pass 2: local = chunk * nqt + tile; pass 1: local = tile * (sampled tiles) + sampled tile
-        const int nst = SAMPLE ? p2_sample_tiles(P.nb_rows[b]) : 1;
-        const int qt = SAMPLE ? local / nst : local % nqt, ch = SAMPLE ? local % nst : local / nqt;
+        if (!SAMPLE) { qt = local % nqt; ch = local / nqt; }
         const int cbt0 = qt * per;
         const int ncb_tile = min(per, ncb_b - cbt0);
-#define P2_CASE(N) case N: { Tile2<N, SAMPLE> it{P, (unsigned)reinterpret_cast<uintptr_t>(ring), ring, sList, sThr, sPend}; it.run(b, cbt0, ch); break; }
+#define P2_CASE(N) case N: { Tile2<N, SAMPLE> it{P, (unsigned)reinterpret_cast<uintptr_t>(ring), ring, sList, sThr, sPend}; it.run(b, cbt0, ch, m_use); break; }
         switch (ncb_tile) {
             P2_CASE(1) P2_CASE(2) P2_CASE(3) P2_CASE(4) P2_CASE(5) P2_CASE(6)
             P2_CASE(7) P2_CASE(8) P2_CASE(9) P2_CASE(10) P2_CASE(11)
-            default: { Tile2<12, SAMPLE> it{P, (unsigned)reinterpret_cast<uintptr_t>(ring), ring, sList, sThr, sPend}; it.run(b, cbt0, ch); break; }
+            default: { Tile2<12, SAMPLE> it{P, (unsigned)reinterpret_cast<uintptr_t>(ring), ring, sList, sThr, sPend}; it.run(b, cbt0, ch, m_use); break; }
         }
 #undef P2_CASE
     }

@@ -331,6 +331,7 @@ struct PrefilterParams {
     const int* nb_rows;
     const int* nch;
     const int* m;
+    const int* m0;        // lmi_pass2.h pass 1: the bucket's primary columns [0, m0) are the sampled ones
     const int* cb_start;
     const int* qt_base;   // [L+1] prefix of the query-tile counts of the buckets taken heaviest first (pass-1 items)
     const int* by_work;   // [L] that order
