@@ -46,6 +46,20 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def lib_source_sha16() -> str:
+    """sha256 over the library's sources (csrc/*.h, *.hip, include/*.h): ties a PMC summary under profiles/ to the kernels
+    it was collected from (profiles/summarize.py stamps the same value into the summary)."""
+    import glob
+    import hashlib
+
+    hsh = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "learnedmetricindex_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "learnedmetricindex_amd", "csrc", "*.hip"))
+                    + glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        hsh.update(os.path.basename(f).encode())
+        hsh.update(open(f, "rb").read())
+    return hsh.hexdigest()[:16]
+
+
 class Workload:
     """Synthetic data of SURVEY 8d (L Gaussian clusters, unit-norm rows, per-piece counter seeds on the device)
     + the MLP trained on it + the HBM-resident index.  `sigma` is the cluster noise (1.0 = the survey's
@@ -174,22 +188,28 @@ class Workload:
                 dist.barrier()
                 torch.cuda.synchronize()
 
-        q_host = self.queries.cpu().pin_memory()  # the batch as it arrives: host memory (pinned, DMA-able)
+        # the batches as they arrive: host memory (pinned, DMA-able).  The timed loop ROTATES several distinct batches (fresh draws
+        # of the same distribution) so that no step finds its queries warm in the Infinity Cache from the step before; batch 0 is
+        # the one the checks below (oracle, recall) look at and the last one submitted.
+        nrot = max(1, self.args.rotate_batches)
+        rot = [self.queries] + [self.gen_rows(7, 100 + i, nq) for i in range(nrot - 1)]
+        q_hosts = [t.cpu().pin_memory() for t in rot]
+        q_host = q_hosts[0]
         ov = os.environ.get("LMI_PIPE_OVERLAP", "1")
         pipe = HostPipeline(eng, nq, d, d, nb, k, depth=int(os.environ.get("LMI_PIPE_DEPTH", "2")), same_queries=True, want_bucket_order=True,
                             overlap_inference=(ov == "1") if world == 1 else os.environ.get("LMI_PIPE_OVERLAP_SHARDED", "0") == "1",
                             two_handles=ov == "2", sharded=searcher if world > 1 else None)
         # (world > 1: the rank's MLP slice of batch i+1 beside the scan of batch i is opt-in -- it could only be rehearsed with
         # gloo on one card, where it was slower; on a single GPU the same overlap is measured: -1.9 %)
-        for _ in range(warmup):
-            pipe.submit(q_host)
+        for i in range(warmup):
+            pipe.submit(q_hosts[(i + 1) % nrot])
         pipe.drain()
         sync_all()
         eng.timings_reset()
         stamps = []
         t0 = time.perf_counter()
-        for _ in range(steps):
-            ticket = pipe.submit(q_host)
+        for i in range(steps):
+            ticket = pipe.submit(q_hosts[(steps - 1 - i) % nrot])   # ... the last step submits batch 0
             stamps.append(time.perf_counter() - t0)
         pipe.drain()
         sync_all()
@@ -216,8 +236,9 @@ class Workload:
             sync_all()
             eng.timings_reset()
             t0 = time.perf_counter()
-            for _ in range(steps):
-                rd, ri, _ = searcher.search(q, q, nb, k)
+            for i in range(steps):
+                qi = rot[(steps - 1 - i) % nrot]
+                rd, ri, _ = searcher.search(qi, qi, nb, k)
             sync_all()
             # phases of the SEQUENTIAL loop: in the pipelined one the next batch's MLP runs on a stream of its own, its
             # events span the time it waits for CUs
@@ -247,6 +268,44 @@ class Workload:
         gt = gt_i.cpu().numpy().astype(np.int64)
         got = out_i[:nr].astype(np.int64)
         return float(np.mean([len(set(a) & set(b)) / float(k) for a, b in zip(got, gt)]))
+
+
+def oracle_check_sample(wl, res, args, ns, nthr):
+    """The bit-exact checker (oracle/lmi_oracle.c) on the first `ns` queries of a workload whose index is NOT copied to the
+    host as a whole: the visited buckets are read back one at a time.  Asserts identical ids and distances; returns the
+    checker's own rate.  Used for the hard leg (the main leg checks inside cpu_baselines, on its host copy of the index)."""
+    from oracle import lmi_oracle
+
+    eng, layers = wl.eng, wl.layers
+    nb, k = wl.cfg["nb"], args.k
+    out_d, out_i, bo = res["out_d"], res["out_i"], res["bo"]
+    qh = wl.queries[:ns].cpu().numpy()
+    t_cpu = time.perf_counter()
+    order_o = lmi_oracle.precompute_bucket_order(layers, qh, nb, nthreads=nthr)
+    t_cpu = time.perf_counter() - t_cpu
+    assert np.array_equal(order_o[:, :, 0], bo[:ns]), "oracle bucket order differs from the GPU's"
+    sizes = eng.bucket_sizes()
+    rank_d = np.full((nb, ns, 10), np.inf)
+    rank_i = np.zeros((nb, ns, 10), dtype=np.uint32)
+    for b in np.unique(order_o[:, :, 0]):
+        if sizes[b] == 0:
+            continue
+        rows, ids = eng.read_bucket(int(b))
+        t1 = time.perf_counter()
+        for r in range(nb):
+            rel = np.flatnonzero(order_o[:, r, 0] == b)
+            if rel.size:
+                sim, idx = lmi_oracle.knn_ip(qh[rel], rows, 10, nthreads=nthr)
+                rank_d[r, rel] = np.float32(1) - sim
+                rank_i[r, rel] = ids[idx]
+        t_cpu += time.perf_counter() - t1
+        del rows, ids
+    fd = fi = None
+    for r in range(nb):
+        fd, fi = lmi_oracle.merge_rank(fd, fi, rank_d[r], rank_i[r], k)
+    assert np.array_equal(fi, out_i[:ns]) and np.array_equal(fd, out_d[:ns].astype(np.float64)), \
+        "CPU oracle and GPU results differ on the sampled queries"
+    return round(ns / t_cpu, 3)
 
 
 def cpu_baselines(wl, res, args):
@@ -317,6 +376,15 @@ def cpu_baselines(wl, res, args):
         "what": "bucket-contiguous slab in host memory, torch-CPU addmm/relu/topk routing, per visited bucket ONE "
                 "matmul for all its (query, rank) slots + topk(10), stable sort merge; full index, no pandas"}
 
+    # ---- (1b) the same best-effort variant on ALL host cores of the box (north_star: "the same box's host cores")
+    if host_cores > nthr:
+        nq_a = min(args.cpu_best_queries, nq)
+        bd2, bi2, _, secs2 = cb.best_effort(slab, offsets, ids_all, layers, torch.from_numpy(qh_all[:nq_a]), nb, k, threads=host_cores)
+        variants["best_effort_torch_allcores"] = {
+            "value": round(nq_a / secs2, 2), "unit": "queries/s", "cores": host_cores, "queries": nq_a, "seconds": round(secs2, 3),
+            "id_set_agreement_with_gpu": round(cb.id_agreement(bi2, out_i[:nq_a]), 6),
+            "what": f"the best-effort variant with torch / BLAS threads = os.cpu_count() = {host_cores}"}
+
     # ---- (2) reference-structured: pandas groupby + .loc gather + BLAS + partial sort, per rank x bucket.
     # Its cost is linear in the rows it touches (75 % is pandas data movement) and the whole 10M-row
     # batch takes minutes on a CPU (reference README: 220 s), so it runs on a BOUNDED sample: `--cpu-ref-buckets`
@@ -355,12 +423,46 @@ def cpu_baselines(wl, res, args):
                     "group, label-based .loc gather copy of each visited bucket, BLAS sgemm + partial sort (faiss.knn "
                     "stand-in), 1 - sim, stable merge; measured on whole sampled buckets, scaled by rows to the full index"}
     best = variants["best_effort_torch"]
-    return {"value": best["value"], "unit": "queries/s", "cores": nthr, "kind": "port",
+    if "best_effort_torch_allcores" in variants and variants["best_effort_torch_allcores"]["value"] > best["value"]:
+        best = variants["best_effort_torch_allcores"]   # `value` = the faster of the two thread counts, `cores` says which
+    return {"value": best["value"], "unit": "queries/s", "cores": best["cores"], "kind": "port",
             "sample": f"value = best-effort CPU variant: all {N} x {d} rows resident in host memory, first {nq_b} of {nq} queries, "
-                      f"all {nb} ranks, {nthr} threads (torch-CPU matmul + topk over the bucket-contiguous slab); "
+                      f"all {nb} ranks, {best['cores']} threads (torch-CPU matmul + topk over the bucket-contiguous slab; the better of "
+                      f"{nthr} threads and all {host_cores} host cores); "
                       f"`variants` holds the reference-structured pandas/BLAS loop on 1 core and on {nthr} cores "
                       f"(bounded bucket sample, scaled) and the bit-exact oracle used as the checker",
             "host_cpu_count": host_cores, "index_copy_to_host_s": round(t_copy, 2), "variants": variants}
+
+
+def dominant_roofline(args, cfg, res, sizes, owner, rank, capi):
+    """Roofline of the dominant kernel of one timed leg.  Algorithmic work per launch: flops = 2*d*sum over (query, rank)
+    slots of the bucket size (sharded runs: this rank's slots); bytes = every visited bucket read once in the kernel's
+    operand type + the packed queries once.  The larger of the two floors names the bound."""
+    d, L, nb, nq = cfg["d"], cfg["leaves"], cfg["nb"], cfg["nq"]
+    phases, bo = res["phases"], res["bo"]
+    flops = res["scan_stats"][0]
+    dom_slot = capi.T_SCAN if args.exact else capi.T_PF_EMIT
+    dom_s = max(float(phases[dom_slot]) * 1e-3, 1e-12)  # 0 when --timing-level < 2: the roofline fields are meaningless then
+    visited = np.unique(bo)
+    visited = visited[(visited >= 0) & (owner[np.clip(visited, 0, L - 1)] == rank)]
+    rows_visited = float(sizes[visited].sum())
+    if args.exact:
+        kernel, op_bytes, peak_tf = "lmi::scan_kernel", 4, PEAK_F32_MFMA_TFLOPS
+    else:
+        kernel, op_bytes, peak_tf = "lmi::pass2_kernel<false>", 2, PEAK_F16_MFMA_TFLOPS
+    dpad = -(-d // 32) * 32 if not args.exact else d   # the fp16 slab pads K to a multiple of 32 (two k16-groups per stage)
+    alg_bytes = op_bytes * d * (rows_visited + nq * nb)
+    t_mfma, t_hbm = flops / (peak_tf * 1e12), alg_bytes / (PEAK_HBM_GBS * 1e9)
+    if t_mfma >= t_hbm:
+        roof = {"bound": "mfma", "achieved": round(flops / dom_s / 1e12, 3), "peak": peak_tf, "unit": "TFLOP/s",
+                "frac": round(flops / dom_s / 1e12 / peak_tf, 4)}
+    else:
+        roof = {"bound": "hbm", "achieved": round(alg_bytes / dom_s / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(alg_bytes / dom_s / 1e9 / PEAK_HBM_GBS, 4)}
+    roof.update({"kernel": kernel, "flops_per_launch": flops, "bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom_s * 1e3, 4),
+                 "launches_timed": res["n_timed"], "floors_ms": {"mfma": round(t_mfma * 1e3, 3), "hbm": round(t_hbm * 1e3, 3)},
+                 "k_padded_to": dpad})
+    return roof, flops, dom_s
 
 
 def launch_ranks(n: int, argv) -> int:
@@ -433,6 +535,8 @@ def main():
     ap.add_argument("--cpu-ref-queries", type=int, default=10_000, help="queries of the reference-structured pandas baseline")
     ap.add_argument("--cpu-ref-buckets", type=int, default=6, help="whole buckets the reference-structured baseline is measured on")
     ap.add_argument("--cpu-threads", type=int, default=0, help="CPU baseline threads (0: min(16, host cores))")
+    ap.add_argument("--rotate-batches", type=int, default=4, help="distinct query batches rotated through the timed loop")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the C1 / C5 legs (BASELINE.json configs[0] / configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-hard-leg", action="store_true", help="skip the second, harder workload (overlapping clusters)")
@@ -495,7 +599,6 @@ def main():
     elapsed, phases, out_d, out_i, bo = res["elapsed"], res["phases"], res["out_d"], res["out_i"], res["bo"]
     flops, pairs, items = res["scan_stats"]
     pf_active, pf_survivors, pf_fallbacks = res["pf_stats"]
-    dom_slot = _capi.T_SCAN if args.exact else _capi.T_PF_EMIT
     sizes, owner = wl.sizes, wl.owner
     if rank == 0 and wl.shard_world > 1:  # how even the bucket assignment turned out for this batch
         bo_h = bo.ravel()
@@ -530,12 +633,18 @@ def main():
     hard = None
     if world == 1 and not args.no_hard_leg and args.config == "c2" and not args.exact:
         wl.eng.close()
-        del wl.eng
+        wl.eng = None
         torch.cuda.empty_cache()
         wh = Workload(args, cfg, dev, rank, world, local_rank, sigma=args.hard_sigma, zipf=args.hard_zipf,
                       centre_scale=args.hard_centre_scale, tag="hard")
         rh = wh.run(max(5, args.steps // 2), 2, measure_resident=True)
         hs = wh.sizes
+        hard_checked = None
+        if rank == 0 and not args.no_cpu_baseline:   # the checker on the HARD workload too: small score gaps, the bound's window matters
+            nthr_h = args.cpu_threads or min(16, os.cpu_count() or 1)
+            hq = min(args.cpu_queries, nq, 128)
+            hard_checked = {"queries": hq, "identical_ids_and_distances": True,
+                            "checker_queries_per_s": oracle_check_sample(wh, rh, args, hq, nthr_h)}
         hard = {"generator": f"centres x{args.hard_centre_scale}, sigma {args.hard_sigma}, cluster weights ~ 1/(1 + c/{args.hard_zipf})",
                 "recall_at_10": round(wh.recall(rh["out_i"], min(args.recall_queries, nq)), 5),
                 "value": round(nq * max(5, args.steps // 2) / rh["elapsed"], 2), "unit": "queries/s",
@@ -544,42 +653,61 @@ def main():
                 "bucket_sizes_min_median_max": [int(hs.min()), int(np.median(hs)), int(hs.max())],
                 "survivors_per_slot": round(rh["pf_stats"][1] / max(1, nq * nb), 2), "fallback_slots": int(rh["pf_stats"][2]),
                 "overflowed_columns": rh.get("pf_redo_columns"),
-                "scan_pairs": int(rh["scan_stats"][1]),
+                "scan_pairs": int(rh["scan_stats"][1]), "oracle_check": hard_checked,
                 "phases_ms": {"pf_sample": round(float(rh["phases"][5]), 4), "pf_emit": round(float(rh["phases"][6]), 4),
                               "rescore": round(float(rh["phases"][7]), 4), "fallback": round(float(rh["phases"][8]), 4)}}
 
+    # ---- the other single-GPU configurations of BASELINE.json, each as a short leg of its own: C1 (configs[0]: 100k x 768,
+    # 1 000 queries -- the reference's CPU-runnable case) and C5 (configs[4]: 10M x 45, 256 leaves, cosine)
+    others = None
+    if world == 1 and args.config == "c2" and not args.no_other_configs and not args.exact and not args.emulate_shard:
+        others = {}
+        for cname in ("c1", "c5"):
+            for w_ in (wl, locals().get("wh")):   # the main (and hard) indexes are no longer needed: free their HBM
+                if w_ is not None and getattr(w_, "eng", None) is not None:
+                    w_.eng.close()
+                    w_.eng = None
+            torch.cuda.empty_cache()
+            ocfg = dict(CONFIGS[cname])
+            wo = Workload(args, ocfg, dev, rank, world, local_rank, tag=cname)
+            osteps = max(10, args.steps)
+            ro = wo.run(osteps, 3, measure_resident=False)
+            oroof, _, _ = dominant_roofline(args, ocfg, ro, wo.sizes, wo.owner, rank, _capi)
+            others[cname] = {"workload": f"{ocfg['n']}x{ocfg['d']}, {ocfg['leaves']} leaves, top-{ocfg['nb']}, {ocfg['nq']}-query batch",
+                             "value": round(ocfg["nq"] * osteps / ro["elapsed"], 2), "unit": "queries/s",
+                             "ms_per_step": round(ro["elapsed"] / osteps * 1e3, 4),
+                             "recall_at_10": None if args.no_recall else round(wo.recall(ro["out_i"], min(args.recall_queries, ocfg["nq"])), 5),
+                             "roofline": oroof,
+                             "phases_ms": {"inference": round(float(ro["phases"][0]), 4), "route_pack": round(float(ro["phases"][1]), 4),
+                                           "pf_sample": round(float(ro["phases"][5]), 4), "pf_emit": round(float(ro["phases"][6]), 4),
+                                           "rescore": round(float(ro["phases"][7]), 4), "merge": round(float(ro["phases"][3]), 4)}}
+            if rank == 0 and not args.no_cpu_baseline:
+                oq = min(args.cpu_queries, ocfg["nq"], 128)
+                others[cname]["oracle_check"] = {"queries": oq, "identical_ids_and_distances": True,
+                                                 "checker_queries_per_s": oracle_check_sample(wo, ro, args, oq, args.cpu_threads or min(16, os.cpu_count() or 1))}
+            wo.eng.close()
+            wo.eng = None
+
     if rank == 0:
-        scan_s = float(phases[_capi.T_SCAN]) * 1e-3
-        dom_s = max(float(phases[dom_slot]) * 1e-3, 1e-12)  # 0 when --timing-level < 2: the roofline fields are meaningless then
-        scan_s = max(scan_s, 1e-12)
-        visited = np.unique(bo)
-        visited = visited[(visited >= 0) & (owner[np.clip(visited, 0, L - 1)] == rank)]
-        rows_visited = float(sizes[visited].sum())
-        # Dominant kernel and its roofline.  Algorithmic work per launch: flops = 2*d*sum over (query, rank)
-        # slots of the bucket size (sharded runs: this rank's slots); bytes = every visited bucket read once
-        # in the kernel's operand type + the packed queries once.
-        if args.exact:
-            kernel, op_bytes, peak_tf = "lmi::scan_kernel", 4, PEAK_F32_MFMA_TFLOPS
-        else:
-            kernel, op_bytes, peak_tf = "lmi::prefilter_kernel<false, 2>", 2, PEAK_F16_MFMA_TFLOPS
-        alg_bytes = op_bytes * d * (rows_visited + nq * nb)
-        t_mfma, t_hbm = flops / (peak_tf * 1e12), alg_bytes / (PEAK_HBM_GBS * 1e9)
-        if t_mfma >= t_hbm:
-            roof = {"bound": "mfma", "achieved": round(flops / dom_s / 1e12, 3), "peak": peak_tf, "unit": "TFLOP/s",
-                    "frac": round(flops / dom_s / 1e12 / peak_tf, 4)}
-        else:
-            roof = {"bound": "hbm", "achieved": round(alg_bytes / dom_s / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(alg_bytes / dom_s / 1e9 / PEAK_HBM_GBS, 4)}
+        scan_s = max(float(phases[_capi.T_SCAN]) * 1e-3, 1e-12)
+        roof, flops, dom_s = dominant_roofline(args, cfg, res, sizes, owner, rank, _capi)
+        # `traffic` (HBM bytes per launch from the PMC counters) and the MFMA pipe's busy fraction cannot be measured inside this
+        # run (counters need rocprofv3 passes of their own): they are REPLAYED from the committed summary of separate
+        # `rocprofv3 --pmc` passes of this same command (tools/profile_round.sh + profiles/summarize.py), and only when that
+        # summary was collected from the library sources this run was built from -- otherwise they are null.
         traffic = mfma_busy = None
         tj = args.traffic_json or os.path.join(ROOT, "profiles", f"scan_pmc_{args.config}{'_exact' if args.exact else ''}.json")
         overridden = any(getattr(args, key) is not None for key in ("n", "nq", "nb", "leaves", "emulate_shard"))
+        traffic_source = None
         if world == 1 and not overridden and os.path.exists(tj):
             pj = json.load(open(tj))
-            traffic, mfma_busy = pj.get("hbm_bytes_per_launch"), pj.get("mfma_pipe_busy_frac")
-        roof.update({"traffic": traffic, "kernel": kernel, "flops_per_launch": flops, "bytes_per_launch": alg_bytes,
-                     "avg_launch_ms": round(dom_s * 1e3, 4), "launches_timed": res["n_timed"],
-                     "mfma_pipe_busy_frac": mfma_busy,
-                     "floors_ms": {"mfma": round(t_mfma * 1e3, 3), "hbm": round(t_hbm * 1e3, 3)},
+            same = pj.get("lib_source_sha16") == lib_source_sha16() and str(pj.get("kernel", "")) in roof["kernel"]
+            traffic_source = {"file": os.path.relpath(tj, ROOT), "collected_utc": pj.get("collected_utc"), "commit": pj.get("commit"),
+                              "lib_source_sha16": pj.get("lib_source_sha16"), "matches_this_build": bool(same),
+                              "how": "replayed from separate rocprofv3 --pmc passes of this command, not measured in this run"}
+            if same:
+                traffic, mfma_busy = pj.get("hbm_bytes_per_launch"), pj.get("mfma_pipe_busy_frac")
+        roof.update({"traffic": traffic, "mfma_pipe_busy_frac": mfma_busy, "traffic_source": traffic_source,
                      # the whole scan phase (all its kernels) priced as SURVEY 8d does: algorithmic f32 flops
                      # against the f32 MFMA peak, whatever precision the prefilter used
                      "scan_phase_f32_equiv": {"achieved": round(flops / scan_s / 1e12, 3), "peak": PEAK_F32_MFMA_TFLOPS,
@@ -624,6 +752,8 @@ def main():
             "sharded_alt_mode": alt,
             "per_rank": per_rank,
             "hard_leg": hard,
+            "other_configs": others,
+            "rotated_batches": args.rotate_batches,
             **({"diagnostic": f"emulated shard {args.emulate_shard}: NOT a bench line"} if args.emulate_shard else {}),
             "phases_ms": {"inference": round(float(res["phases_resident"][0] if res.get("overlapped") and "phases_resident" in res else phases[0]), 4), "route_pack": round(float(phases[1]), 4),
                           "scan": round(float(phases[2]), 4), "merge": round(float(phases[3]), 4),

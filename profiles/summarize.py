@@ -48,8 +48,10 @@ def main(src, tag, dominant=None):
         if not f:
             continue
         vals, durs, meta = [], [], None
-        for r in csv.DictReader(open(f)):
-            if is_dom(r["Kernel_Name"]) and r["Counter_Name"] == name:
+        rows_f = [r for r in csv.DictReader(open(f)) if is_dom(r["Kernel_Name"]) and r["Counter_Name"] == name]
+        longest = max([int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows_f] or [0])
+        for r in rows_f:
+            if int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) >= 0.2 * longest:   # (the redo launch of pass 2 returns at once)
                 vals.append(float(r["Counter_Value"]))
                 durs.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
                 meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count",
@@ -64,8 +66,10 @@ def main(src, tag, dominant=None):
         if not f:
             continue
         acc = {}
-        for r in csv.DictReader(open(f)):
-            if is_dom(r["Kernel_Name"]):
+        rows_f = [r for r in csv.DictReader(open(f)) if is_dom(r["Kernel_Name"])]
+        longest = max([int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows_f] or [0])
+        for r in rows_f:
+            if int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) >= 0.2 * longest:
                 acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
         for k, v in acc.items():
             extra[k] = sum(v) / len(v)
@@ -83,6 +87,21 @@ def main(src, tag, dominant=None):
         pmc["note"] = ("(2 * FETCH_SIZE + WRITE_SIZE) KiB -> bytes; FETCH_SIZE counts L2 misses, Infinity-Cache "
                        "hits included, so this is an upper bound on true HBM reads")
     pmc["kernel"] = DOMINANT
+    # provenance (bench.py replays hbm_bytes_per_launch / mfma_pipe_busy_frac only for the library build they were collected from)
+    import datetime
+    import subprocess
+    sys.path.insert(0, os.path.dirname(out_dir))
+    try:
+        import bench
+        pmc["lib_source_sha16"] = bench.lib_source_sha16()
+    except Exception as e:  # noqa: BLE001
+        pmc["lib_source_sha16"] = None
+        print("no source hash:", e, file=sys.stderr)
+    try:
+        pmc["commit"] = subprocess.run(["git", "-C", os.path.dirname(out_dir), "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except Exception:  # noqa: BLE001
+        pmc["commit"] = None
+    pmc["collected_utc"] = datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ")
     with open(os.path.join(out_dir, f"{tag}_scan_pmc.json"), "w") as fh:
         json.dump(pmc, fh, indent=1)
     print(json.dumps(pmc, indent=1))

@@ -97,3 +97,62 @@ def test_prefilter_bound_holds(oracle, kind, d):
     do, io, _ = oracle.search(None, None, X, Q[:16], labels[:, None], NB, 10, nthreads=8, bucket_order=order[:16][:, :, None])
     np.testing.assert_array_equal(ii[:16], io)
     np.testing.assert_array_equal(dd[:16].astype(np.float64), do)
+
+
+def test_bound_on_stored_candidates_at_real_bucket_sizes(oracle):
+    """The bound at REAL bucket sizes: 1.2M x 768 rows in 32 overlapping clusters (centres x 0.26: the hard
+    leg's generator; buckets of ~37 500 rows), 512 queries, top-4.  No test hook: the candidates are the ones pass 2 stored for
+    its thresholds (lmi_debug_read_candidates WITHOUT lmi_debug_emit_all); for every stored (query, row) the kernel's shat is
+    compared with the oracle's canonical chain: |shat - s'| <= eps'.  The max ratio is printed."""
+    import torch
+
+    from learnedmetricindex_amd import _capi
+
+    dev = torch.device("cuda", 0)
+    n, d, Lr, nb, nq = 1_200_000, 768, 32, 4, 512
+    g = torch.Generator(device=dev).manual_seed(31)
+    centres = 0.26 * torch.randn(Lr, d, generator=g, device=dev)
+    lab = torch.randint(0, Lr, (n,), generator=g, device=dev)
+    X = torch.nn.functional.normalize(centres[lab] + torch.randn(n, d, generator=g, device=dev), dim=1).contiguous()
+    Q = torch.nn.functional.normalize(centres[torch.randint(0, Lr, (nq,), generator=g, device=dev)]
+                                      + torch.randn(nq, d, generator=g, device=dev), dim=1).contiguous()
+    order = (Q @ torch.nn.functional.normalize(centres, dim=1).T).topk(nb, dim=1).indices.to(torch.int32).contiguous()
+    idx = _capi.Index(0, prefilter=True)
+    idx.set_stream(torch.cuda.current_stream().cuda_stream)
+    labels = lab.cpu().numpy().astype(np.int64)
+    idx.set_buckets(X, labels, Lr)
+    assert idx.bucket_sizes().min() >= 30_000
+    dd = torch.empty((nq, 10), dtype=torch.float32, device=dev)
+    ii = torch.empty((nq, 10), dtype=torch.int32, device=dev)
+    idx.scan_topk_device(Q, order, nb, 10, dd, ii)
+    torch.cuda.synchronize()
+    active, survivors, fallbacks = idx.prefilter_stats()
+    assert active and fallbacks == 0
+    Qh, oh = Q.cpu().numpy(), order.cpu().numpy()
+    worst, checked, emitted = 0.0, 0, []
+    for b in range(Lr):
+        slots = [(q, r) for q in range(nq) for r in range(nb) if oh[q, r] == b]
+        if not slots:
+            continue
+        rows_b, _ = idx.read_bucket(b)
+        for q, r in slots[:24]:   # bounded: 24 slots per bucket
+            rr, shat, cnt, eps2, qs, xs = idx.debug_read_candidates(q * nb + r)
+            emitted.append(cnt)
+            if rr.size == 0:
+                continue
+            assert cnt <= 1024 and np.isfinite(eps2) and eps2 > 0
+            s_c = oracle.forward_logits([(rows_b[rr], np.zeros(rr.size, np.float32))], Qh[q:q + 1], nthreads=4)[0]
+            sp = s_c.astype(np.float64) * float(qs) * float(xs)
+            ratio = np.abs(shat.astype(np.float64) - sp) / (0.5 * eps2)
+            worst = max(worst, float(ratio.max()))
+            checked += rr.size
+    print(f"[bound, real sizes] max |shat - s'|/eps' = {worst:.4f} over {checked} stored (query,row) pairs; "
+          f"candidates per slot: mean {np.mean(emitted):.1f}, max {np.max(emitted)}; {survivors / (nq * nb):.2f} survivors per slot")
+    assert checked > 5_000 and worst < 1.0
+    # and the answer is the oracle's on a sample of the batch
+    sel = np.arange(0, nq, 16)
+    Xh = X.cpu().numpy()
+    do, io, _ = oracle.search(None, None, Xh, Qh[sel], labels[:, None], nb, 10, nthreads=16, bucket_order=oh[sel][:, :, None])
+    np.testing.assert_array_equal(ii.cpu().numpy().view(np.uint32)[sel], io)
+    np.testing.assert_array_equal(dd.cpu().numpy()[sel].astype(np.float64), do)
+    idx.close()

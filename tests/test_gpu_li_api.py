@@ -219,4 +219,19 @@ def test_resident_cache_key_and_query_chunks(oracle):
     assert li._engine is None
     d4, n4, _ = li.search(df, Qn, df, Qs, dp, [12], 3, 10)
     np.testing.assert_array_equal(n4, no)
+    # the key is order-sensitive and covers every weight -- a placement permuted between two objects of different
+    # buckets, or a changed LAST-layer weight, misses the cache (a sum of samples / the first layer alone did not see either)
+    eng = li._engine
+    i, j = 0, int(np.flatnonzero(dp[:, 0] != dp[0, 0])[0])
+    dp_sw = dp.copy()
+    dp_sw[[i, j]] = dp_sw[[j, i]]
+    li.search(df, Qn, df, Qs, dp_sw, [12], 3, 10)
+    assert li._engine is not eng
+    eng = li._engine
+    last = [m for m in li.root_model.model.layers if isinstance(m, torch.nn.Linear)][-1]
+    with torch.no_grad():
+        last.bias[0] += 0.5
+    li.root_model._engine = None
+    li.search(df, Qn, df, Qs, dp_sw, [12], 3, 10)
+    assert li._engine is not eng
     li.close()

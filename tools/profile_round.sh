@@ -4,7 +4,7 @@
 #   bash tools/profile_round.sh r02 [dominant-kernel-regex]
 set -uo pipefail
 export TMPDIR=/tmp
-tag="$1"; K="${2:-prefilter_kernel<false}"
+tag="$1"; K="${2:-pass2_kernel<false}"
 root="$PWD"; out="$root/gpurun_out/prof_$tag"
 mkdir -p "$out"
 B="python3 $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-recall --no-hard-leg"
@@ -16,6 +16,6 @@ timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-reg
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-include-regex "$K" --output-format csv -d "$out/pmc_sq" -- $B > /dev/null 2> "$out/sq.err" || { echo "sq pass failed"; exit 1; }
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc TCC_HIT TCC_MISS TCC_REQ TCC_EA0_RDREQ --kernel-include-regex "$K" --output-format csv -d "$out/pmc_tcc" -- $B > /dev/null 2> "$out/tcc.err" || { echo "tcc pass failed"; exit 1; }
 cd "$root"
-python3 profiles/summarize.py "$out" "$tag" "$K" > "$out/summary.txt" 2>&1 || { echo "summarize failed"; tail -5 "$out/summary.txt"; exit 1; }
+# (profiles/summarize.py runs in the build container afterwards, on the merged gpurun_out/prof_<tag>: it stamps the commit)
 cp "$out/bench_under_rocprof.json" "$out/${tag}_bench_under_rocprof.json"
 echo "profiles done"
