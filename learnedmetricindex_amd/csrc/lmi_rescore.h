@@ -18,6 +18,8 @@
 // Used when d % 4 == 0 and d <= RS_MAXD; other shapes keep select_rescore_kernel.  Results are bit-identical
 // (same chain, same selection rule); tests/test_gpu_prefilter.py runs both.
 #pragma once
+#include <type_traits>
+
 #include "lmi_prefilter.h"
 
 namespace lmi {
@@ -205,16 +207,19 @@ __global__ __launch_bounds__(64 * RC_WAVES, 1) void rescore_kernel(RescoreParams
     __builtin_amdgcn_wave_barrier();
     const int nchunks = (d + RC_CHUNK - 1) / RC_CHUNK;
     const unsigned qaddr = (unsigned)reinterpret_cast<uintptr_t>(qs);
-    for (int base = 0; base < total; base += RC_ROWS) {
+    // One batch of <= RC_ROWS chains.  NP = LDS-DMA pieces per chunk that hold rows of THIS batch (a wave re-scores ~13 rows since
+    // the bound is per query: 2 pieces instead of the 9 that cover 64 rows -- issuing the unused ones was most of the kernel's time).
+    auto run_batch = [&](auto np_c, int base) {
+        constexpr int NP = decltype(np_c)::value;
         const int nrows = min(RC_ROWS, total - base);
         // DMA plan: piece pc, lane i writes LDS bytes [pc*1024 + 16 i, +16) of the chunk buffer = row r, byte col of the
-        // 528-byte pitch; its source is row r's chunk + col.  (r, col) do not depend on the chunk: one source
-        // pointer per piece, advanced by 512 bytes per chunk.  Lanes in the pad column or past the batch read the
+        // pitch; its source is row r's chunk + col.  (r, col) do not depend on the chunk: one source
+        // pointer per piece, advanced by the chunk's bytes per chunk.  Lanes in the pad column or past the batch read the
         // first row's segment again (an L2 hit nobody uses).
-        const float* src[RC_PIECES];
-        unsigned colb[RC_PIECES];
+        const float* src[NP];
+        unsigned colb[NP];
 #pragma unroll
-        for (int pc = 0; pc < RC_PIECES; ++pc) {
+        for (int pc = 0; pc < NP; ++pc) {
             const int o = pc * 1024 + lane * 16;
             const int r = o / RC_PITCH;
             const int cb = o - r * RC_PITCH;
@@ -230,10 +235,10 @@ __global__ __launch_bounds__(64 * RC_WAVES, 1) void rescore_kernel(RescoreParams
         auto issue = [&](int c, unsigned char* buf) {
             const int cbytes = min(RC_CHUNK, d - c * RC_CHUNK) * 4;  // the last chunk of a row may be short
 #pragma unroll
-            for (int pc = 0; pc < RC_PIECES; ++pc) {
+            for (int pc = 0; pc < NP; ++pc) {
                 // a lane past the row's end re-reads the row's first bytes of this chunk (kept inside the row)
-                const float* s = src[pc] + c * RC_CHUNK - ((int)colb[pc] < cbytes ? 0 : (int)colb[pc] / 4);
-                glds16(reinterpret_cast<const float4*>(s), reinterpret_cast<float4*>(buf + pc * 1024));
+                const float* s_ = src[pc] + c * RC_CHUNK - ((int)colb[pc] < cbytes ? 0 : (int)colb[pc] / 4);
+                glds16(reinterpret_cast<const float4*>(s_), reinterpret_cast<float4*>(buf + pc * 1024));
             }
         };
         float acc = 0.0f;
@@ -245,9 +250,9 @@ __global__ __launch_bounds__(64 * RC_WAVES, 1) void rescore_kernel(RescoreParams
             unsigned char* cur = mine + slot * RC_BUF;
             const int ahead = min(RC_DEPTH - 1, nchunks - 1 - c);  // chunks that may stay in flight once chunk c has landed
             if (c + RC_DEPTH - 1 < nchunks) issue(c + RC_DEPTH - 1, mine + (slot == 0 ? RC_DEPTH - 1 : slot - 1) * RC_BUF);
-            if (ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * RC_PIECES) : "memory");
-            else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * RC_PIECES) : "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(RC_PIECES) : "memory");
+            if (ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * NP) : "memory");
+            else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NP) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NP) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             slot = slot + 1 == RC_DEPTH ? 0 : slot + 1;
             if (lane < nrows) {
@@ -281,6 +286,12 @@ __global__ __launch_bounds__(64 * RC_WAVES, 1) void rescore_kernel(RescoreParams
             }
         }
         if (lane < nrows) ksc[base + lane] = acc;
+    };
+    for (int base = 0; base < total; base += RC_ROWS) {
+        const int np = (min(RC_ROWS, total - base) * RC_PITCH + 1023) / 1024;   // wave-uniform
+        if (np <= 2) run_batch(std::integral_constant<int, 2>{}, base);
+        else if (np <= 4 && RC_PIECES > 4) run_batch(std::integral_constant<int, (RC_PIECES > 4 ? 4 : RC_PIECES)>{}, base);
+        else run_batch(std::integral_constant<int, RC_PIECES>{}, base);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
