@@ -144,7 +144,6 @@ struct lmi_index {
     bool rescore_streamed = true;  // lmi_rescore.h (LMI_RESCORE_SIMPLE=1 in the environment: select_rescore_kernel)
     int last_nslots = 0, last_nb = 0;
     bool last_fast = false;
-    bool pf_v2 = true;            // LMI_PF_V1=1: the round-2 prefilter kernels (lmi_prefilter.h) instead of lmi_pass2.h (A/B)
     bool pf_qbound = true;        // LMI_PF_QBOUND=0: per-bucket bounds only (query_bound_kernel off)
     bool pf_primary = true;       // LMI_PF_PRIMARY=0: pass 1 samples every column although one bound per query is used
     bool debug_emit_all = false;  // lmi_debug_emit_all
@@ -215,7 +214,6 @@ extern "C" LMI_API int lmi_create(int device, lmi_index** out) {
     }
     if (const char* e = getenv("LMI_RESCORE_SIMPLE")) h->rescore_streamed = !(e[0] && e[0] != '0');
     if (const char* e = getenv("LMI_PF_NO_REDO")) h->pf_redo = !(e[0] && e[0] != '0');
-    if (const char* e = getenv("LMI_PF_V1")) h->pf_v2 = !(e[0] && e[0] != '0');
     if (const char* e = getenv("LMI_PF_QBOUND")) h->pf_qbound = e[0] && e[0] != '0';
     if (const char* e = getenv("LMI_PF_PRIMARY")) h->pf_primary = e[0] && e[0] != '0';
     // per handle = per device (a process may hold handles on several devices; the attribute is per device)
@@ -303,7 +301,7 @@ extern "C" LMI_API int lmi_set_stream(lmi_index* h, void* s) {
 
 extern "C" LMI_API int lmi_set_chunk_rows(lmi_index* h, int rows) {
     if (!h) return fail("lmi_set_chunk_rows: NULL handle");
-    if (rows < PF_TILE_ROWS || rows % PF_TILE_ROWS) return fail("lmi_set_chunk_rows: rows must be a positive multiple of %d", PF_TILE_ROWS);
+    if (rows < P2_TILE_ROWS || rows % P2_TILE_ROWS) return fail("lmi_set_chunk_rows: rows must be a positive multiple of %d", P2_TILE_ROWS);
     if (h->building || h->built) return fail("lmi_set_chunk_rows: must be called before lmi_buckets_begin");
     h->chunk_rows = rows;
     h->chunk_rows_auto = false;
@@ -526,7 +524,7 @@ extern "C" LMI_API int lmi_buckets_begin(lmi_index* h, int64_t N, int d, int L, 
         long long owned_rows = 0;
         for (int b = 0; b < L; ++b) { max_rows = std::max(max_rows, h->h_nb_rows[b]); owned_rows += h->h_nb_rows[b]; }
         if (h->chunk_rows_auto)
-            h->chunk_rows = (int)std::min<long long>(2048, std::max<long long>(PF_TILE_ROWS, rup(owned_rows / 4096, PF_TILE_ROWS)));
+            h->chunk_rows = (int)std::min<long long>(2048, std::max<long long>(P2_TILE_ROWS, rup(owned_rows / 4096, P2_TILE_ROWS)));
         const int need = (int)rup(cdiv(max_rows, 1024), 256);
         if (need > h->chunk_rows) h->chunk_rows = need;
     }
@@ -987,8 +985,8 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     R.qt_base = R.order_tmp + L;
     R.grp_base1 = R.qt_base + (L + 1);
     R.grp_total1 = R.grp_base1 + (size_t)NGRP * (L + 1);
-    const bool v2 = (h->prefilter && h->have16) && h->pf_v2;
-    R.tile_cb = v2 ? P2_MAXCB : (h->prefilter && h->have16) ? 4 * PF_NG : 4;
+    const bool v2 = h->prefilter && h->have16;   // the prefilter's kernels: lmi_pass2.h (tiles of up to 12 col-blocks)
+    R.tile_cb = v2 ? P2_MAXCB : 4;
     R.sample_items = v2 ? 1 : 0;
     // one bound per QUERY is enough when the caller keeps the k <= 10 best over all ranks (query_bound_kernel, lmi_pass2.h): pass 1
     // then samples only each query's primary slot(s) -- a quarter of the columns at n_buckets = 4
@@ -996,7 +994,6 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     R.primary_nb = (qbound && h->pf_primary) ? nb : 0;
 
     const size_t ncols = (size_t)ncb_bound * 32;
-    int pf_parts = 4;
     FillRanges Z;
     Z.count = 0;
     bool fill_ok = true;
@@ -1016,13 +1013,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         CHK(h->cand_s.reserve(ncols * PF_CAP * 4));
         CHK(h->fallback.reserve((size_t)nslots * 4));
         CHK(h->nkeep.reserve((size_t)nslots * 4));
-        // pass-1 items per (bucket, query tile): enough of them to fill the chip.  The host only knows an
-        // estimate of the (bucket, tile) pairs: this rank's share of the slots / 256 + its buckets.
-        long long owned_rows = 0, owned_buckets = 0;
-        for (int b = 0; b < L; ++b) { owned_rows += h->h_nb_rows[b]; owned_buckets += h->h_nb_rows[b] > 0; }
-        const double pairs_est = (double)nslots * (double)owned_rows / (double)std::max<long long>(1, h->N) / (32.0 * 4 * PF_NG) + (double)owned_buckets;
-        pf_parts = pairs_est * 4 >= 4.0 * h->num_cus ? 4 : pairs_est * 8 >= 4.0 * h->num_cus ? 8 : PF_PARTS_MAX;
-        const size_t bound_words = v2 ? ncols * P2_NSL * 16 : ncols * pf_parts * 4 * PF_LK;
+        const size_t bound_words = ncols * P2_NSL * 16;   // pass 1: [P2_NSL lists][16 slots][columns]
         CHK(h->pf_bound.reserve(bound_words * 4 + 4096));  // + room for the developer builds' phase stamps
         fill(h->pf_bound.p, (long long)bound_words, 0xFF800000u /* -inf */);
         fill(h->cand_cnt.p, (long long)ncols, 0u);
@@ -1108,13 +1099,10 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         F.grp_base = R.grp_base;
         F.grp_n = R.grp_n;
         F.grp_total = R.grp_total;
-        F.qt_base = R.qt_base;
-        F.by_work = R.order_tmp;
         F.grp_base1 = R.grp_base1;
         F.grp_total1 = R.grp_total1;
         F.ncols = (long long)ncols;
         F.head = S.head;
-        F.parts = pf_parts;
         F.bound = h->pf_bound.as<float>();
         F.bound1 = S.col_thr;
         F.eps2 = h->eps2.as<float>();
@@ -1122,13 +1110,12 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         F.cand_row = h->cand_row.as<unsigned>();
         F.cand_s = h->cand_s.as<float>();
         F.redo_count = nullptr; F.redo_bucket = nullptr; F.redo_col = nullptr;
-        h->stamps_off = ((v2 ? ncols * P2_NSL * 16 : ncols * pf_parts * 4 * PF_LK) * 4 + 255) / 256 * 256;
+        h->stamps_off = (ncols * P2_NSL * 16 * 4 + 255) / 256 * 256;
         F.stamps = reinterpret_cast<unsigned long long*>(static_cast<char*>(h->pf_bound.p) + h->stamps_off);
-#if defined(LMI_PF_STAMPS) || defined(LMI_P2_STAMPS)
+#if defined(LMI_P2_STAMPS)
         HIPCHK(hipMemsetAsync(F.stamps, 0, 2 * 8 * 12 * 8, h->stream));
 #endif
-        constexpr int PF_BLOCKS_PER_CU = PF_NG == 1 ? 2 : 1;
-        if (v2) {
+        {
             pass2_kernel<true><<<h->num_cus, 64 * P2_WAVES, 0, h->stream>>>(F);   // pass 1: slot maxima of the sampled tiles
             HIPCHK(hipGetLastError());
             bound_merge2_kernel<<<cdiv((long long)ncols, 64), 256, 0, h->stream>>>(F.bound, (long long)ncols, F.bound1);
@@ -1137,13 +1124,6 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
                 query_bound_kernel<<<cdiv(nq, 256), 256, 0, h->stream>>>(h->slot_col.as<int>(), nq, nb, F.eps2, F.bound1);
                 HIPCHK(hipGetLastError());
             }
-        } else {
-        prefilter_kernel<true, PF_NG><<<h->num_cus * PF_BLOCKS_PER_CU, 256 * PF_NG, 0, h->stream>>>(F);   // pass 1: bounds from a sample
-        HIPCHK(hipGetLastError());
-if (pf_parts <= 4) bound_merge_kernel<16><<<cdiv((long long)ncols * 16, 256), 256, 0, h->stream>>>(F.bound, (long long)ncols, F.bound1);
-        else if (pf_parts <= 8) bound_merge_kernel<32><<<cdiv((long long)ncols * 32, 256), 256, 0, h->stream>>>(F.bound, (long long)ncols, F.bound1);
-        else bound_merge_kernel<64><<<cdiv((long long)ncols * 64, 256), 256, 0, h->stream>>>(F.bound, (long long)ncols, F.bound1);
-        HIPCHK(hipGetLastError());
         }
         if (h->debug_emit_all) {  // test hook: bound = -inf, every row of the bucket is a candidate
             FillRanges D;
@@ -1155,8 +1135,7 @@ if (pf_parts <= 4) bound_merge_kernel<16><<<cdiv((long long)ncols * 16, 256), 25
 
         // pass 2: candidates.  The query-resident form (opt-in: measured slower) needs a col-block's
         // fragments to fit a wave's registers (d <= 768)
-        if (v2) pass2_kernel<false><<<h->num_cus, 64 * P2_WAVES, 0, h->stream>>>(F);
-        else prefilter_kernel<false, PF_NG><<<h->num_cus * PF_BLOCKS_PER_CU, 256 * PF_NG, 0, h->stream>>>(F);
+        pass2_kernel<false><<<h->num_cus, 64 * P2_WAVES, 0, h->stream>>>(F);
         HIPCHK(hipGetLastError());
         CHK(record(h, 6));
         if (h->pf_redo && !h->debug_emit_all) {
@@ -1171,8 +1150,7 @@ if (pf_parts <= 4) bound_merge_kernel<16><<<cdiv((long long)ncols * 16, 256), 25
             PrefilterParams F2 = F;
             F2.head = F.head + 16;
             F2.redo_count = rc; F2.redo_bucket = rb; F2.redo_col = rcol;
-            if (v2) pass2_kernel<false><<<h->num_cus, 64 * P2_WAVES, 0, h->stream>>>(F2);
-            else prefilter_kernel<false, PF_NG><<<h->num_cus * PF_BLOCKS_PER_CU, 256 * PF_NG, 0, h->stream>>>(F2);
+            pass2_kernel<false><<<h->num_cus, 64 * P2_WAVES, 0, h->stream>>>(F2);
             HIPCHK(hipGetLastError());
         }
         RescoreParams Q;

@@ -31,6 +31,7 @@ constexpr int P2_G = 2;                                                  // k16-
 constexpr int P2_MAXCB = 12;                                             // col-blocks per tile
 constexpr int P2_WAVES = 8;
 constexpr int P2_TILE_RB = P2_WAVES;                                     // row-blocks per tile (256 vectors)
+constexpr int P2_TILE_ROWS = 32 * P2_TILE_RB;
 constexpr int P2_A_BYTES = P2_WAVES * P2_G * 1024;                       // 16 KiB: the stage's vector fragments
 constexpr int P2_SLOT_BYTES = P2_A_BYTES + P2_MAXCB * P2_G * 1024;       // 40 KiB per ring slot
 constexpr int P2_RING = 3;

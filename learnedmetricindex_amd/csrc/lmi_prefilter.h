@@ -33,12 +33,7 @@ namespace lmi {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
-constexpr int PF_RB = 2;            // row-blocks per wave: block tile = 4 waves x 2 x 32 = 256 vectors
-constexpr int PF_TILE_ROWS = 256;
-#ifndef LMI_PF_STAGE_G
-#define LMI_PF_STAGE_G 2
-#endif
-constexpr int PF_STAGE_G = LMI_PF_STAGE_G;  // k16-groups per stage -> BK = 16 * PF_STAGE_G
+constexpr int PF_STAGE_G = 2;       // k16-groups per stage of the scan kernels (lmi_pass2.h): the slab pads K to a multiple of 32
 #ifndef LMI_PF_CAP
 #define LMI_PF_CAP 1024  // 2048: duplicate-heavy data (60-100 copies of a vector) stops overflowing the buffers (tools/dup_cliff.py:
                          // 11 -> 1.7 ms at 100 copies) for +1.2 % on the benchmark (the buffers' stride doubles)
@@ -283,715 +278,46 @@ __global__ void slot_bound_kernel(const int* __restrict__ bucket_order, const in
 }
 
 // ------------------------------------------------------------------------------------------------
-// Prefilter kernels: fp16 operands; block tile 256 vectors x 256 queries (8 waves = two groups of four, one
-// block per CU; build option LMI_PF_NG=1: 256 x 128, 4 waves, two blocks per CU); wave = 64 vectors x <= 128
-// queries, 8 accumulator tiles; both operands by LDS-DMA into a ring of three stages (32 k each, 32 KiB),
-// one barrier per stage, stage u+2 in flight while stage u computes; inside a stage the fragment reads are
-// inline asm, the DMA pieces sit between the MFMA groups and the last group is deferred across the barrier
-// (step_fused).  (A/B on MI355X, 10M x 768: a one-stage register pipeline (A to VGPRs, B via VGPR ->
-// ds_write) spent 71 % of its wave time parked on waits -- an fp16 stage is 8x shorter than an f32 one,
-// shorter than the memory latency; the ring is 25 % faster.)  Two passes over the same code (template SAMPLE):
-//   pass 1 (SAMPLE):  P.parts (4, 8 or 16) items per (bucket, query tile) scan every PF_SAMPLE-th 256-row
-//                     tile of the whole bucket (part p takes sampled tiles p, p+parts, ..) with per-lane
-//                     VALUES-ONLY top-PF_LK lists, merge the 8 lists of a column and store the part's 10
-//                     best; the consumer's 10th best of the union of the parts is a lower bound of the
-//                     bucket's 10th best That (-inf if the lists hold < 10 values);
-//   pass 2 (!SAMPLE): items (bucket, query tile, chunk) from the XCD-affine queues; no lists, no
-//                     inter-item traffic: every row with shat >= bound[col] - 2 eps' is appended to
-//                     the slot's candidate buffer.  About 10 * PF_SAMPLE rows per slot pass.
+// The prefilter's scan kernels (pass 1: sampled bounds, pass 2: candidate emission) are in lmi_pass2.h.  (Rounds 1-2 ran
+// `prefilter_kernel<SAMPLE, NG>` from this file: 256 x 256 block tiles, a wave = 64 vectors x <= 128 queries, two query tiles per
+// bucket; removed in round 3 -- git history and DESIGN.md sections 5b / 5e keep its measurements.)
 // ------------------------------------------------------------------------------------------------
-// (LMI_PF_SAMPLE, LMI_PF_SAMPLE_ROWS, sample_stride: lmi_kernels.h -- the routing kernels count the sampled tiles too)
-#ifndef LMI_PF_RING2
-#define LMI_PF_RING2 3  // ring slots of the NG 2 pass-2 kernel (3 or 4; A/B on MI355X: 4 is 1-3 % slower, more in flight only raised the load latency)
-#endif
-#ifndef LMI_PF_RING2_SAMPLE
-#define LMI_PF_RING2_SAMPLE 4  // .. of pass 1, which waits 3-4 x longer for a stage to land (stamps) and has the LDS: -3.4 %
-#endif
 #ifndef LMI_PF_A_AUX
-#define LMI_PF_A_AUX 0  // cache policy of the vector-fragment DMA (2 = nt: measured 3 % slower, a chunk is read by its 2 query tiles)
+#define LMI_PF_A_AUX 0  // cache policy of the vector-fragment DMA (2 = nt)
 #endif
-#ifndef LMI_PF_FUSED
-#define LMI_PF_FUSED 1  // NG 2: DMA pieces interleaved with the MFMA groups of the stage
-#endif
-constexpr int PF_FUSED = LMI_PF_FUSED;
-#ifndef LMI_PF_NG
-#define LMI_PF_NG 2
-#endif
-constexpr int PF_NG = LMI_PF_NG;  // wave groups per prefilter block (PreItem): 1 -> 128-query tiles, 2 -> 256-query tiles
-constexpr int PF_PARTS_MAX = 16;  // ... split over P.parts = 4, 8 or 16 items per (bucket, query tile) (the host picks: enough
-                                 // items to fill the chip also when a rank owns 1/8 of the buckets), merged by the consumers
 
 struct PrefilterParams {
     const uint4* slab16;
     const uint4* qfrag16;
-    int KG16;  // k16-groups per row-block (multiple of PF_STAGE_G)
+    int KG16;  // k16-groups per row-block (multiple of 2: a stage holds two)
     int L;
     int chunk_rb;
     const int* rb_start;
     const int* nb_rows;
     const int* nch;
     const int* m;
-    const int* m0;        // lmi_pass2.h pass 1: the bucket's primary columns [0, m0) are the sampled ones
+    const int* m0;        // pass 1: the bucket's primary columns [0, m0) are sampled at the full rate (route_count_kernel)
     const int* cb_start;
-    const int* qt_base;   // [L+1] prefix of the query-tile counts of the buckets taken heaviest first (pass-1 items)
-    const int* by_work;   // [L] that order
     const int* grp_bucket;
     const int* grp_base;
     const int* grp_n;
     const int* grp_total;
-    const int* grp_base1;  // lmi_pass2.h pass 1: the XCD-affine queues of its (bucket, query tile, sampled tile) items
+    const int* grp_base1;  // pass 1: the XCD-affine queues of its (bucket, query tile, sampled tile) items
     const int* grp_total1;
-    long long ncols;       // columns of the batch (stride of the pass-1 lists of lmi_pass2.h)
-    unsigned* head;       // [NGRP] pass-2 queue heads; [NGRP] = pass-1 head ([NGRP..2 NGRP): lmi_pass2.h's pass-1 queues)
-    int parts;            // pass-1 items per (bucket, query tile): 4, 8 or 16
-    float* bound;         // [columns][parts][4 row-waves][PF_LK] pass 1: the best sampled shat of every 64-row strip
-    float* bound1;        // [columns] bound_merge_kernel: 10th best of the union of the parts -> pass 2
+    long long ncols;       // columns of the batch (stride of the pass-1 lists)
+    unsigned* head;       // [0, NGRP) pass-2 queue heads; [16, 16 + NGRP): the heads of pass 2's redo launch; [24, 24 + NGRP): pass 1
+    float* bound;         // [P2_NSL lists][16 slots][columns] pass 1: slot maxima of the sampled tiles (lmi_pass2.h)
+    float* bound1;        // [columns] bound_merge2_kernel (+ query_bound_kernel): the lower bound of That pass 2 emits against
     const float* eps2;    // 2 eps' per column
     unsigned* cand_cnt;   // [columns]
     unsigned* cand_row;   // [columns][PF_CAP]
     float* cand_s;        // [columns][PF_CAP]
-    unsigned long long* stamps;  // LMI_PF_STAMPS builds: phase cycles (behind the pass-1 lists in pf_bound)
+    unsigned long long* stamps;  // LMI_P2_STAMPS builds: phase cycles (behind the pass-1 lists in pf_bound)
     // second run of pass 2 for the columns whose candidate buffer overflowed (overflow_rebound_kernel); all null in the first
     const unsigned* redo_count;      // [1] columns to redo: 0 -> the launch returns at once
     const int* redo_bucket;          // [L] the bucket has such a column: its items are run again, the others skipped
     const unsigned char* redo_col;   // [columns] only these columns keep a finite threshold
 };
-
-// Pass 1 keeps the PF_LK best values per lane and column.  The bound only has to be the 10th best of SOME
-// subset of the bucket's scores: the union of the 8 (row-wave, half) lists x parts of a column holds the
-// sample's ten best unless five of them fall into one list; a shorter list is a cheaper insert (the
-// epilogue of pass 1 is VALU-bound) and a higher entry threshold.
-#ifndef LMI_PF_EPI_G
-#define LMI_PF_EPI_G 1  // pass 2: score registers tested per branch of the epilogue (A/B on MI355X: 1: -2.7 %, 2: -1.6 %, 4: +11 % -- its 4-entry reservations overflow the 64-entry list)
-#endif
-constexpr int PF_LIST = 64 + LMI_PF_EPI_G;  // compaction-list entries per wave (+ slack for the group that overflows it)
-#ifndef LMI_PF_LK
-#define LMI_PF_LK 4
-#endif
-constexpr int PF_LK = LMI_PF_LK;
-// one instruction each (fmaxf / fminf also canonicalise both operands: three); a quiet NaN operand yields the other one
-__device__ __forceinline__ float vmaxf(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float vminf(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ void vlist_insert(float (&v)[PF_LK], float s) {  // values-only sorted insert (descending)
-    // compare-exchange chain: the carried value sinks through the list; 2 PF_LK - 1 min/max, no branch, no predicate
-    // (v_max/v_min return the other operand for a NaN: a NaN never enters the list)
-#pragma unroll
-    for (int t = 0; t < PF_LK; ++t) {
-        const float hi = vmaxf(v[t], s);
-        if (t + 1 < PF_LK) s = vminf(v[t], s);
-        v[t] = hi;
-    }
-}
-
-// NG = wave groups per block.  NG 1: 4 waves, 256 vectors x 128 queries, two blocks per CU.  NG 2: 8 waves,
-// 256 vectors x 256 queries, one block per CU: group g (waves 4g..4g+3) owns its share of the tile's
-// col-blocks and both groups read the SAME staged vector fragments, so a CU fetches every vector stage
-// once instead of twice and a bucket has half as many query tiles re-reading its chunks.
-// In-kernel phase timing of pass 2 (developer builds, -DLMI_PF_STAMPS): shader-clock cycles per wave and phase summed into
-// P.bound (free once bound_merge_kernel has run) as u64 [8 waves][12 phases]: 0 landed-wait, 1 barrier, 2 stage (MFMA + DMA
-// issue), 3 epilogue rest (clearing the accumulators), 4 item start, 5 item end, 7 = tiles, 8 / 9 / 10 = the epilogue's flush /
-// threshold pass / list read + position atomics.  tools/pf_stamps.py prints the table.
-#ifdef LMI_PF_STAMPS
-#ifndef LMI_PF_STAMPS_SAMPLE
-#define LMI_PF_STAMPS_SAMPLE 0  // 1: stamp pass 1 (prefilter_kernel<true, .>) instead of pass 2
-#endif
-#define PF_STAMP(PH) if (SAMPLE == (LMI_PF_STAMPS_SAMPLE != 0)) { const unsigned long long t_ = __builtin_readcyclecounter(); st_acc[PH] += t_ - st_last; st_last = t_; }
-#define PF_STAMPS_WRITE(NVT)                                                                         \
-        if (SAMPLE == (LMI_PF_STAMPS_SAMPLE != 0)) {                                                 \
-            st_acc[7] = (unsigned long long)(NVT);                                                   \
-            if (lane == 0) {                                                                         \
-                unsigned long long* g = P.stamps + w * 12;                                           \
-                for (int i = 0; i < 12; ++i) atomicAdd(g + i, st_acc[i]);                            \
-            }                                                                                        \
-        }
-#else
-#define PF_STAMP(PH)
-#define PF_STAMPS_WRITE(NVT)
-#endif
-
-template <int NCB, bool SAMPLE, int NG>
-struct PreItem {
-    static constexpr int NLIST = SAMPLE ? NCB : 1;
-    // ring slots: what is in flight (RING - 1 stages) over the load latency bounds the stage rate; NG 2's
-    // one block per CU leaves LDS for a fourth slot (3 x 32 KiB in flight instead of 2 x 24 KiB x 2 blocks)
-    static constexpr int RING = NG == 1 ? 3 : (SAMPLE ? LMI_PF_RING2_SAMPLE : LMI_PF_RING2);
-    const PrefilterParams& P;
-    uint4* sB0;
-    uint4* sB1;  // three DISTINCT __shared__ B arrays [4 NG col-blocks][PF_STAGE_G][64] uint4 = 8 NG KiB each ...
-    uint4* sB2;  // ... and three A arrays [4 row-waves][PF_RB][PF_STAGE_G][64] (16 KiB each): the LDS-DMA ring
-    uint4 *sA0, *sA1, *sA2;
-    uint4 *sB3, *sA3;       // fourth ring slot (RING 4 only)
-    uint2* sList;           // pass 2: [4 NG waves][64] candidate compaction lists
-    int lane, w, h, c;
-    int wr, grp;            // row-wave (0..3) and wave group (0..NG-1): w = 4 grp + wr
-    int cbofs;              // first col-block of this wave's group inside the tile
-    float lv[NLIST][PF_LK]; // pass 1 only
-    float thr[NCB];         // pass 2: bound - 2 eps' of this lane's column in col-block n (+inf: idle column)
-    half8 p_a, p_b[NCB];    // NG 2: operands of the stage's deferred last MFMA group (step_fused)
-    unsigned pend_pos, pend_row, pend_col;  // pass 2: this lane's candidate of the previous tile ...
-    float pend_s;                           // ... whose position atomic is in flight
-    f32x16 acc[PF_RB][NCB];
-#ifdef LMI_PF_STAMPS
-    unsigned long long st_acc[12], st_last;
-#endif
-
-    template <int SLOT>
-    __device__ __forceinline__ void issue_dma(const uint4* ap0, const uint4* ap1, const uint4* qp) {
-#ifdef LMI_ABL_NOLOAD  // timing-only ablation builds (tools/scan_ab.py --no-check)
-        return;
-#endif
-#ifdef LMI_ABL_HOTA    // every block streams the same 64 KiB of A: all L2 hits
-        ap0 = P.slab16 + (((size_t)(ap0 - P.slab16)) & 2047);
-        ap1 = P.slab16 + (((size_t)(ap1 - P.slab16)) & 2047) + 2048;
-#endif
-        uint4* sA = SLOT == 0 ? sA0 : SLOT == 1 ? sA1 : SLOT == 2 ? sA2 : sA3;
-        uint4* sB = SLOT == 0 ? sB0 : SLOT == 1 ? sB1 : SLOT == 2 ? sB2 : sB3;
-        // this wave stages row-blocks j = grp, grp + NG, .. of its row-wave's PF_RB (ap0 [, ap1]) and col-block w
-#pragma unroll
-        for (int g = 0; g < PF_STAGE_G; ++g) {
-            glds16(reinterpret_cast<const float4*>(ap0 + g * 64 + lane),
-                   reinterpret_cast<float4*>(sA + ((wr * PF_RB + (NG == 1 ? 0 : grp)) * PF_STAGE_G + g) * 64));
-            if (NG == 1)
-                glds16(reinterpret_cast<const float4*>(ap1 + g * 64 + lane), reinterpret_cast<float4*>(sA + ((wr * PF_RB + 1) * PF_STAGE_G + g) * 64));
-            glds16(reinterpret_cast<const float4*>(qp + g * 64 + lane), reinterpret_cast<float4*>(sB + (w * PF_STAGE_G + g) * 64));
-        }
-    }
-
-    template <int SLOT>
-    __device__ __forceinline__ void compute_dma() {
-        const uint4* sA = (SLOT == 0 ? sA0 : SLOT == 1 ? sA1 : SLOT == 2 ? sA2 : sA3) + (wr * PF_RB) * PF_STAGE_G * 64 + lane;
-        const uint4* sB = (SLOT == 0 ? sB0 : SLOT == 1 ? sB1 : SLOT == 2 ? sB2 : sB3) + cbofs * PF_STAGE_G * 64 + lane;
-#pragma unroll
-        for (int g = 0; g < PF_STAGE_G; ++g) {
-            half8 bq[NCB];
-#pragma unroll
-            for (int n = 0; n < NCB; ++n) {
-                const uint4 t = sB[(n * PF_STAGE_G + g) * 64];
-                bq[n] = *reinterpret_cast<const half8*>(&t);
-            }
-#pragma unroll
-            for (int j = 0; j < PF_RB; ++j) {
-                const uint4 ta = sA[(j * PF_STAGE_G + g) * 64];
-                const half8 av = *reinterpret_cast<const half8*>(&ta);
-#pragma unroll
-                for (int n = 0; n < NCB; ++n)
-                    acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bq[n], acc[j][n], 0, 0, 0);
-            }
-        }
-    }
-
-    // NG 2: stage SLOT's MFMAs with the 4 DMA pieces of stage SLOT+RING-1 (slot DST) issued one before each
-    // group of NCB MFMAs.  The fragment reads are inline asm: hipcc orders every ds_read it can see behind
-    // ALL pending LDS-DMA (`s_waitcnt vmcnt(0)`: it cannot tell the ring slots apart once the loop's back
-    // edge merges its bookkeeping), which drains the look-ahead; the ring's own `s_waitcnt vmcnt(N)` +
-    // barrier is the real ordering.  Reads run one MFMA group ahead of their use; every fragment of the
-    // stage has registers of its own (nothing an in-flight MFMA still reads is overwritten).
-    template <int OFF>
-    static __device__ __forceinline__ void lds_rd(half8& r, unsigned addr) {
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
-    }
-    template <int G>
-    __device__ __forceinline__ void rd_b(half8 (&b)[NCB], unsigned aB) {
-        lds_rd<(0 * PF_STAGE_G + G) * 1024>(b[0], aB);
-        if (NCB > 1) lds_rd<(1 * PF_STAGE_G + G) * 1024>(b[NCB > 1 ? 1 : 0], aB);
-        if (NCB > 2) lds_rd<(2 * PF_STAGE_G + G) * 1024>(b[NCB > 2 ? 2 : 0], aB);
-        if (NCB > 3) lds_rd<(3 * PF_STAGE_G + G) * 1024>(b[NCB > 3 ? 3 : 0], aB);
-    }
-    // the reads issued so far have landed; the operands are "defined" here for the compiler
-    static __device__ __forceinline__ void lds_wait(half8& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a) :: "memory"); }
-    static __device__ __forceinline__ void lds_wait(half8& a, half8 (&b)[NCB]) {
-        if (NCB == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b[0]) :: "memory");
-        if (NCB == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b[0]), "+v"(b[NCB > 1 ? 1 : 0]) :: "memory");
-        if (NCB == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b[0]), "+v"(b[NCB > 1 ? 1 : 0]), "+v"(b[NCB > 2 ? 2 : 0]) :: "memory");
-        if (NCB == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b[0]), "+v"(b[NCB > 1 ? 1 : 0]), "+v"(b[NCB > 2 ? 2 : 0]), "+v"(b[NCB > 3 ? 3 : 0]) :: "memory");
-    }
-    template <int J>
-    __device__ __forceinline__ void mma(const half8& a, const half8 (&b)[NCB]) {
-#pragma unroll
-        for (int n = 0; n < NCB; ++n)
-            acc[J][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[n], acc[J][n], 0, 0, 0);
-    }
-
-    // The stage's last MFMA group is deferred across the next barrier (its operands p_a, p_b are already
-    // in registers, so the ring slot is free): it runs while the next stage's first fragment reads are in
-    // flight -- right after a barrier both waves of a SIMD wait for LDS at the same time.
-    template <int SLOT, int DST>
-    __device__ __forceinline__ void step_fused(const uint4* ap0, const uint4* qp, bool pending) {
-        static_assert(PF_STAGE_G == 2 && PF_RB == 2, "written out for 2 k-groups x 2 row-blocks");
-        const uint4* sA = (SLOT == 0 ? sA0 : SLOT == 1 ? sA1 : SLOT == 2 ? sA2 : sA3) + (wr * PF_RB) * PF_STAGE_G * 64 + lane;
-        const uint4* sB = (SLOT == 0 ? sB0 : SLOT == 1 ? sB1 : SLOT == 2 ? sB2 : sB3) + cbofs * PF_STAGE_G * 64 + lane;
-        const unsigned aA = (unsigned)reinterpret_cast<uintptr_t>(sA);  // generic address of LDS: low 32 bits = LDS offset
-        const unsigned aB = (unsigned)reinterpret_cast<uintptr_t>(sB);
-        float4* dA = reinterpret_cast<float4*>((DST == 0 ? sA0 : DST == 1 ? sA1 : DST == 2 ? sA2 : sA3) + (wr * PF_RB + grp) * PF_STAGE_G * 64);
-        float4* dB = reinterpret_cast<float4*>((DST == 0 ? sB0 : DST == 1 ? sB1 : DST == 2 ? sB2 : sB3) + w * PF_STAGE_G * 64);
-        half8 a00, a10, a01, a11, b0[NCB], b1[NCB];  // a<j><g>
-        // fragment (j, g) of A at (j * G + g) KiB, (n, g) of B at (n * G + g) KiB
-        rd_b<0>(b0, aB);
-        lds_rd<(0 * PF_STAGE_G + 0) * 1024>(a00, aA);
-        lds_rd<(1 * PF_STAGE_G + 0) * 1024>(a10, aA);
-        if (pending) mma<1>(p_a, p_b);
-        __builtin_amdgcn_sched_barrier(0);
-        lds_wait(a00, b0);
-        lds_wait(a10);
-        rd_b<1>(b1, aB);
-        lds_rd<(0 * PF_STAGE_G + 1) * 1024>(a01, aA);
-        lds_rd<(1 * PF_STAGE_G + 1) * 1024>(a11, aA);
-#ifndef LMI_ABL_NOLOAD
-        glds16o<0, LMI_PF_A_AUX>(reinterpret_cast<const float4*>(ap0 + lane), dA);
-#endif
-        mma<0>(a00, b0);
-        __builtin_amdgcn_sched_barrier(0);
-#ifndef LMI_ABL_NOLOAD
-        glds16o<1024, LMI_PF_A_AUX>(reinterpret_cast<const float4*>(ap0 + lane), dA);
-#endif
-        mma<1>(a10, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        lds_wait(a01, b1);
-        lds_wait(a11);
-#ifndef LMI_ABL_NOLOAD
-        glds16(reinterpret_cast<const float4*>(qp + lane), dB);
-#endif
-        mma<0>(a01, b1);
-        __builtin_amdgcn_sched_barrier(0);
-#ifndef LMI_ABL_NOLOAD
-        glds16o<1024>(reinterpret_cast<const float4*>(qp + lane), dB);
-#endif
-        p_a = a11;
-#pragma unroll
-        for (int n = 0; n < NCB; ++n) p_b[n] = b1[n];
-    }
-
-    // pass 1: per-lane values-only top-10 lists (predicated insert; a ballot + branch per score was 20 % slower)
-    __device__ __forceinline__ void epilogue_sample(int rb_tile0, int n_b) {
-        const bool ragged = (unsigned)((rb_tile0 + (wr + 1) * PF_RB) * 32) > (unsigned)n_b;  // wave-uniform: rows past the bucket's end
-#pragma unroll
-        for (int j = 0; j < PF_RB; ++j) {
-            const unsigned rowbase = (unsigned)((rb_tile0 + wr * PF_RB + j) * 32);
-#pragma unroll
-            for (int n = 0; n < NCB; ++n) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float s = acc[j][n][r];
-                    if (ragged && rowbase + acc_row(r, h) >= (unsigned)n_b) s = -INFINITY;  // zero-padded / clamped rows
-                    vlist_insert(lv[SAMPLE ? n : 0], s);
-                    acc[j][n][r] = 0.0f;
-                }
-            }
-        }
-    }
-
-    // pass 2: a candidate's (column, row, shat) goes to the slot's buffer at position atomicAdd(cand_cnt).
-    // A returning global atomic inside the K pipeline drains the LDS-DMA look-ahead (vmcnt is one
-    // in-order counter), so a tile with few candidates (the wave counts them first: <= 64 in its
-    // 64 x 128 scores; expected ~16 at 83 000-row buckets) splits the emission over two tile ends:
-    // the candidates are compacted through a wave-private 64-entry LDS list (ballot + mbcnt, no LDS
-    // atomics) so that lane i owns entry i and issues ITS atomic; position and entry stay in 4
-    // registers while the next tile computes; the stores go out at the next tile end (flush_pending),
-    // long after the atomic returned.  Dense tiles (small buckets: every row is a candidate) take the
-    // direct path, one returning atomic per candidate.
-    __device__ __forceinline__ void flush_pending() {
-        if (pend_pos < (unsigned)PF_CAP) {
-            P.cand_row[(size_t)pend_col * PF_CAP + pend_pos] = pend_row;
-            P.cand_s[(size_t)pend_col * PF_CAP + pend_pos] = pend_s;
-        }
-        pend_pos = 0xffffffffu;
-    }
-
-    __device__ __forceinline__ void epilogue_emit(int rb_tile0, int n_b, size_t col0) {
-        flush_pending();
-        PF_STAMP(8)
-        const unsigned row0 = (unsigned)((rb_tile0 + wr * PF_RB) * 32);  // first of this wave's 64 rows
-        if (row0 + 32u * PF_RB > (unsigned)n_b) {  // wave-uniform: the bucket's ragged end (zero-padded / clamped rows)
-#pragma unroll
-            for (int j = 0; j < PF_RB; ++j)
-#pragma unroll
-                for (int n = 0; n < NCB; ++n)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (row0 + j * 32 + acc_row(r, h) >= (unsigned)n_b) acc[j][n][r] = __builtin_nanf("");  // fails every >= (a bound may be -inf)
-        }
-        // optimistic compaction: (column, row, shat) of every passing score -> list[0..cnt); more than 64
-        // discards the list and re-emits the whole tile on the direct path below
-        uint2* list = sList + w * PF_LIST;
-        int tot = 0;  // wave-uniform
-        {
-            // entry key = (column in tile) << 8 | (row in the wave's 64 rows); opaque so that the 128
-            // per-(j,n,r) keys are formed where they are used (base + literal), not hoisted out of the K loop
-            unsigned kb = (unsigned)((c << 8) | (4 * h));
-            asm volatile("" : "+v"(kb));
-            // Scores that pass are rare (~16 of the wave's 8 192), so the registers are tested in groups of LMI_PF_EPI_G
-            // through their maximum and the per-register pass (ballot + compaction) runs for a group with a hit only;
-            // the no-hit case is the FALL-THROUGH path (a taken branch per register cost ~40 cycles x 128).
-#pragma unroll
-            for (int j = 0; j < PF_RB; ++j)
-#pragma unroll
-                for (int n = 0; n < NCB; ++n)
-#pragma unroll
-                    for (int r0 = 0; r0 < 16; r0 += LMI_PF_EPI_G) {
-                        // one v_max / v_max3 + v_max (fmaxf() also canonicalises both operands: 3 instructions per pair); a quiet
-                        // NaN (ragged rows) never wins
-                        float gm = acc[j][n][r0];
-                        if (LMI_PF_EPI_G == 2) asm("v_max_f32 %0, %1, %2" : "=v"(gm) : "v"(acc[j][n][r0]), "v"(acc[j][n][r0 + (LMI_PF_EPI_G > 1 ? 1 : 0)]));
-                        if (LMI_PF_EPI_G == 4) {
-                            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(gm) : "v"(acc[j][n][r0]), "v"(acc[j][n][r0 + (LMI_PF_EPI_G > 1 ? 1 : 0)]), "v"(acc[j][n][r0 + (LMI_PF_EPI_G > 2 ? 2 : 0)]));
-                            asm("v_max_f32 %0, %1, %2" : "=v"(gm) : "v"(gm), "v"(acc[j][n][r0 + (LMI_PF_EPI_G > 3 ? 3 : 0)]));
-                        }
-                        static_assert(LMI_PF_EPI_G == 1 || LMI_PF_EPI_G == 2 || LMI_PF_EPI_G == 4, "group maximum written out for 1, 2, 4");
-                        bool gpass = gm >= thr[n];  // thr = +inf for idle columns
-#ifdef LMI_ABL_NOEMIT
-                        gpass = gpass && thr[n] == 12345.678f;  // never true, keeps the compares alive
-#endif
-                        const unsigned long long gmask = __ballot(gpass);
-                        if (__builtin_expect(gmask != 0ull, 0)) {
-                            // every lane of the group with a hit takes LMI_PF_EPI_G consecutive list entries (one ballot per
-                            // group, no branch per register); a register below the threshold leaves its entry invalid
-                            if (gpass) {
-                                const int my = tot + LMI_PF_EPI_G * (int)__builtin_amdgcn_mbcnt_hi((unsigned)(gmask >> 32),
-                                                                                                  __builtin_amdgcn_mbcnt_lo((unsigned)gmask, 0u));
-                                uint2* at = list + min(my, 64);  // past the list: its slack entries (the tile then takes the direct path)
-#pragma unroll
-                                for (int u = 0; u < LMI_PF_EPI_G; ++u) {
-                                    const int r = r0 + u;
-                                    const unsigned key = kb + (unsigned)(((n * 32) << 8) | (j * 32 + (r & 3) + 8 * (r >> 2)));
-                                    at[u] = make_uint2(acc[j][n][r] >= thr[n] ? key : 0xffffffffu, __float_as_uint(acc[j][n][r]));
-                                }
-                            }
-                            tot += LMI_PF_EPI_G * (int)__popcll(gmask);
-                        }
-                    }
-        }
-        PF_STAMP(9)
-        if (tot > 0 && tot <= 64) {
-            if (lane < tot) {
-                const uint2 e = list[lane];
-                if (e.x != 0xffffffffu) {
-                    pend_col = (unsigned)(col0 + (e.x >> 8));
-                    pend_row = row0 + (e.x & 255u);
-                    pend_s = __uint_as_float(e.y);
-#ifdef LMI_ABL_NOATOMIC  // timing-only ablation: no returning atomic in the K pipeline (positions collide)
-                    pend_pos = (unsigned)lane;
-#else
-                    pend_pos = atomicAdd(P.cand_cnt + pend_col, 1u);
-#endif
-                }
-            }
-        } else if (tot > 64) {
-            float t3[NCB];
-#pragma unroll
-            for (int n = 0; n < NCB; ++n) { t3[n] = thr[n]; asm volatile("" : "+v"(t3[n])); }
-#pragma unroll
-            for (int j = 0; j < PF_RB; ++j)
-#pragma unroll
-                for (int n = 0; n < NCB; ++n)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (acc[j][n][r] >= t3[n]) {
-                            const size_t col = col0 + n * 32 + c;
-                            const unsigned pos = atomicAdd(P.cand_cnt + col, 1u);
-                            if (pos < (unsigned)PF_CAP) {
-                                P.cand_row[col * PF_CAP + pos] = row0 + j * 32 + acc_row(r, h);
-                                P.cand_s[col * PF_CAP + pos] = acc[j][n][r];
-                            }
-                        }
-        }
-        PF_STAMP(10)
-#pragma unroll
-        for (int j = 0; j < PF_RB; ++j)
-#pragma unroll
-            for (int n = 0; n < NCB; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.0f;
-    }
-
-    // The tile = col-blocks [cbt0, cbt0 + ncb_tile) of bucket b; this wave's group owns NCB of them from cbofs
-    // (`idle`: none -- the wave stages its share, computes a duplicate and emits nothing).
-    // SAMPLE: `ch` is the part p in [0, P.parts): the item covers the tiles (p + P.parts*i)*PF_SAMPLE, i = 0,1,..
-    // of the whole bucket and writes its 10 best values; !SAMPLE: chunk `ch`, every tile.
-    __device__ __forceinline__ void run(int b, int cbt0, int ncb_tile, int cbofs_, bool idle, int ch) {
-#ifdef LMI_PF_STAMPS
-        for (int i = 0; i < 12; ++i) st_acc[i] = 0;
-        st_last = __builtin_readcyclecounter();
-#endif
-        const int tid = threadIdx.x;
-        lane = tid & 63; h = lane >> 5; c = lane & 31;
-        w = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: stage pointers and LDS destinations stay in SGPRs
-        wr = w & 3; grp = w >> 2; cbofs = cbofs_;
-        const int KG = P.KG16, NS = KG / PF_STAGE_G;
-        const int n_b = P.nb_rows[b];
-        const int nrb_b = (n_b + 31) >> 5;
-        const int nrb_all = SAMPLE ? nrb_b : min(P.chunk_rb, nrb_b - ch * P.chunk_rb);
-        const int nvt_all = (nrb_all + 4 * PF_RB - 1) / (4 * PF_RB);
-        // Sampling stride of the bucket: every PF_SAMPLE-th tile for large buckets, denser for small ones, so that
-        // pass 2 never emits more than ~0.5 % of a bucket's rows per slot (10 x stride of them): at 160 candidates
-        // per slot a 5 000-row bucket puts > 64 candidates into every 64 x 128 wave tile and the epilogue
-        // leaves its fast path for one returning atomic per candidate (a few such buckets cost 7 % of pass 2).
-        const int stride = SAMPLE ? sample_stride(n_b) : 1;
-        const int TSTEP = SAMPLE ? stride * P.parts : 1;          // tile stride
-        const int t0 = SAMPLE ? ch * stride : 0;                  // first tile
-        const int nvt = nvt_all > t0 ? (nvt_all - t0 + TSTEP - 1) / TSTEP : 0;  // tiles this item processes
-        const int rb_in_b0 = SAMPLE ? t0 * 4 * PF_RB : ch * P.chunk_rb;
-        const int cb_tile = P.cb_start[b] + cbt0;                 // the tile's first col-block (global)
-        const int m_left = idle ? 0 : P.m[b] - (cbt0 + cbofs) * 32;  // live columns from this group's first one
-        const size_t col0 = (size_t)(cb_tile + cbofs) * 32;
-        // wave-uniform bases; the lane's 16 bytes are added at the DMA (SGPR base + 32-bit lane offset)
-        const uint4* aslab = P.slab16 + ((size_t)P.rb_start[b] * KG) * 64;
-        const uint4* bbase = P.qfrag16 + ((size_t)(cb_tile + min(w, ncb_tile - 1)) * KG) * 64;
-        const size_t rb_stride = (size_t)KG * 64;
-        const int rb_last = nrb_b - 1;
-#pragma unroll
-        for (int n = 0; n < NCB; ++n) {
-            if (SAMPLE) {
-#pragma unroll
-                for (int j = 0; j < PF_LK; ++j) lv[SAMPLE ? n : 0][j] = -INFINITY;
-            } else {
-                const float v10 = P.bound1[col0 + n * 32 + c];
-                const bool wanted = !P.redo_col || (n * 32 + c < m_left && P.redo_col[col0 + n * 32 + c]);
-                thr[n] = n * 32 + c < m_left && wanted ? v10 - P.eps2[col0 + n * 32 + c] : INFINITY;
-            }
-#pragma unroll
-            for (int j = 0; j < PF_RB; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.0f;
-        }
-        pend_pos = 0xffffffffu;
-        // running pointers of the NEXT stage to load: this wave's share of its row-wave's vectors, col-block w
-        int vt_n = 0, t_n = 0;  // vt_n counts tiles; tile index = vt * TSTEP
-        const int j0 = NG == 1 ? 0 : grp;
-        const uint4* ap0 = aslab + (size_t)min(rb_in_b0 + wr * PF_RB + j0, rb_last) * rb_stride;
-        const uint4* ap1 = aslab + (size_t)min(rb_in_b0 + wr * PF_RB + 1, rb_last) * rb_stride;  // NG 1 only
-        const uint4* qp = bbase;
-        // LDS-DMA ring of RING slots: stage u+RING-1 is issued while stage u computes, so a load has
-        // RING-1 stage times to land (a one-stage register pipeline left 71 % of the wave time parked on
-        // waits; bytes in flight / load latency is what bounds the stage rate).  Every wave issues exactly
-        // (PF_RB/NG + 1) * PF_STAGE_G DMAs per stage (6 or 4; waves whose col-block is past the tile stage
-        // a duplicate) and the stream never stops (past the end the last stage is re-loaded), so "stage u
-        // has landed" is a constant `s_waitcnt vmcnt((RING-2) x that)`: only the younger stages may be
-        // pending (the epilogue's few stores/atomics are younger still: the wait only gets more
-        // conservative).  A tile is NSR = NS rounded up to a multiple of RING stages (the extra ones load,
-        // compute nothing), so every tile starts in ring slot 0 and the epilogue has ONE call site.
-        static_assert((PF_RB / NG + 1) * PF_STAGE_G == (NG == 1 ? 6 : 4) && (NG == 2 || RING == 3), "vmcnt literals below");
-        const int NSR = (NS + RING - 1) / RING * RING;
-#define PF_ADVANCE                                                                                \
-        if (++t_n < NS) { ap0 += PF_STAGE_G * 64; ap1 += PF_STAGE_G * 64; qp += PF_STAGE_G * 64; } \
-        else if (t_n == NSR) {                                                                    \
-            t_n = 0;                                                                              \
-            if (vt_n + 1 < nvt) {                                                                 \
-                ++vt_n; qp = bbase;                                                               \
-                ap0 = aslab + (size_t)min(rb_in_b0 + (vt_n * TSTEP * 4 + wr) * PF_RB + j0, rb_last) * rb_stride; \
-                ap1 = aslab + (size_t)min(rb_in_b0 + (vt_n * TSTEP * 4 + wr) * PF_RB + 1, rb_last) * rb_stride; \
-            }                                                                                     \
-        }
-#ifdef LMI_ABL_NOWAIT  // timing-only ablation builds: garbage results
-#define PF_WAIT_LANDED
-#else
-#define PF_WAIT_LANDED                                                                            \
-        if (NG == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                             \
-        else if (RING == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                      \
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-#endif
-#ifdef LMI_ABL_NOBAR
-#define PF_BARRIER
-#else
-#define PF_BARRIER __builtin_amdgcn_s_barrier();
-#endif
-        // LMI_PF_FUSED (NG 2): the stage's 4 DMA pieces are issued one before each group of 4 MFMAs instead of
-        // all at once after the barrier (where both waves of a SIMD sit in DMA issue with the MFMA pipe idle).
-#define PF_STEP(SLOT, LIVE)                                                                       \
-        PF_WAIT_LANDED                                                                            \
-        PF_STAMP(0)                                                                               \
-        PF_BARRIER                                                                                \
-        PF_STAMP(1)                                                                               \
-        if (NG == 2 && PF_FUSED && (LIVE)) {                                                      \
-            step_fused<SLOT, (SLOT + RING - 1) % RING>(ap0, qp, SLOT > 0 || t > 0);               \
-            PF_ADVANCE                                                                            \
-        } else {                                                                                  \
-            issue_dma<(SLOT + RING - 1) % RING>(ap0, ap1, qp);                                    \
-            PF_ADVANCE                                                                            \
-            if (LIVE) compute_dma<SLOT>();                                                        \
-        }                                                                                         \
-        PF_STAMP(2)
-        PF_STAMP(4)
-        if (nvt > 0) {
-            issue_dma<0>(ap0, ap1, qp);
-            PF_ADVANCE
-            issue_dma<1>(ap0, ap1, qp);
-            PF_ADVANCE
-            if (RING == 4) {
-                issue_dma<2>(ap0, ap1, qp);
-                PF_ADVANCE
-            }
-        }
-        for (int vt = 0; vt < nvt; ++vt) {
-            for (int t = 0; t < NSR; t += RING) {
-                PF_STEP(0, true)
-                PF_STEP(1, t + 1 < NS)
-                PF_STEP(2, t + 2 < NS)
-                if (RING == 4) {
-                    PF_STEP(3, t + 3 < NS)
-                }
-            }
-            if (NG == 2 && PF_FUSED) mma<1>(p_a, p_b);  // the tile's last deferred group
-            if (SAMPLE) epilogue_sample(rb_in_b0 + vt * TSTEP * 4 * PF_RB, n_b);
-            else epilogue_emit(rb_in_b0 + vt * TSTEP * 4 * PF_RB, n_b, col0);
-            PF_STAMP(3)
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the look-ahead before the LDS is reused
-        __syncthreads();
-        PF_STAMP(5)
-#undef PF_STEP
-#undef PF_ADVANCE
-#undef PF_WAIT_LANDED
-#undef PF_BARRIER
-        if (!SAMPLE) {
-            flush_pending();
-            PF_STAMPS_WRITE(nvt)
-            return;
-        }
-        // ---- pass 1: the lists go to bound[col][part][row-wave][PF_LK]; bound_merge_kernel takes the 10th best of a column's
-        //      parts x 4 lists.  The two halves of a wave (lanes l, l ^ 32: same column, other rows) are merged here, by
-        //      shuffles: any subset of the bucket's scores gives a valid bound, and one top-PF_LK list per 64 rows x sampled
-        //      tiles still holds the sample's ten best unless five of them fall into the same 64 rows.  (The block-wide
-        //      merge through LDS this replaces -- 8 barriers, 32 threads merging serially -- was 15 % of pass 1.) ----
-        if (!idle) {
-#pragma unroll
-            for (int n = 0; n < NCB; ++n) {
-                float other[PF_LK];
-#pragma unroll
-                for (int j = 0; j < PF_LK; ++j) other[j] = __shfl_xor(lv[SAMPLE ? n : 0][j], 32, 64);
-#pragma unroll
-                for (int j = 0; j < PF_LK; ++j) vlist_insert(lv[SAMPLE ? n : 0], other[j]);
-                if (h == 0) {
-                    float* bl = P.bound + (((col0 + n * 32 + c) * (size_t)P.parts + ch) * 4 + wr) * PF_LK;
-#pragma unroll
-                    for (int j = 0; j < PF_LK; ++j) bl[j] = lv[SAMPLE ? n : 0][j];
-                }
-            }
-        }
-        PF_STAMP(6)   // pass 1: the merge of the value lists
-        PF_STAMPS_WRITE(nvt)
-    }
-};
-
-// 10th best of the union of a column's nparts x 4 sampled lists (each PF_LK values, sorted descending).  One lane per list
-// (LPC = 4 nparts lanes per column: 16, 32 or 64), the list in registers (one 16-byte load); ten steps of "largest head wins
-// and advances", the maximum over the column's lanes by butterfly steps.
-template <int LPC>
-__global__ __launch_bounds__(256) void bound_merge_kernel(const float* __restrict__ lists, long long ncols, float* __restrict__ bound1) {
-    const long long col = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / LPC;
-    const int li = threadIdx.x & (LPC - 1);
-    float v[PF_LK];
-#pragma unroll
-    for (int j = 0; j < PF_LK; ++j) v[j] = -INFINITY;
-    if (col < ncols) {
-        const float* src = lists + (col * LPC + li) * PF_LK;
-#pragma unroll
-        for (int j = 0; j < PF_LK; ++j) v[j] = src[j];
-    }
-    float pv = -INFINITY;
-#pragma unroll
-    for (int step = 0; step < KPB; ++step) {
-        float m = v[0];  // the lane's head; a winner shifts its list up by one
-        int who = li;
-#pragma unroll
-        for (int o = 1; o < LPC; o <<= 1) {
-            const float om = __shfl_xor(m, o, 64);
-            const int ow = __shfl_xor(who, o, 64);
-            if (om > m || (om == m && ow < who)) { m = om; who = ow; }
-        }
-        pv = m;  // -inf once the sample is exhausted: fewer than 10 sampled rows
-        if (who == li && m > -INFINITY) {
-#pragma unroll
-            for (int j = 0; j + 1 < PF_LK; ++j) v[j] = v[j + 1];
-            v[PF_LK - 1] = -INFINITY;
-        }
-    }
-    if (col < ncols && li == 0) bound1[col] = pv;
-}
-
-template <bool SAMPLE, int NG>
-__global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void prefilter_kernel(PrefilterParams P) {
-    __shared__ __attribute__((aligned(16))) uint4 sB0[4 * NG * PF_STAGE_G * 64];
-    __shared__ __attribute__((aligned(16))) uint4 sB1[4 * NG * PF_STAGE_G * 64];
-    __shared__ __attribute__((aligned(16))) uint4 sB2[4 * NG * PF_STAGE_G * 64];
-    __shared__ __attribute__((aligned(16))) uint4 sA0[4 * PF_RB * PF_STAGE_G * 64];
-    __shared__ __attribute__((aligned(16))) uint4 sA1[4 * PF_RB * PF_STAGE_G * 64];
-    __shared__ __attribute__((aligned(16))) uint4 sA2[4 * PF_RB * PF_STAGE_G * 64];
-    constexpr bool RING4 = NG == 2 && (SAMPLE ? LMI_PF_RING2_SAMPLE : LMI_PF_RING2) == 4;
-    __shared__ __attribute__((aligned(16))) uint4 sB3[RING4 ? 4 * NG * PF_STAGE_G * 64 : 1];
-    __shared__ __attribute__((aligned(16))) uint4 sA3[RING4 ? 4 * PF_RB * PF_STAGE_G * 64 : 1];
-    __shared__ uint2 sList[SAMPLE ? 1 : 4 * NG * PF_LIST];
-#define PF_ITEM_ARGS P, sB0, sB1, sB2, sA0, sA1, sA2, sB3, sA3, sList
-    int* s_item = reinterpret_cast<int*>(sB1);
-    int grp = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & (NGRP - 1));
-    if (!SAMPLE && P.redo_count && *P.redo_count == 0u) return;  // the redo launch of a batch without overflowed columns
-    for (;;) {
-        if (threadIdx.x == 0) {
-            int b = -1, local = 0;
-          do {
-            b = -1;
-            if (SAMPLE) {  // one plain queue of (bucket, query tile) items
-                const int tot = P.qt_base[P.L] * P.parts;
-                const int it = (int)atomicAdd(&P.head[NGRP], 1u);
-                if (it < tot) {
-                    const int pair = it / P.parts;  // (bucket, query tile) pair; parts adjacent in the queue
-                    int lo = 0, hi = P.L;
-                    while (hi - lo > 1) {
-                        const int mid = (lo + hi) >> 1;
-                        if (P.qt_base[mid] <= pair) lo = mid; else hi = mid;
-                    }
-                    b = P.by_work[lo];
-                    local = (pair - P.qt_base[lo]) * P.parts + (it % P.parts);
-                }
-            } else {
-                for (int tries = 0; tries < NGRP; ++tries) {
-                    const int tot = P.grp_total[grp];
-                    if (__hip_atomic_load(&P.head[grp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)tot) {
-                        const int it = (int)atomicAdd(&P.head[grp], 1u);
-                        if (it < tot) {
-                            const int* base = P.grp_base + grp * (P.L + 1);
-                            int lo = 0, hi = P.grp_n[grp];
-                            while (hi - lo > 1) {
-                                const int mid = (lo + hi) >> 1;
-                                if (base[mid] <= it) lo = mid; else hi = mid;
-                            }
-                            b = P.grp_bucket[grp * P.L + lo];
-                            local = it - base[lo];
-                            break;
-                        }
-                    }
-                    grp = (grp + 1) & (NGRP - 1);
-                }
-            }
-          } while (!SAMPLE && P.redo_bucket && b >= 0 && !P.redo_bucket[b]);  // redo launch: items of untouched buckets are dropped
-            s_item[0] = b;
-            s_item[1] = local;
-        }
-        __syncthreads();
-        const int b = s_item[0], local = s_item[1];
-        __syncthreads();
-        if (b < 0) return;
-        // query tiles of the bucket: its col-blocks split evenly over nqt = ceil(col-blocks / (4 NG)) tiles
-        // (route_scan_kernel / route_group_kernel count the same nqt); a tile's col-blocks split over the groups
-        const int ncb_b = (P.m[b] + 31) >> 5;
-        const int nqt = (ncb_b + 4 * NG - 1) / (4 * NG);
-        const int per = (ncb_b + nqt - 1) / nqt;
-        const int qt = SAMPLE ? local / P.parts : local % nqt, ch = SAMPLE ? local % P.parts : local / nqt;
-        const int cbt0 = qt * per;
-        const int ncb_tile = min(per, ncb_b - cbt0);
-        const int wgrp = (int)(threadIdx.x >> 8);
-        const int ncb_g0 = NG == 1 ? ncb_tile : (ncb_tile + 1) >> 1;
-        int ncb_w = wgrp ? ncb_tile - ncb_g0 : ncb_g0;
-        int cbofs = wgrp ? ncb_g0 : 0;
-        const bool idle = ncb_w == 0;
-        if (idle) { ncb_w = 1; cbofs = 0; }
-        switch (ncb_w) {
-            case 1: { PreItem<1, SAMPLE, NG> it{PF_ITEM_ARGS}; it.run(b, cbt0, ncb_tile, cbofs, idle, ch); break; }
-            case 2: { PreItem<2, SAMPLE, NG> it{PF_ITEM_ARGS}; it.run(b, cbt0, ncb_tile, cbofs, idle, ch); break; }
-            case 3: { PreItem<3, SAMPLE, NG> it{PF_ITEM_ARGS}; it.run(b, cbt0, ncb_tile, cbofs, idle, ch); break; }
-            default: { PreItem<4, SAMPLE, NG> it{PF_ITEM_ARGS}; it.run(b, cbt0, ncb_tile, cbofs, idle, ch); break; }
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // Select + exact re-rank: one wave per (query, rank) slot.

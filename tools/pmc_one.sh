@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 out="$1"; shift
 mkdir -p "$out"
 B="python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-recall --no-hard-leg"
-K="prefilter_kernel<false"
+K="pass2_kernel<false"
 for lib in "$@"; do
   tag=$(basename "$lib" .so)
   export LMI_LIB="$PWD/$lib"

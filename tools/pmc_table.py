@@ -3,7 +3,7 @@
 import csv, glob, os, sys
 from collections import defaultdict
 root = sys.argv[1]
-KERNEL = sys.argv[2] if len(sys.argv) > 2 else "prefilter_kernel<false"
+KERNEL = sys.argv[2] if len(sys.argv) > 2 else "pass2_kernel<false"
 for var in sorted(d for d in os.listdir(root) if os.path.isdir(os.path.join(root, d))):
     acc = defaultdict(list)
     dur = []
