@@ -226,6 +226,10 @@ LMI_API int lmi_prefilter_stats(lmi_index *h, int *active, int64_t *survivors, i
 /* Tuning: rows per scan chunk (multiple of the 256-row block tile).  Not called: lmi_buckets_begin picks
  * 256..2048 by the size of the index (this rank's rows / 4096), and more for buckets beyond 1024 chunks. */
 LMI_API int lmi_set_chunk_rows(lmi_index *h, int rows);
+/* Device memory (bytes) the per-call workspaces of one lmi_search / lmi_scan_topk of nq queries x n_buckets need on a built
+ * index -- the candidate buffers of the prefilter dominate (~10 KiB per (query, bucket) slot).  No reference counterpart (the
+ * reference holds no device memory); li/LearnedIndex.py sizes its query chunks from it. */
+LMI_API int lmi_workspace_bytes(lmi_index *h, int nq, int n_buckets, int64_t *bytes);
 
 /* Test hooks for the prefilter's error bound (tests/test_gpu_bound.py; no reference counterpart).
  * lmi_debug_emit_all(1): the next scans drop the sampled bound, so pass 2 emits EVERY row of a visited

@@ -68,6 +68,7 @@ SIGNATURES = {
     "lmi_timings_mean": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(ctypes.c_int)]),
     "lmi_scan_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double), _i64p, _i64p]),
     "lmi_set_chunk_rows": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "lmi_workspace_bytes": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _i64p]),
     "lmi_set_prefilter": (ctypes.c_int, [_vp, ctypes.c_int]),
     "lmi_debug_peek": (ctypes.c_int, [_vp, ctypes.c_char_p, _vp, ctypes.c_int64]),
     "lmi_clone_view": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
@@ -405,6 +406,12 @@ class Index:
         assert ids.shape == (n,) and ids.dtype == np.uint32 and ids.flags.c_contiguous
         _check(lib().lmi_bucket_read(self._h, int(b), _ptr(rows), _ptr(ids)))
         return rows, ids
+
+    def workspace_bytes(self, nq: int, nb: int) -> int:
+        """Device bytes the per-call workspaces of a search of nq queries x nb buckets need (lmi_workspace_bytes)."""
+        out = ctypes.c_int64(0)
+        _check(lib().lmi_workspace_bytes(self._h, int(nq), int(nb), ctypes.byref(out)))
+        return out.value
 
     def timings(self) -> np.ndarray:
         ms = np.zeros(T_COUNT, dtype=np.float32)

@@ -956,7 +956,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     CHK(h->part_base.reserve((L + 1) * 8));
     CHK(h->stats.reserve(32));
     CHK(h->head.reserve(128));
-    const size_t grp_ints = (size_t)NGRP * L + 2 * (size_t)NGRP * (L + 1) + 3 * NGRP + L + (L + 1);
+    const size_t grp_ints = (size_t)NGRP * L + 2 * (size_t)NGRP * (L + 1) + 3 * NGRP;
     CHK(h->grp.reserve(grp_ints * 4));
     CHK(h->slot_local.reserve((size_t)nslots * 4));
     CHK(h->slot_col.reserve((size_t)nslots * 4));
@@ -981,9 +981,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     R.grp_base = R.grp_bucket + (size_t)NGRP * L;
     R.grp_n = R.grp_base + (size_t)NGRP * (L + 1);
     R.grp_total = R.grp_n + NGRP;
-    R.order_tmp = R.grp_total + NGRP;
-    R.qt_base = R.order_tmp + L;
-    R.grp_base1 = R.qt_base + (L + 1);
+    R.grp_base1 = R.grp_total + NGRP;
     R.grp_total1 = R.grp_base1 + (size_t)NGRP * (L + 1);
     const bool v2 = h->prefilter && h->have16;   // the prefilter's kernels: lmi_pass2.h (tiles of up to 12 col-blocks)
     R.tile_cb = v2 ? P2_MAXCB : 4;
@@ -1248,6 +1246,35 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     h->last_nslots = nslots;
     h->last_nb = nb;
     h->last_fast = fast;
+    return 0;
+}
+
+// Device memory one lmi_search / lmi_scan_topk call of nq queries x nb buckets needs for its per-call workspaces (the
+// sizes scan_enqueue reserves, summed; host-pointer calls add the staged inputs and outputs).  A caller with a memory budget
+// sizes its query chunks from this instead of a constant (li/LearnedIndex.py).
+extern "C" LMI_API int lmi_workspace_bytes(lmi_index* h, int nq, int nb, int64_t* bytes) {
+    if (!h || !bytes) return fail("lmi_workspace_bytes: NULL argument");
+    if (nq < 0 || nb < 1) return fail("lmi_workspace_bytes: bad nq/n_buckets");
+    if (!h->built) return fail("lmi_workspace_bytes: the bucket index is not built");
+    const long long L = h->L, nslots = (long long)nq * nb;
+    const long long ncb = nslots / 32 + L + 4, ncols = ncb * 32;
+    const bool fast = h->prefilter && h->have16;
+    int max_nch = 0;
+    for (int b = 0; b < h->L; ++b) max_nch = std::max(max_nch, h->h_nch[b]);
+    long long t = 0;
+    t += nslots * (4 + 4 + 2 * KPB * 4);                         // slot_local, slot_col, rank lists
+    t += ncols * (4 + 4) + ncb * h->KGs * 1024;                  // colmap, col_thr, f32 query fragments
+    t += (long long)nq * h->d * 4 * 2 + nslots * 4 + (long long)nq * std::max(nb, KPB) * 12;   // staged queries, bucket order, outputs
+    if (fast) {
+        t += (long long)nq * 12 + ncb * h->KG16 * 1024;           // query norms / scales, fp16 query fragments
+        t += ncols * (4 + 4 + 2ll * PF_CAP * 4 + 1);             // eps2, candidate counts + buffers, redo flags
+        t += ncols * P2_NSL * 16 * 4 + 4096;                     // pass-1 lists
+        t += nslots * (4 + 4 + (long long)RC_KEEP * 4) + nslots; // fallback, nkeep, survivor rows, re-rank lists
+    } else {
+        t += std::max<long long>(1, (long long)nb * max_nch * nq) * KPB * 8;   // chunk partial lists of the exact scan
+    }
+    if (h->metric == LMI_METRIC_L2) t += (long long)nq * (h->d + 1) * 4;
+    *bytes = t;
     return 0;
 }
 

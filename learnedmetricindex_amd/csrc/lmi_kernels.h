@@ -309,13 +309,11 @@ struct RouteArrays {
     int* grp_base;        // [NGRP][L+1] prefix of the buckets' item counts inside the group
     int* grp_n;           // [NGRP]      buckets in the group
     int* grp_total;       // [NGRP]      items in the group
-    int* order_tmp;       // [L] buckets sorted by work, heaviest first
-    int* qt_base;         // [L+1] prefix of the query-tile counts of order_tmp[0..] (prefilter pass-1 items)
     int* grp_base1;       // [NGRP][L+1] the same prefix for the pass-1 items (query tiles x sampled tiles) of lmi_pass2.h
     int* grp_total1;      // [NGRP]
     int tile_cb;          // col-blocks per query tile: 4 (exact scan), 12 (prefilter: lmi_pass2.h), 8 (the round-2 prefilter kernel)
     int primary_nb;       // > 0 (= n_buckets): a slot is primary iff no lower rank of its query holds a bucket of >= 64 rows here
-    int sample_items;     // 1: qt_base counts pass-1 items of lmi_pass2.h = query tiles x SAMPLED 256-row tiles of the bucket
+    int sample_items;     // 1: also build the pass-1 queues of lmi_pass2.h (grp_base1 / grp_total1: query tiles x SAMPLED tiles)
 };
 
 // ---- prefilter pass 1: which tiles of a bucket are sampled (shared by the routing kernels and lmi_prefilter.h / lmi_pass2.h) ----
@@ -483,17 +481,6 @@ __global__ __launch_bounds__(1024) void route_group_kernel(int L, RouteArrays R)
         order_s[rank] = b;
     }
     __syncthreads();
-    // query-tile prefix over the buckets heaviest first (prefilter pass-1 queue: LPT); thread i sums its own
-    // prefix (a serial scan by one thread was the kernel's critical path)
-    for (int i = t; i <= L; i += 1024) {
-        int q = 0;
-        for (int j = 0; j < i; ++j) {
-            const int bj = order_s[j];
-            q += query_tiles(m_s[bj], R.tile_cb) * (R.sample_items ? sample_tiles256(R.nb_rows[bj]) : 1);
-        }
-        R.qt_base[i] = q;
-        if (i < L) R.order_tmp[i] = order_s[i];
-    }
     // Buckets -> queues in "snake" order over the work-sorted list (ranks 0..7 -> queues 0..7, ranks 8..15 ->
     // queues 7..0, ..): every thread places its own bucket, the prefix of a queue's item counts is a loop
     // over its <= L/8 earlier members.  (Exact LPT is serial: 54-73 us at L = 120 whichever way it was

@@ -98,6 +98,9 @@ __device__ __forceinline__ void select_tail(const RescoreParams& P, const Select
     const unsigned cbits = __float_as_uint(cut);
     const unsigned kcut = cut != cut ? 1u : cbits ^ ((cbits >> 31) ? 0xffffffffu : 0x80000000u);
     unsigned* out = O.surv_row + (size_t)p * RC_KEEP;
+    // survivors are stored as ABSOLUTE slab rows (bucket start + row): the re-rank wave then needs no bucket_order -> rb_start
+    // round trips before it can request the rows (its waves run one per SIMD: every dependent load is exposed latency)
+    const unsigned row_base = (unsigned)P.rb_start[P.bucket_order[p]] * 32u;
     unsigned nk = 0;
 #pragma unroll
     for (int i = 0; i < PERV; ++i) {
@@ -106,7 +109,7 @@ __device__ __forceinline__ void select_tail(const RescoreParams& P, const Select
             const unsigned long long bal = __ballot(keep);
             if (keep) {
                 const unsigned k = nk + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
-                if (k < (unsigned)RC_KEEP) out[k] = i < SPEC ? r_spec[i < SPEC ? i : 0] : cr[lane + 64 * i];
+                if (k < (unsigned)RC_KEEP) out[k] = row_base + (i < SPEC ? r_spec[i < SPEC ? i : 0] : cr[lane + 64 * i]);
             }
             nk += (unsigned)__popcll(bal);
         }
@@ -193,12 +196,15 @@ __global__ __launch_bounds__(64 * RC_WAVES, 1) void rescore_kernel(RescoreParams
     // the survivor lists of the wave's slots, slot after slot, and the wave's query (G divides nb: one query per wave)
     int off[G + 1];
     off[0] = 0;
+    int colv[G], fbv[G], nkv[G];   // all 3 G loads in flight together (a short-circuit `&&` chained them: three round trips per slot)
+#pragma unroll
+    for (int sl = 0; sl < G; ++sl) { colv[sl] = P.slot_col[p0 + sl]; fbv[sl] = P.fallback[p0 + sl]; nkv[sl] = P.nkeep[p0 + sl]; }
+#pragma unroll
+    for (int sl = 0; sl < G; ++sl) off[sl + 1] = off[sl] + ((colv[sl] >= 0 && !fbv[sl]) ? nkv[sl] : 0);   // wave-uniform
 #pragma unroll
     for (int sl = 0; sl < G; ++sl) {
-        const int p = p0 + sl;
-        const int nk = (P.slot_col[p] >= 0 && !P.fallback[p]) ? P.nkeep[p] : 0;   // wave-uniform
-        for (int i = lane; i < nk; i += 64) krow[off[sl] + i] = O.surv_row[(size_t)p * RC_KEEP + i];
-        off[sl + 1] = off[sl] + nk;
+        const int nk = off[sl + 1] - off[sl];
+        for (int i = lane; i < nk; i += 64) krow[off[sl] + i] = O.surv_row[(size_t)(p0 + sl) * RC_KEEP + i];
     }
     const int total = off[G];
     const float* qg = P.q + (size_t)(p0 / P.nb) * d;
@@ -211,6 +217,13 @@ __global__ __launch_bounds__(64 * RC_WAVES, 1) void rescore_kernel(RescoreParams
     // the bound is per query: 2 pieces instead of the 9 that cover 64 rows -- issuing the unused ones was most of the kernel's time).
     auto run_batch = [&](auto np_c, int base) {
         constexpr int NP = decltype(np_c)::value;
+        // the wave's RC_DEPTH x RC_BUF bytes of chunk buffers, cut into buffers of NP pieces: fewer rows -> MORE chunks in flight
+        // (13 instead of 3 at NP = 2).  A wave of ~13 rows waited 24 x for a 2-deep pipeline of 128-byte row segments: latency,
+        // not bandwidth (profiles/r03_pass2_experiments.txt, section 12).
+        constexpr int BUFB = NP * 1024;
+        constexpr int DEPTH_RAW = (RC_DEPTH * RC_BUF) / BUFB;
+        constexpr int DEPTH = DEPTH_RAW > 16 ? 16 : ((DEPTH_RAW - 1) * NP > 60 ? 60 / NP + 1 : DEPTH_RAW);
+        static_assert(DEPTH >= 2 && (DEPTH - 1) * NP <= 63, "vmcnt literal");
         const int nrows = min(RC_ROWS, total - base);
         // DMA plan: piece pc, lane i writes LDS bytes [pc*1024 + 16 i, +16) of the chunk buffer = row r, byte col of the
         // pitch; its source is row r's chunk + col.  (r, col) do not depend on the chunk: one source
@@ -228,8 +241,8 @@ __global__ __launch_bounds__(64 * RC_WAVES, 1) void rescore_kernel(RescoreParams
             const int i = base + (okl ? r : 0);
 #pragma unroll
             for (int t = 1; t < G; ++t) sl += i >= off[t] ? 1 : 0;
-            const int b = P.bucket_order[p0 + sl];
-            src[pc] = P.rows + ((size_t)P.rb_start[b] * 32 + krow[i]) * d + (okl ? cb / 4 : 0);
+            (void)sl;
+            src[pc] = P.rows + (size_t)krow[i] * d + (okl ? cb / 4 : 0);
             colb[pc] = okl ? (unsigned)cb : 0u;
         }
         auto issue = [&](int c, unsigned char* buf) {
@@ -243,18 +256,18 @@ __global__ __launch_bounds__(64 * RC_WAVES, 1) void rescore_kernel(RescoreParams
         };
         float acc = 0.0f;
 #pragma unroll
-        for (int c = 0; c < RC_DEPTH - 1; ++c)
-            if (c < nchunks) issue(c, mine + c * RC_BUF);
-        int slot = 0;  // c % RC_DEPTH
+        for (int c = 0; c < DEPTH - 1; ++c)
+            if (c < nchunks) issue(c, mine + c * BUFB);
+        int slot = 0;  // c % DEPTH
         for (int c = 0; c < nchunks; ++c) {
-            unsigned char* cur = mine + slot * RC_BUF;
-            const int ahead = min(RC_DEPTH - 1, nchunks - 1 - c);  // chunks that may stay in flight once chunk c has landed
-            if (c + RC_DEPTH - 1 < nchunks) issue(c + RC_DEPTH - 1, mine + (slot == 0 ? RC_DEPTH - 1 : slot - 1) * RC_BUF);
-            if (ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * NP) : "memory");
-            else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NP) : "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NP) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            slot = slot + 1 == RC_DEPTH ? 0 : slot + 1;
+            unsigned char* cur = mine + slot * BUFB;
+            if (c + DEPTH - 1 < nchunks) {   // steady state: chunk c has landed once only the DEPTH - 1 younger chunks are outstanding
+                issue(c + DEPTH - 1, mine + (slot == 0 ? DEPTH - 1 : slot - 1) * BUFB);
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"((DEPTH - 1) * NP) : "memory");
+            } else {                          // the row's tail: everything still in flight (one more latency, then the waits are free)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            slot = slot + 1 == DEPTH ? 0 : slot + 1;
             if (lane < nrows) {
                 typedef float f32x4 __attribute__((ext_vector_type(4)));
                 const unsigned xa = (unsigned)reinterpret_cast<uintptr_t>(cur) + (unsigned)lane * RC_PITCH;
@@ -311,9 +324,9 @@ __global__ __launch_bounds__(64 * RC_WAVES, 1) void rescore_kernel(RescoreParams
             for (int j = lo; j < hi; ++j) pos += better(ksc[j], krow[j], sc, row) ? 1 : 0;
             if (pos < KPB) {
                 const int p = p0 + sl;
-                const int b = P.bucket_order[p];
                 P.rank_d[(size_t)p * KPB + pos] = P.raw ? sc : sim_to_dist(sc, P.qn2, p / P.nb);
-                P.rank_id[(size_t)p * KPB + pos] = P.raw ? row : P.ids_slab[(size_t)P.rb_start[b] * 32 + row];
+                // (krow holds absolute slab rows; the raw form -- lmi_knn_ip -- returns the row inside its bucket)
+                P.rank_id[(size_t)p * KPB + pos] = P.raw ? row - (unsigned)P.rb_start[P.bucket_order[p]] * 32u : P.ids_slab[row];
             }
         }
     }

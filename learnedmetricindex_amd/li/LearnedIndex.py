@@ -216,9 +216,11 @@ class LearnedIndex(Logger):
         if nq == 0:
             kout = _capi.Index.kout(n_buckets, k)
             return np.empty((0, kout)), np.empty((0, kout), dtype=np.uint32), measured_time
-        # The prefilter's per-call workspace is ~8.7 KiB per (query, bucket) slot (candidate buffers): large
-        # batches x many buckets are answered in query chunks that keep it under _WORKSPACE_BYTES.
-        step = max(1, min(nq, self._WORKSPACE_BYTES // (8900 * max(1, n_buckets))))
+        # The prefilter's per-call workspace is ~10 KiB per (query, bucket) slot (candidate buffers): large batches x many
+        # buckets are answered in query chunks that keep it under _WORKSPACE_BYTES.  The library says what a call needs.
+        fixed = eng.workspace_bytes(0, n_buckets)
+        per_query = max(1, (eng.workspace_bytes(1024, n_buckets) - fixed) // 1024)
+        step = max(1, min(nq, (self._WORKSPACE_BYTES - fixed) // per_query if self._WORKSPACE_BYTES > fixed else 1))
         if len(n_categories) > 1:
             step = min(step, self._nav_chunk())
         parts_d, parts_n = [], []

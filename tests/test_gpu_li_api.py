@@ -201,7 +201,8 @@ def test_resident_cache_key_and_query_chunks(oracle):
     d1, n1, _ = li.search(df, Qn, df, Qs, dp.copy(), [12], 3, 10)      # same contents, another array: cache hit
     assert li._engine is eng
     np.testing.assert_array_equal(n1, n)
-    li._WORKSPACE_BYTES = 8900 * 3 * 37                                   # 37 queries per chunk
+    li._WORKSPACE_BYTES = eng.workspace_bytes(37, 3)                      # ~37 queries per chunk (lmi_workspace_bytes)
+    assert eng.workspace_bytes(200, 3) > li._WORKSPACE_BYTES > eng.workspace_bytes(0, 3)
     d2, n2, mt = li.search(df, Qn, df, Qs, dp, [12], 3, 10)
     np.testing.assert_array_equal(n2, n)
     np.testing.assert_array_equal(d2, d)
