@@ -17,6 +17,9 @@
 // The B-fragment reads run D = 3 fragments ahead of the MFMAs as ONE stream that continues across the stage barrier: the
 // last D MFMAs of a stage are issued after the next stage's barrier, interleaved with its first reads (a stage's first
 // fragment would otherwise be waited for by both waves of a SIMD at once, MFMA pipe idle).
+// (Also measured, round 3, and removed again: a 2-D wave tiling -- a wave = 2 row-blocks x <= 6 col-blocks, 16 fragment reads per
+// 24 MFMAs instead of 26 -- parity-green and exactly as fast (pass 2 4.18-4.21 ms either way): LDS read traffic is not what the
+// kernel's power budget goes to.  profiles/r03_pass2_experiments.txt, section 13.)
 // Pass 1 (SAMPLE) = the same tile on sampled tiles only; one item per (bucket, query tile, sampled tile); per lane and
 // col-block the MAXIMUM of its 16 scores is all it keeps: the slot maxima of a column come from disjoint rows, so the 10th
 // largest of them is the 10th best of a subset of the bucket = a valid lower bound of That (lmi_prefilter.h, header).
