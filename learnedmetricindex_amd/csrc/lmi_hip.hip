@@ -217,10 +217,14 @@ extern "C" LMI_API int lmi_create(int device, lmi_index** out) {
     if (const char* e = getenv("LMI_PF_QBOUND")) h->pf_qbound = e[0] && e[0] != '0';
     if (const char* e = getenv("LMI_PF_PRIMARY")) h->pf_primary = e[0] && e[0] != '0';
     // per handle = per device (a process may hold handles on several devices; the attribute is per device)
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     *out = h;
     return 0;
 }
@@ -1180,26 +1184,30 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
             CHK(h->surv_row.reserve((size_t)nslots * RC_KEEP * 4));
             CHK(h->rs_flag.reserve((size_t)groups * 4));
             const int sub_cap = cdiv(groups, RC_SUB);
-            CHK(h->rs_active.reserve((size_t)(RC_SUB + RC_SUB * sub_cap) * 4));
+            CHK(h->rs_active.reserve((size_t)(RC_SUB + RC_SUB * sub_cap) * 4 + (size_t)(1 + groups) * 4));
             SelectOut O;
             O.surv_row = h->surv_row.as<unsigned>();
             O.G = G;
             O.grp_flag = h->rs_flag.as<int>();
             O.active = h->rs_active.as<int>();
             O.sub_cap = sub_cap;
+            O.big = O.active + RC_SUB + RC_SUB * sub_cap;
             {
                 FillRanges Zr;
-                Zr.count = 2;
+                Zr.count = 3;
                 Zr.p[0] = reinterpret_cast<unsigned*>(O.grp_flag); Zr.n[0] = groups; Zr.v[0] = 0u;
                 Zr.p[1] = reinterpret_cast<unsigned*>(O.active); Zr.n[1] = RC_SUB; Zr.v[1] = 0u;
+                Zr.p[2] = reinterpret_cast<unsigned*>(O.big); Zr.n[2] = 1; Zr.v[2] = 0u;
                 fill_ranges_kernel<<<cdiv(groups, 1024), 256, 0, h->stream>>>(Zr);
                 HIPCHK(hipGetLastError());
             }
             select_kernel<<<cdiv(nslots, 4), 256, 0, h->stream>>>(Q, O);
             HIPCHK(hipGetLastError());
             const int blocks = cdiv(groups, RC_WAVES);
-            const int lds = RC_WAVES * rc_wave_lds(h->d, G);
-#define LMI_RC_LAUNCH(GV) { rescore_kernel<GV><<<blocks, 64 * RC_WAVES, lds, h->stream>>>(Q, O); }
+            const int lds = RC_WAVES * rc_wave_lds(h->d, G), lds_s = RC_WAVES * rc_wave_lds(h->d, G, true);
+            // first every group in the small-LDS form (three blocks per CU), then the groups it passed on (more survivors than it holds)
+#define LMI_RC_LAUNCH(GV) { rescore_kernel<GV, true><<<blocks, 64 * RC_WAVES, lds_s, h->stream>>>(Q, O); \
+                            rescore_kernel<GV, false><<<blocks, 64 * RC_WAVES, lds, h->stream>>>(Q, O); }
             if (G == 4) LMI_RC_LAUNCH(4) else if (G == 3) LMI_RC_LAUNCH(3) else if (G == 2) LMI_RC_LAUNCH(2) else LMI_RC_LAUNCH(1)
 #undef LMI_RC_LAUNCH
             HIPCHK(hipGetLastError());

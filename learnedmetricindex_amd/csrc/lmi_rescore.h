@@ -60,6 +60,7 @@ struct SelectOut {
                           // [RC_SUB][sub_cap] group numbers; group g goes to sub-list g % RC_SUB (10 000 returning atomics on
                           // ONE counter were most of select_kernel's 139 us)
     int sub_cap;          // ceil(groups / RC_SUB)
+    int* big;             // [1 + groups] groups with more survivors than the small-LDS launch holds: count, then group numbers
 };
 constexpr int RC_SUB = 64;
 
@@ -167,31 +168,47 @@ __global__ __launch_bounds__(256) void select_kernel(RescoreParams P, SelectOut 
     else select_tail<PER, SPEC>(P, O, p, col, lane, cnt, cs, cr, s_spec, r_spec);
 }
 
-// dynamic LDS per wave: RC_DEPTH chunk buffers | q [d] | rows [G*RC_KEEP] | scores [G*RC_KEEP]
-__host__ __device__ inline int rc_wave_lds(int d, int G) { return RC_DEPTH * RC_BUF + d * 4 + G * RC_KEEP * 8; }
+// Two launches share the code.  SMALL: every active group (query); a wave holds at most RC_SMALL_ROWS survivors -- since the bound is
+// per query a wave has ~13 -- in 11.5 KiB of LDS (d = 768), three blocks per CU: the kernel is a chain of dependent loads at low
+// occupancy, so more waves in flight is what it needs; a group with more survivors goes onto the `big` list and the second launch
+// (!SMALL: one wave per SIMD, room for G x RC_KEEP survivors) takes those.
+constexpr int RC_SMALL_ROWS = 28;                 // 4 LDS-DMA pieces of 7 rows
+constexpr int RC_SMALL_RING = 8 * 1024;           // chunk buffers of the small form (4 x 2 pieces or 2 x 4 pieces)
+// dynamic LDS per wave: chunk buffers | q [d] | rows [KEEPW] | scores [KEEPW]
+__host__ __device__ inline int rc_wave_lds(int d, int G, bool small_form = false) {
+    return small_form ? RC_SMALL_RING + d * 4 + 32 * 8 : RC_DEPTH * RC_BUF + d * 4 + G * RC_KEEP * 8;
+}
 static_assert(RC_CHUNK % 32 == 0 && (RC_ROWS == 32 || RC_ROWS == 64) && RC_DEPTH >= 2 && RC_DEPTH <= 4, "rescore_kernel shapes");
 
-template <int G>
-__global__ __launch_bounds__(64 * RC_WAVES, 1) void rescore_kernel(RescoreParams P, SelectOut O) {
+template <int G, bool SMALL>
+__global__ __launch_bounds__(64 * RC_WAVES, SMALL ? 3 : 1) void rescore_kernel(RescoreParams P, SelectOut O) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rc_smem[];
+    constexpr int RINGB = SMALL ? RC_SMALL_RING : RC_DEPTH * RC_BUF;
+    constexpr int KEEPW = SMALL ? 32 : G * RC_KEEP;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wid = blockIdx.x * RC_WAVES + wv;
-    // wave wid -> the wid-th entry of the concatenated sub-lists (inclusive prefix of the 64 counts across the lanes)
-    int incl = O.active[lane];
+    int p0;
+    if (SMALL) {
+        // wave wid -> the wid-th entry of the concatenated sub-lists (inclusive prefix of the 64 counts across the lanes)
+        int incl = O.active[lane];
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int up = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += up;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        const int sub = (int)__popcll(__ballot(incl <= wid));  // sub-lists that end at or before entry wid
+        if (sub >= RC_SUB) return;                             // wid >= total
+        const int before = sub ? __shfl(incl, sub - 1, 64) : 0;
+        p0 = O.active[RC_SUB + sub * O.sub_cap + (wid - before)] * G;
+    } else {
+        if (wid >= O.big[0]) return;
+        p0 = O.big[1 + wid] * G;
     }
-    const int sub = (int)__popcll(__ballot(incl <= wid));  // sub-lists that end at or before entry wid
-    if (sub >= RC_SUB) return;                             // wid >= total
-    const int before = sub ? __shfl(incl, sub - 1, 64) : 0;
-    const int p0 = O.active[RC_SUB + sub * O.sub_cap + (wid - before)] * G;
     const int d = P.d;
-    unsigned char* mine = rc_smem + (size_t)wv * rc_wave_lds(d, G);
-    float* qs = reinterpret_cast<float*>(mine + RC_DEPTH * RC_BUF);
-    unsigned* krow = reinterpret_cast<unsigned*>(mine + RC_DEPTH * RC_BUF + d * 4);
-    float* ksc = reinterpret_cast<float*>(krow + G * RC_KEEP);
+    unsigned char* mine = rc_smem + (size_t)wv * rc_wave_lds(d, G, SMALL);
+    float* qs = reinterpret_cast<float*>(mine + RINGB);
+    unsigned* krow = reinterpret_cast<unsigned*>(mine + RINGB + d * 4);
+    float* ksc = reinterpret_cast<float*>(krow + KEEPW);
     const float FMAXV = 3.402823466e+38f;
     // the survivor lists of the wave's slots, slot after slot, and the wave's query (G divides nb: one query per wave)
     int off[G + 1];
@@ -201,6 +218,10 @@ __global__ __launch_bounds__(64 * RC_WAVES, 1) void rescore_kernel(RescoreParams
     for (int sl = 0; sl < G; ++sl) { colv[sl] = P.slot_col[p0 + sl]; fbv[sl] = P.fallback[p0 + sl]; nkv[sl] = P.nkeep[p0 + sl]; }
 #pragma unroll
     for (int sl = 0; sl < G; ++sl) off[sl + 1] = off[sl] + ((colv[sl] >= 0 && !fbv[sl]) ? nkv[sl] : 0);   // wave-uniform
+    if (SMALL && off[G] > RC_SMALL_ROWS) {   // more than this launch holds: the second launch takes the group
+        if (lane == 0) O.big[1 + atomicAdd(&O.big[0], 1)] = p0 / G;
+        return;
+    }
 #pragma unroll
     for (int sl = 0; sl < G; ++sl) {
         const int nk = off[sl + 1] - off[sl];
@@ -221,7 +242,7 @@ __global__ __launch_bounds__(64 * RC_WAVES, 1) void rescore_kernel(RescoreParams
         // (13 instead of 3 at NP = 2).  A wave of ~13 rows waited 24 x for a 2-deep pipeline of 128-byte row segments: latency,
         // not bandwidth (profiles/r03_pass2_experiments.txt, section 12).
         constexpr int BUFB = NP * 1024;
-        constexpr int DEPTH_RAW = (RC_DEPTH * RC_BUF) / BUFB;
+        constexpr int DEPTH_RAW = RINGB / BUFB;
         constexpr int DEPTH = DEPTH_RAW > 16 ? 16 : ((DEPTH_RAW - 1) * NP > 60 ? 60 / NP + 1 : DEPTH_RAW);
         static_assert(DEPTH >= 2 && (DEPTH - 1) * NP <= 63, "vmcnt literal");
         const int nrows = min(RC_ROWS, total - base);
@@ -303,8 +324,8 @@ __global__ __launch_bounds__(64 * RC_WAVES, 1) void rescore_kernel(RescoreParams
     for (int base = 0; base < total; base += RC_ROWS) {
         const int np = (min(RC_ROWS, total - base) * RC_PITCH + 1023) / 1024;   // wave-uniform
         if (np <= 2) run_batch(std::integral_constant<int, 2>{}, base);
-        else if (np <= 4 && RC_PIECES > 4) run_batch(std::integral_constant<int, (RC_PIECES > 4 ? 4 : RC_PIECES)>{}, base);
-        else run_batch(std::integral_constant<int, RC_PIECES>{}, base);
+        else if (SMALL || (np <= 4 && RC_PIECES > 4)) run_batch(std::integral_constant<int, (RC_PIECES > 4 ? 4 : RC_PIECES)>{}, base);
+        else { if constexpr (!SMALL) run_batch(std::integral_constant<int, RC_PIECES>{}, base); }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
