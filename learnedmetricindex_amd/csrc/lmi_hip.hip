@@ -730,7 +730,7 @@ static int record(lmi_index* h, int i) {
     // every recorded event is a ~6 us bubble between two kernels: level 1 keeps the call's first and last
     // event (LMI_T_TOTAL), level 0 none
     if (h->timing_level == 0 || (h->timing_level == 1 && i != 0 && i != 1 && i != 4)) return 0;
-    if (!h->ev[i]) HIPCHK(hipEventCreateWithFlags(&h->ev[i], hipEventDefault));
+    if (!h->ev[i]) HIPCHK(hipEventCreateWithFlags(&h->ev[i], hipEventDisableSystemFence));   // timing only: no system-scope release at the record
     HIPCHK(hipEventRecord(h->ev[i], h->stream));
     h->ev_valid[i] = true;
     return 0;
@@ -1207,7 +1207,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
             const int lds = RC_WAVES * rc_wave_lds(h->d, G), lds_s = RC_WAVES * rc_wave_lds(h->d, G, true);
             // first every group in the small-LDS form (three blocks per CU), then the groups it passed on (more survivors than it holds)
 #define LMI_RC_LAUNCH(GV) { rescore_kernel<GV, true><<<blocks, 64 * RC_WAVES, lds_s, h->stream>>>(Q, O); \
-                            rescore_kernel<GV, false><<<blocks, 64 * RC_WAVES, lds, h->stream>>>(Q, O); }
+                            rescore_kernel<GV, false><<<std::min(blocks, h->num_cus), 64 * RC_WAVES, lds, h->stream>>>(Q, O); }
             if (G == 4) LMI_RC_LAUNCH(4) else if (G == 3) LMI_RC_LAUNCH(3) else if (G == 2) LMI_RC_LAUNCH(2) else LMI_RC_LAUNCH(1)
 #undef LMI_RC_LAUNCH
             HIPCHK(hipGetLastError());

@@ -181,29 +181,9 @@ __host__ __device__ inline int rc_wave_lds(int d, int G, bool small_form = false
 static_assert(RC_CHUNK % 32 == 0 && (RC_ROWS == 32 || RC_ROWS == 64) && RC_DEPTH >= 2 && RC_DEPTH <= 4, "rescore_kernel shapes");
 
 template <int G, bool SMALL>
-__global__ __launch_bounds__(64 * RC_WAVES, SMALL ? 3 : 1) void rescore_kernel(RescoreParams P, SelectOut O) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char rc_smem[];
+__device__ __forceinline__ void rescore_group(const RescoreParams& P, const SelectOut& O, unsigned char* rc_smem, int wv, int lane, int p0) {
     constexpr int RINGB = SMALL ? RC_SMALL_RING : RC_DEPTH * RC_BUF;
     constexpr int KEEPW = SMALL ? 32 : G * RC_KEEP;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int wid = blockIdx.x * RC_WAVES + wv;
-    int p0;
-    if (SMALL) {
-        // wave wid -> the wid-th entry of the concatenated sub-lists (inclusive prefix of the 64 counts across the lanes)
-        int incl = O.active[lane];
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int up = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += up;
-        }
-        const int sub = (int)__popcll(__ballot(incl <= wid));  // sub-lists that end at or before entry wid
-        if (sub >= RC_SUB) return;                             // wid >= total
-        const int before = sub ? __shfl(incl, sub - 1, 64) : 0;
-        p0 = O.active[RC_SUB + sub * O.sub_cap + (wid - before)] * G;
-    } else {
-        if (wid >= O.big[0]) return;
-        p0 = O.big[1 + wid] * G;
-    }
     const int d = P.d;
     unsigned char* mine = rc_smem + (size_t)wv * rc_wave_lds(d, G, SMALL);
     float* qs = reinterpret_cast<float*>(mine + RINGB);
@@ -364,6 +344,35 @@ __global__ __launch_bounds__(64 * RC_WAVES, SMALL ? 3 : 1) void rescore_kernel(R
                 P.rank_d[(size_t)p * KPB + lane] = P.raw ? -FMAXV : pad_dist(P.qn2);
                 P.rank_id[(size_t)p * KPB + lane] = P.raw ? NOROW : P.ids_slab[(size_t)rb0 * 32 + (n_b - 1)];
             }
+        }
+    }
+}
+
+template <int G, bool SMALL>
+__global__ __launch_bounds__(64 * RC_WAVES, SMALL ? 3 : 1) void rescore_kernel(RescoreParams P, SelectOut O) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rc_smem[];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * RC_WAVES + wv;
+    if (SMALL) {
+        // wave wid -> the wid-th entry of the concatenated sub-lists (inclusive prefix of the 64 counts across the lanes)
+        int incl = O.active[lane];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        const int sub = (int)__popcll(__ballot(incl <= wid));  // sub-lists that end at or before entry wid
+        if (sub >= RC_SUB) return;                             // wid >= total
+        const int before = sub ? __shfl(incl, sub - 1, 64) : 0;
+        rescore_group<G, true>(P, O, rc_smem, wv, lane, O.active[RC_SUB + sub * O.sub_cap + (wid - before)] * G);
+    } else {
+        // the passed-on groups are few (none on most batches): a grid of one block per CU walks the list, so that an empty list
+        // costs one launch of 256 blocks and not one block (148 KiB of LDS each, one per CU at a time) per four groups
+        const int nbig = __builtin_amdgcn_readfirstlane(O.big[0]);
+        for (int i = wid; i < nbig; i += (int)gridDim.x * RC_WAVES) {
+            rescore_group<G, false>(P, O, rc_smem, wv, lane, O.big[1 + i] * G);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the wave's LDS lists are rewritten by its next group
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
