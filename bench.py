@@ -251,6 +251,10 @@ class Workload:
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
         res["scan_stats"] = eng.scan_stats()
         res["pf_stats"] = eng.prefilter_stats()
+        try:   # candidates pass 2 emitted for the last batch (all columns)
+            res["pf_candidates"] = int(eng.debug_peek("cand_total", 8).view(np.uint64)[0]) if not self.args.exact else 0
+        except Exception:  # noqa: BLE001
+            res["pf_candidates"] = None
         try:   # columns whose candidate buffer overflowed in the last batch (they get a second run of pass 2)
             res["pf_redo_columns"] = int(eng.debug_peek("pf_redo", 4).view(np.uint32)[0]) if not self.args.exact else 0
         except Exception:  # noqa: BLE001
@@ -449,8 +453,9 @@ def dominant_roofline(args, cfg, res, sizes, owner, rank, capi):
     if args.exact:
         kernel, op_bytes, peak_tf = "lmi::scan_kernel", 4, PEAK_F32_MFMA_TFLOPS
     else:
-        kernel, op_bytes, peak_tf = "lmi::pass2_kernel<false>", 2, PEAK_F16_MFMA_TFLOPS
-    dpad = -(-d // 32) * 32 if not args.exact else d   # the fp16 slab pads K to a multiple of 32 (two k16-groups per stage)
+        kernel, op_bytes, peak_tf = ("lmi::pass2_kernel<false>" if d > 128 else "lmi::pass2_small_kernel<KG, false>"), 2, PEAK_F16_MFMA_TFLOPS
+    # the fp16 slab pads K to whole k16-groups (d <= 128, lmi_pass2_small.h) or to pairs of them (a stage of pass2_kernel holds two)
+    dpad = d if args.exact else (-(-d // 16) * 16 if d <= 128 else -(-d // 32) * 32)
     alg_bytes = op_bytes * d * (rows_visited + nq * nb)
     t_mfma, t_hbm = flops / (peak_tf * 1e12), alg_bytes / (PEAK_HBM_GBS * 1e9)
     if t_mfma >= t_hbm:
@@ -746,7 +751,8 @@ def main():
                        "scan_pairs": int(pairs), "scan_items": int(items)},
             "roofline": roof,
             "prefilter": None if args.exact else {"survivors_per_slot": round(pf_survivors / max(1, nq * nb), 2),
-                                                   "fallback_slots": int(pf_fallbacks), "overflowed_columns": res.get("pf_redo_columns")},
+                                                   "fallback_slots": int(pf_fallbacks), "overflowed_columns": res.get("pf_redo_columns"),
+                                                   "candidates": res.get("pf_candidates")},
             "cpu_baseline": cpu,
             "resident": resident,
             "sharded_alt_mode": alt,

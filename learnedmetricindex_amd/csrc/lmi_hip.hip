@@ -4,6 +4,7 @@
 #include "lmi_kernels.h"
 #include "lmi_prefilter.h"
 #include "lmi_pass2.h"
+#include "lmi_pass2_small.h"
 #include "lmi_mlp_fused.h"
 #include "lmi_rescore.h"
 
@@ -140,9 +141,11 @@ struct lmi_index {
     DevBuf qnorm, qscale, qfrag16, eps2, cand_cnt, cand_row, cand_s, fallback, pf_bound, nkeep, surv_row, rs_flag, rs_active;
     DevBuf redo;   // [1] count | [L] bucket flags | [columns] column flags (bytes): overflow_rebound_kernel
     size_t stamps_off = 0;         // developer builds: byte offset of the phase stamps inside pf_bound
+    bool pf_small = true;          // d <= 128: pass2_small_kernel (LMI_PF_SMALL=0 in the environment: pass2_kernel for every d)
     bool pf_redo = true;           // overflow_rebound_kernel + pass 2's redo launch (LMI_PF_NO_REDO=1 in the environment: off)
     bool rescore_streamed = true;  // lmi_rescore.h (LMI_RESCORE_SIMPLE=1 in the environment: select_rescore_kernel)
     int last_nslots = 0, last_nb = 0;
+    long long last_ncols = 0;
     bool last_fast = false;
     bool pf_qbound = true;        // LMI_PF_QBOUND=0: per-bucket bounds only (query_bound_kernel off)
     bool pf_primary = true;       // LMI_PF_PRIMARY=0: pass 1 samples every column although one bound per query is used
@@ -214,9 +217,15 @@ extern "C" LMI_API int lmi_create(int device, lmi_index** out) {
     }
     if (const char* e = getenv("LMI_RESCORE_SIMPLE")) h->rescore_streamed = !(e[0] && e[0] != '0');
     if (const char* e = getenv("LMI_PF_NO_REDO")) h->pf_redo = !(e[0] && e[0] != '0');
+    if (const char* e = getenv("LMI_PF_SMALL")) h->pf_small = !(e[0] == '0');
     if (const char* e = getenv("LMI_PF_QBOUND")) h->pf_qbound = e[0] && e[0] != '0';
     if (const char* e = getenv("LMI_PF_PRIMARY")) h->pf_primary = e[0] && e[0] != '0';
     // per handle = per device (a process may hold handles on several devices; the attribute is per device)
+#define LMI_PS_ATTR(K) \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pass2_small_kernel<K, false>), hipFuncAttributeMaxDynamicSharedMemorySize, ps_lds_bytes(K))); \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pass2_small_kernel<K, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ps_lds_bytes(K)));
+    LMI_PS_ATTR(6) LMI_PS_ATTR(7) LMI_PS_ATTR(8)
+#undef LMI_PS_ATTR
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -527,8 +536,13 @@ extern "C" LMI_API int lmi_buckets_begin(lmi_index* h, int64_t N, int d, int L, 
         int max_rows = 0;
         long long owned_rows = 0;
         for (int b = 0; b < L; ++b) { max_rows = std::max(max_rows, h->h_nb_rows[b]); owned_rows += h->h_nb_rows[b]; }
-        if (h->chunk_rows_auto)
+        if (h->chunk_rows_auto) {
             h->chunk_rows = (int)std::min<long long>(2048, std::max<long long>(P2_TILE_ROWS, rup(owned_rows / 4096, P2_TILE_ROWS)));
+            // d <= 128 (lmi_pass2_small.h): a 2048-row item is ~5 us of work there, about what taking it from the queue and
+            // staging its query fragments costs: up to 8192 rows per item (10M x 45: pass 2 0.40 -> 0.27 ms)
+            if (h->pf_small && cdiv(d, 16) <= PS_MAXKG)
+                h->chunk_rows = (int)std::min<long long>(8192, std::max<long long>(P2_TILE_ROWS, rup(owned_rows / 1024, P2_TILE_ROWS)));
+        }
         const int need = (int)rup(cdiv(max_rows, 1024), 256);
         if (need > h->chunk_rows) h->chunk_rows = need;
     }
@@ -657,7 +671,8 @@ extern "C" LMI_API int lmi_buckets_end(lmi_index* h) {
     h->have16 = false;
     if (h->prefilter && h->n_rb_total > 0) {
         // fp16 copy of the slab for the prefilter: one power-of-two scale for the whole index
-        h->KG16 = (int)rup(cdiv(h->d, 16), PF_STAGE_G);
+        // (pass2_kernel's stages hold two k16-groups; the low-dimensional form has no stages: d = 45 is 48 wide, not 64)
+        h->KG16 = (h->pf_small && cdiv(h->d, 16) <= PS_MAXKG) ? (int)cdiv(h->d, 16) : (int)rup(cdiv(h->d, 16), PF_STAGE_G);
         const long long n_rows = (long long)h->n_rb_total * 32;
         CHK(h->xmaxbits.reserve(16));
         CHK(h->xscale.reserve(16));
@@ -931,6 +946,24 @@ extern "C" LMI_API int lmi_mlp_proba(lmi_index* h, const float* queries_nav, int
     return 0;
 }
 
+// pass 1 (SAMPLE) / pass 2 of the fp16 prefilter: the low-dimensional form for d <= 128 (lmi_pass2_small.h), else lmi_pass2.h
+template <bool SAMPLE>
+static int launch_pass2(lmi_index* h, const PrefilterParams& F) {
+    if (h->pf_small && F.KG16 <= PS_MAXKG) {
+        const int grid = h->num_cus * ps_blocks_per_cu(F.KG16), lds = ps_lds_bytes(F.KG16);
+#define LMI_PS_CASE(K) case K: pass2_small_kernel<K, SAMPLE><<<grid, 64 * PS_WAVES, lds, h->stream>>>(F); break;
+        switch (F.KG16) {
+            LMI_PS_CASE(1) LMI_PS_CASE(2) LMI_PS_CASE(3) LMI_PS_CASE(4) LMI_PS_CASE(5) LMI_PS_CASE(6) LMI_PS_CASE(7) LMI_PS_CASE(8)
+            default: return fail("internal: KG16 = %d outside the low-dimensional form (%s:%d)", F.KG16, __FILE__, __LINE__);
+        }
+#undef LMI_PS_CASE
+    } else {
+        pass2_kernel<SAMPLE><<<h->num_cus, 64 * P2_WAVES, 0, h->stream>>>(F);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_order, int nb, int kout, int raw,
                         float* d_dists, uint32_t* d_ids, uint32_t* d_keys) {
     const float* d_qn2 = nullptr;
@@ -1118,8 +1151,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         HIPCHK(hipMemsetAsync(F.stamps, 0, 2 * 8 * 12 * 8, h->stream));
 #endif
         {
-            pass2_kernel<true><<<h->num_cus, 64 * P2_WAVES, 0, h->stream>>>(F);   // pass 1: slot maxima of the sampled tiles
-            HIPCHK(hipGetLastError());
+            CHK(launch_pass2<true>(h, F));   // pass 1: slot maxima of the sampled tiles
             bound_merge2_kernel<<<cdiv((long long)ncols, 64), 256, 0, h->stream>>>(F.bound, (long long)ncols, F.bound1);
             HIPCHK(hipGetLastError());
             if (qbound) {   // the caller keeps the k <= 10 best over all ranks: one bound per query
@@ -1137,8 +1169,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
 
         // pass 2: candidates.  The query-resident form (opt-in: measured slower) needs a col-block's
         // fragments to fit a wave's registers (d <= 768)
-        pass2_kernel<false><<<h->num_cus, 64 * P2_WAVES, 0, h->stream>>>(F);
-        HIPCHK(hipGetLastError());
+        CHK(launch_pass2<false>(h, F));
         CHK(record(h, 6));
         if (h->pf_redo && !h->debug_emit_all) {
             // columns whose candidate buffer overflowed get the 10th best stored score as their bound and one more run of pass 2
@@ -1152,8 +1183,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
             PrefilterParams F2 = F;
             F2.head = F.head + 16;
             F2.redo_count = rc; F2.redo_bucket = rb; F2.redo_col = rcol;
-            pass2_kernel<false><<<h->num_cus, 64 * P2_WAVES, 0, h->stream>>>(F2);
-            HIPCHK(hipGetLastError());
+            CHK(launch_pass2<false>(h, F2));
         }
         RescoreParams Q;
         Q.bucket_order = d_order;
@@ -1253,6 +1283,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     h->stats_pending = true;
     h->last_nslots = nslots;
     h->last_nb = nb;
+    h->last_ncols = (long long)ncols;
     h->last_fast = fast;
     return 0;
 }
@@ -1771,6 +1802,16 @@ extern "C" LMI_API int lmi_debug_peek(lmi_index* h, const char* name, void* dst,
     size_t off = 0;
     if (!strcmp(name, "pf_bound")) b = &h->pf_bound;
     if (!strcmp(name, "pf_stamps")) { b = &h->pf_bound; off = h->stamps_off; }
+    if (!strcmp(name, "cand_total")) {   // 8 bytes: candidates pass 2 emitted in the last scan, summed over the columns (capped counts not: the counters run on)
+        if (bytes != 8 || !h->last_fast) return fail("lmi_debug_peek: cand_total is 8 bytes after a prefilter scan");
+        unsigned long long* d_acc = reinterpret_cast<unsigned long long*>(h->stats.as<long long>() + 2);
+        HIPCHK(hipMemsetAsync(d_acc, 0, 8, h->stream));
+        sum_u32_kernel<<<64, 256, 0, h->stream>>>(h->cand_cnt.as<unsigned>(), h->last_ncols, d_acc);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(dst, d_acc, 8, hipMemcpyDeviceToHost));
+        return 0;
+    }
     if (!strcmp(name, "pf_redo")) b = &h->redo;   // [0]: columns whose candidate buffer overflowed in the last scan (second run of pass 2)
     if (!b) return fail("lmi_debug_peek: unknown buffer '%s'", name);
     if (bytes < 0 || off + (size_t)bytes > b->cap) return fail("lmi_debug_peek: %lld bytes asked of a %zu-byte buffer", (long long)bytes, b->cap);

@@ -591,6 +591,67 @@ __global__ void query_bound_kernel(const int* __restrict__ slot_col, int nq, int
     }
 }
 
+// One work item for the block (thread 0 pops, the block learns it through s_item): bucket b, its query tile = col-blocks
+// [cbt0, cbt0 + ncb_tile), chunk / sampled tile `ch`, and the live columns m_use.  Returns false when the queues are empty.
+// The XCD-affine queues (route_group_kernel): pass 1 has its own prefixes (items = query tiles x SAMPLED tiles) and heads; a
+// bucket's items go to the same XCD in both passes: its queries' fragments stay in that L2.
+struct P2Item { int b, cbt0, ncb_tile, ch, m_use; };
+template <bool SAMPLE>
+__device__ __forceinline__ bool p2_pop_item(const PrefilterParams& P, int& grp, int* s_item, P2Item& it) {
+    if (threadIdx.x == 0) {
+        int b = -1, local = 0;
+        do {
+            b = -1;
+            unsigned* heads = P.head + (SAMPLE ? 24 : 0);
+            const int* totals = SAMPLE ? P.grp_total1 : P.grp_total;
+            const int* bases = SAMPLE ? P.grp_base1 : P.grp_base;
+            for (int tries = 0; tries < NGRP; ++tries) {
+                const int tot = totals[grp];
+                if (__hip_atomic_load(&heads[grp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)tot) {
+                    const int itn = (int)atomicAdd(&heads[grp], 1u);
+                    if (itn < tot) {
+                        const int* base = bases + grp * (P.L + 1);
+                        int lo = 0, hi = P.grp_n[grp];
+                        while (hi - lo > 1) {
+                            const int mid = (lo + hi) >> 1;
+                            if (base[mid] <= itn) lo = mid; else hi = mid;
+                        }
+                        b = P.grp_bucket[grp * P.L + lo];
+                        local = itn - base[lo];
+                        break;
+                    }
+                }
+                grp = (grp + 1) & (NGRP - 1);
+            }
+        } while (!SAMPLE && P.redo_bucket && b >= 0 && !P.redo_bucket[b]);
+        s_item[0] = b;
+        s_item[1] = local;
+    }
+    __syncthreads();
+    const int b = s_item[0], local = s_item[1];
+    __syncthreads();
+    if (b < 0) return false;
+    // query tiles of the bucket: its col-blocks split evenly over nqt = ceil(col-blocks / 12) tiles.
+    // pass 2: local = chunk * nqt + tile, all columns.  pass 1: pass1_decode -> sampled tile j, query tile; every
+    // P1_ALL_EVERY-th sampled tile runs over all the columns, the others over the primary ones (the bucket's first m0).
+    int qt = 0, ch = 0;
+    bool all_cols = true;
+    if (SAMPLE) {
+        const int nqa = query_tiles(P.m[b], P2_MAXCB), nqp = query_tiles(P.m0[b], P2_MAXCB);
+        all_cols = pass1_decode(local, nqa, nqp, &ch, &qt);
+    }
+    it.m_use = all_cols ? P.m[b] : P.m0[b];
+    const int ncb_b = (it.m_use + 31) >> 5;
+    const int nqt = (ncb_b + P2_MAXCB - 1) / P2_MAXCB;
+    const int per = (ncb_b + nqt - 1) / nqt;
+    if (!SAMPLE) { qt = local % nqt; ch = local / nqt; }
+    it.b = b;
+    it.ch = ch;
+    it.cbt0 = qt * per;
+    it.ncb_tile = min(per, ncb_b - it.cbt0);
+    return true;
+}
+
 template <bool SAMPLE>
 __global__ __launch_bounds__(64 * P2_WAVES, 1) void pass2_kernel(PrefilterParams P) {
     __shared__ __attribute__((aligned(16))) uint4 ring[P2_RING * P2_SLOT_BYTES / 16];
@@ -600,62 +661,11 @@ __global__ __launch_bounds__(64 * P2_WAVES, 1) void pass2_kernel(PrefilterParams
     __shared__ int s_item[2];
     int grp = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & (NGRP - 1));
     if (!SAMPLE && P.redo_count && *P.redo_count == 0u) return;  // the redo launch of a batch without overflowed columns
-    for (;;) {
-        if (threadIdx.x == 0) {
-            int b = -1, local = 0;
-            do {
-                b = -1;
-                {
-                    // the XCD-affine queues (route_group_kernel): pass 1 has its own prefixes (items = query tiles x SAMPLED tiles)
-                    // and heads; a bucket's items go to the same XCD in both passes: its queries' fragments stay in that L2
-                    unsigned* heads = P.head + (SAMPLE ? 24 : 0);
-                    const int* totals = SAMPLE ? P.grp_total1 : P.grp_total;
-                    const int* bases = SAMPLE ? P.grp_base1 : P.grp_base;
-                    for (int tries = 0; tries < NGRP; ++tries) {
-                        const int tot = totals[grp];
-                        if (__hip_atomic_load(&heads[grp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)tot) {
-                            const int it = (int)atomicAdd(&heads[grp], 1u);
-                            if (it < tot) {
-                                const int* base = bases + grp * (P.L + 1);
-                                int lo = 0, hi = P.grp_n[grp];
-                                while (hi - lo > 1) {
-                                    const int mid = (lo + hi) >> 1;
-                                    if (base[mid] <= it) lo = mid; else hi = mid;
-                                }
-                                b = P.grp_bucket[grp * P.L + lo];
-                                local = it - base[lo];
-                                break;
-                            }
-                        }
-                        grp = (grp + 1) & (NGRP - 1);
-                    }
-                }
-            } while (!SAMPLE && P.redo_bucket && b >= 0 && !P.redo_bucket[b]);
-            s_item[0] = b;
-            s_item[1] = local;
-        }
-        __syncthreads();
-        const int b = s_item[0], local = s_item[1];
-        __syncthreads();
-        if (b < 0) return;
-        // query tiles of the bucket: its col-blocks split evenly over nqt = ceil(col-blocks / 12) tiles.
-        // pass 2: local = chunk * nqt + tile, all columns.  pass 1: pass1_decode -> sampled tile j, query tile; every
-        // P1_ALL_EVERY-th sampled tile runs over all the columns, the others over the primary ones (the bucket's first m0).
-        int qt, ch;
-        bool all_cols = true;
-        if (SAMPLE) {
-            const int nqa = query_tiles(P.m[b], P2_MAXCB), nqp = query_tiles(P.m0[b], P2_MAXCB);
-            all_cols = pass1_decode(local, nqa, nqp, &ch, &qt);
-        }
-        const int m_use = all_cols ? P.m[b] : P.m0[b];
-        const int ncb_b = (m_use + 31) >> 5;
-        const int nqt = (ncb_b + P2_MAXCB - 1) / P2_MAXCB;
-        const int per = (ncb_b + nqt - 1) / nqt;
-        if (!SAMPLE) { qt = local % nqt; ch = local / nqt; }
-        const int cbt0 = qt * per;
-        const int ncb_tile = min(per, ncb_b - cbt0);
+    P2Item item;
+    while (p2_pop_item<SAMPLE>(P, grp, s_item, item)) {
+        const int b = item.b, cbt0 = item.cbt0, ch = item.ch, m_use = item.m_use;
 #define P2_CASE(N) case N: { Tile2<N, SAMPLE> it{P, (unsigned)reinterpret_cast<uintptr_t>(ring), ring, sList, sThr, sPend}; it.run(b, cbt0, ch, m_use); break; }
-        switch (ncb_tile) {
+        switch (item.ncb_tile) {
             P2_CASE(1) P2_CASE(2) P2_CASE(3) P2_CASE(4) P2_CASE(5) P2_CASE(6)
             P2_CASE(7) P2_CASE(8) P2_CASE(9) P2_CASE(10) P2_CASE(11)
             default: { Tile2<12, SAMPLE> it{P, (unsigned)reinterpret_cast<uintptr_t>(ring), ring, sList, sThr, sPend}; it.run(b, cbt0, ch, m_use); break; }

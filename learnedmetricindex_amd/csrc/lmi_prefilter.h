@@ -289,7 +289,7 @@ __global__ void slot_bound_kernel(const int* __restrict__ bucket_order, const in
 struct PrefilterParams {
     const uint4* slab16;
     const uint4* qfrag16;
-    int KG16;  // k16-groups per row-block (multiple of 2: a stage holds two)
+    int KG16;  // k16-groups per row-block (d > 128: a multiple of 2, a stage of pass2_kernel holds two)
     int L;
     int chunk_rb;
     const int* rb_start;
@@ -605,6 +605,14 @@ __global__ void overflow_rebound_kernel(const int* __restrict__ slot_col, const 
     redo_col[col] = 1;
     redo_bucket[bucket_order[p]] = 1;
     atomicAdd(redo_count, 1u);
+}
+
+__global__ void sum_u32_kernel(const unsigned* __restrict__ v, long long n, unsigned long long* __restrict__ out) {
+    unsigned long long a = 0;
+    for (long long i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) a += v[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, a);
 }
 
 __global__ void prefilter_stats_kernel(const int* __restrict__ nkeep, const int* __restrict__ fallback, int nslots,
