@@ -304,36 +304,41 @@ struct Tile2 {
         for (int n = 0; n < NCB; ++n) asm volatile("" : "+v"(thr[n]));   // defined from here on
 #pragma unroll
         for (int n = 0; n < NCB; ++n) {
-            // a col-block without any passing score (the common case once the bounds are tight) costs 8 v_max3 + 1 compare:
-            // the per-register pass below runs for col-blocks with a hit only.  v_max3 returns the other operands for a NaN.
-            float m0, m1, m2, m3, m4;
-            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m0) : "v"(acc[n][0]), "v"(acc[n][1]), "v"(acc[n][2]));
-            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m1) : "v"(acc[n][3]), "v"(acc[n][4]), "v"(acc[n][5]));
-            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m2) : "v"(acc[n][6]), "v"(acc[n][7]), "v"(acc[n][8]));
-            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m3) : "v"(acc[n][9]), "v"(acc[n][10]), "v"(acc[n][11]));
-            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m4) : "v"(acc[n][12]), "v"(acc[n][13]), "v"(acc[n][14]));
-            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m0) : "v"(m0), "v"(m1), "v"(acc[n][15]));
-            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m2) : "v"(m2), "v"(m3), "v"(m4));
-            asm("v_max_f32 %0, %1, %2" : "=v"(m0) : "v"(m0), "v"(m2));
-            bool any = m0 >= thr[n];
+            // About one score in a thousand passes (~40 candidates per column and bucket): four col-blocks in ten hold a candidate.
+            // Maxima of the four register groups (rows 8 j + 4 hh + 0..3) first: a col-block without one costs 10 max + 1 compare, one
+            // with a single candidate tests 4 group maxima + 4 registers, not 16.  v_max3 returns the other operands for a NaN.
+            float gm[4], t0, mall;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t0) : "v"(acc[n][4 * j]), "v"(acc[n][4 * j + 1]), "v"(acc[n][4 * j + 2]));
+                asm("v_max_f32 %0, %1, %2" : "=v"(gm[j]) : "v"(t0), "v"(acc[n][4 * j + 3]));
+            }
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t0) : "v"(gm[0]), "v"(gm[1]), "v"(gm[2]));
+            asm("v_max_f32 %0, %1, %2" : "=v"(mall) : "v"(t0), "v"(gm[3]));
+            bool any = mall >= thr[n];
 #ifdef LMI_ABL_NOEMIT
             any = any && thr[n] == 12345.678f;
 #endif
             if (__builtin_expect(__ballot(any) == 0ull, 1)) continue;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const bool pass = acc[n][r] >= thr[n];  // thr = +inf for idle columns, NaN scores never pass
-                const unsigned long long mask = __ballot(pass);
-                if (__builtin_expect(mask != 0ull, 0)) {
-                    if (pass) {
-                        const int my = tot + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                        const unsigned key = kb + (unsigned)(((n * 32) << 8) | ((r & 3) + 8 * (r >> 2)));
-                        const unsigned la = list_addr + (unsigned)min(my, 64) * 8u;
-                        const unsigned sb = __float_as_uint(acc[n][r]);
-                        const u32x2 ent = {key, sb};
-                        asm volatile("ds_write_b64 %0, %1" :: "v"(la), "v"(ent) : "memory");
+            for (int j = 0; j < 4; ++j) {
+                if (__ballot(gm[j] >= thr[n]) == 0ull) continue;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 4 * j + i;
+                    const bool pass = acc[n][r] >= thr[n];  // thr = +inf for idle columns, NaN scores never pass
+                    const unsigned long long mask = __ballot(pass);
+                    if (__builtin_expect(mask != 0ull, 0)) {
+                        if (pass) {
+                            const int my = tot + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                            const unsigned key = kb + (unsigned)(((n * 32) << 8) | ((r & 3) + 8 * (r >> 2)));
+                            const unsigned la = list_addr + (unsigned)min(my, 64) * 8u;
+                            const unsigned sb = __float_as_uint(acc[n][r]);
+                            const u32x2 ent = {key, sb};
+                            asm volatile("ds_write_b64 %0, %1" :: "v"(la), "v"(ent) : "memory");
+                        }
+                        tot += (int)__popcll(mask);
                     }
-                    tot += (int)__popcll(mask);
                 }
             }
         }
@@ -596,6 +601,27 @@ __global__ void query_bound_kernel(const int* __restrict__ slot_col, int nq, int
 // The XCD-affine queues (route_group_kernel): pass 1 has its own prefixes (items = query tiles x SAMPLED tiles) and heads; a
 // bucket's items go to the same XCD in both passes: its queries' fragments stay in that L2.
 struct P2Item { int b, cbt0, ncb_tile, ch, m_use; };
+// Item `local` of bucket b.  Query tiles of the bucket: its col-blocks split evenly over nqt = ceil(col-blocks / 12) tiles.
+// pass 2: local = chunk * nqt + tile, all columns.  pass 1: pass1_decode -> sampled tile j, query tile; every
+// P1_ALL_EVERY-th sampled tile runs over all the columns, the others over the primary ones (the bucket's first m0).
+template <bool SAMPLE>
+__device__ __forceinline__ void p2_decode_item(const PrefilterParams& P, int b, int local, P2Item& it) {
+    int qt = 0, ch = 0;
+    bool all_cols = true;
+    if (SAMPLE) {
+        const int nqa = query_tiles(P.m[b], P2_MAXCB), nqp = query_tiles(P.m0[b], P2_MAXCB);
+        all_cols = pass1_decode(local, nqa, nqp, &ch, &qt);
+    }
+    it.m_use = all_cols ? P.m[b] : P.m0[b];
+    const int ncb_b = (it.m_use + 31) >> 5;
+    const int nqt = (ncb_b + P2_MAXCB - 1) / P2_MAXCB;
+    const int per = (ncb_b + nqt - 1) / nqt;
+    if (!SAMPLE) { qt = local % nqt; ch = local / nqt; }
+    it.b = b;
+    it.ch = ch;
+    it.cbt0 = qt * per;
+    it.ncb_tile = min(per, ncb_b - it.cbt0);
+}
 template <bool SAMPLE>
 __device__ __forceinline__ bool p2_pop_item(const PrefilterParams& P, int& grp, int* s_item, P2Item& it) {
     if (threadIdx.x == 0) {
@@ -631,26 +657,70 @@ __device__ __forceinline__ bool p2_pop_item(const PrefilterParams& P, int& grp, 
     const int b = s_item[0], local = s_item[1];
     __syncthreads();
     if (b < 0) return false;
-    // query tiles of the bucket: its col-blocks split evenly over nqt = ceil(col-blocks / 12) tiles.
-    // pass 2: local = chunk * nqt + tile, all columns.  pass 1: pass1_decode -> sampled tile j, query tile; every
-    // P1_ALL_EVERY-th sampled tile runs over all the columns, the others over the primary ones (the bucket's first m0).
-    int qt = 0, ch = 0;
-    bool all_cols = true;
-    if (SAMPLE) {
-        const int nqa = query_tiles(P.m[b], P2_MAXCB), nqp = query_tiles(P.m0[b], P2_MAXCB);
-        all_cols = pass1_decode(local, nqa, nqp, &ch, &qt);
-    }
-    it.m_use = all_cols ? P.m[b] : P.m0[b];
-    const int ncb_b = (it.m_use + 31) >> 5;
-    const int nqt = (ncb_b + P2_MAXCB - 1) / P2_MAXCB;
-    const int per = (ncb_b + nqt - 1) / nqt;
-    if (!SAMPLE) { qt = local % nqt; ch = local / nqt; }
-    it.b = b;
-    it.ch = ch;
-    it.cbt0 = qt * per;
-    it.ncb_tile = min(per, ncb_b - it.cbt0);
+    p2_decode_item<SAMPLE>(P, b, local, it);
     return true;
 }
+
+// The block's OWN queue (its XCD's group of buckets) with the group's item prefix in LDS: the binary search is ~10 LDS reads
+// instead of as many L2 round trips (~3 us per item: a tenth of a pass-1 item at d = 768, as much as a whole item at d = 45).
+// PREFETCH (lmi_pass2_small.h, where an item is a few microseconds): thread 0 also takes the NEXT ticket when an item starts,
+// the atomic's round trip hides behind the item (costs a live register across the item: not for pass2_kernel's K loop).
+// Once the own group is used up the block falls back to p2_pop_item's walk over the other groups (the tail of the launch).
+constexpr int P2_PREFIX_CAP = 1025;   // buckets + 1 of a group held in LDS (more: the global prefix is searched)
+template <bool SAMPLE, bool PREFETCH, int NTHREADS>
+struct P2Queue {
+    const PrefilterParams& P;
+    int* s_item;     // [2] LDS
+    int* s_prefix;   // [P2_PREFIX_CAP] LDS
+    int grp, own, own_tot, own_n, ticket;
+    const int* own_base;
+    unsigned* own_head;
+    bool prefix_lds, own_live;
+
+    __device__ __forceinline__ void init() {
+        own = grp = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & (NGRP - 1));
+        own_head = P.head + (SAMPLE ? 24 : 0) + own;
+        own_tot = (SAMPLE ? P.grp_total1 : P.grp_total)[own];
+        own_n = P.grp_n[own];
+        own_base = (SAMPLE ? P.grp_base1 : P.grp_base) + own * (P.L + 1);
+        prefix_lds = own_n + 1 <= P2_PREFIX_CAP;
+        if (prefix_lds)
+            for (int i = threadIdx.x; i <= own_n; i += NTHREADS) s_prefix[i] = own_base[i];
+        own_live = own_tot > 0 && !(!SAMPLE && P.redo_bucket);   // (the redo launch skips buckets: it keeps to the plain pop)
+        ticket = -1;
+        if (PREFETCH && own_live && threadIdx.x == 0) ticket = (int)atomicAdd(own_head, 1u);
+        __syncthreads();
+    }
+    __device__ __forceinline__ bool next(P2Item& it) {
+        if (own_live) {
+            if (threadIdx.x == 0) {
+                int b = -1, local = 0;
+                if (!PREFETCH) ticket = (int)atomicAdd(own_head, 1u);
+                if (ticket < own_tot) {
+                    int lo = 0, hi = own_n;
+                    if (prefix_lds) {
+                        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_prefix[mid] <= ticket) lo = mid; else hi = mid; }
+                        local = ticket - s_prefix[lo];
+                    } else {
+                        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (own_base[mid] <= ticket) lo = mid; else hi = mid; }
+                        local = ticket - own_base[lo];
+                    }
+                    b = P.grp_bucket[own * P.L + lo];
+                    if (PREFETCH) ticket = (int)atomicAdd(own_head, 1u);   // the next one: consumed when this item is done
+                }
+                s_item[0] = b;
+                s_item[1] = local;
+            }
+            __syncthreads();
+            const int b = s_item[0], local = s_item[1];
+            __syncthreads();
+            if (b >= 0) { p2_decode_item<SAMPLE>(P, b, local, it); return true; }
+            own_live = false;
+            grp = (own + 1) & (NGRP - 1);
+        }
+        return p2_pop_item<SAMPLE>(P, grp, s_item, it);
+    }
+};
 
 template <bool SAMPLE>
 __global__ __launch_bounds__(64 * P2_WAVES, 1) void pass2_kernel(PrefilterParams P) {
@@ -659,10 +729,12 @@ __global__ __launch_bounds__(64 * P2_WAVES, 1) void pass2_kernel(PrefilterParams
     __shared__ float sThr[SAMPLE ? 1 : P2_MAXCB * 32];
     __shared__ __attribute__((aligned(16))) uint4 sPend[SAMPLE ? 1 : P2_WAVES * 64];
     __shared__ int s_item[2];
-    int grp = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & (NGRP - 1));
+    __shared__ int s_prefix[P2_PREFIX_CAP];
     if (!SAMPLE && P.redo_count && *P.redo_count == 0u) return;  // the redo launch of a batch without overflowed columns
+    P2Queue<SAMPLE, false, 64 * P2_WAVES> queue{P, s_item, s_prefix};
+    queue.init();
     P2Item item;
-    while (p2_pop_item<SAMPLE>(P, grp, s_item, item)) {
+    while (queue.next(item)) {
         const int b = item.b, cbt0 = item.cbt0, ch = item.ch, m_use = item.m_use;
 #define P2_CASE(N) case N: { Tile2<N, SAMPLE> it{P, (unsigned)reinterpret_cast<uintptr_t>(ring), ring, sList, sThr, sPend}; it.run(b, cbt0, ch, m_use); break; }
         switch (item.ncb_tile) {

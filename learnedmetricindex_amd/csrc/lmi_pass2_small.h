@@ -35,38 +35,19 @@ __host__ __device__ constexpr int ps_lds_bytes(int kg) { return P2_MAXCB * kg * 
 __host__ __device__ constexpr int ps_blocks_per_cu(int kg) { return kg <= 4 ? LMI_PS_BLOCKS4 : kg <= 6 ? 2 : 1; }   // LDS: 160 KiB per CU
 static_assert(2 * ps_lds_bytes(6) <= 160 * 1024 && ps_lds_bytes(PS_MAXKG) <= 160 * 1024 && ps_lds_bytes(5) <= 64 * 1024, "LDS budget");
 
-// The block's queue (its XCD's group of buckets) as this kernel uses it.  An item here is a few microseconds of work, so the
-// pop must not cost as much: the group's item prefix sits in LDS (the binary search is ~10 LDS reads instead of as many L2
-// round trips), and thread 0 takes the NEXT ticket when an item starts -- the atomic's round trip hides behind the item.
-// Once the own group is used up the block falls back to p2_pop_item's walk over the other groups (the tail of the launch).
-constexpr int PS_PREFIX_CAP = 1025;   // buckets + 1 of a group held in LDS (more: the global prefix is searched)
-
 template <int KG, bool SAMPLE>
 __global__ __launch_bounds__(64 * PS_WAVES, ps_blocks_per_cu(KG)) void pass2_small_kernel(PrefilterParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ps_smem[];
     uint4* sB = reinterpret_cast<uint4*>(ps_smem);                            // [col-blocks of the tile][KG][64 lanes]
     float* sThr = reinterpret_cast<float*>(ps_smem + P2_MAXCB * KG * 1024);   // [P2_MAXCB * 32] emission thresholds (pass 2)
     __shared__ int s_item[2];
-    __shared__ int s_prefix[PS_PREFIX_CAP];
+    __shared__ int s_prefix[P2_PREFIX_CAP];
     __shared__ uint2 s_list[SAMPLE ? 1 : PS_WAVES * 64];   // pass 2: a wave's candidates of one row-block pair (key, score bits)
-    int grp = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & (NGRP - 1));
     if (!SAMPLE && P.redo_count && *P.redo_count == 0u) return;  // the redo launch of a batch without overflowed columns
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, c = lane & 31;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // the own group's queue
-    const int own = grp;
-    unsigned* own_head = P.head + (SAMPLE ? 24 : 0) + own;
-    const int own_tot = (SAMPLE ? P.grp_total1 : P.grp_total)[own];
-    const int own_n = P.grp_n[own];
-    const int* own_base = (SAMPLE ? P.grp_base1 : P.grp_base) + own * (P.L + 1);
-    const bool prefix_lds = own_n + 1 <= PS_PREFIX_CAP;
-    if (prefix_lds)
-        for (int i = tid; i <= own_n; i += 64 * PS_WAVES) s_prefix[i] = own_base[i];
-    bool own_live = own_tot > 0 && !(!SAMPLE && P.redo_bucket);   // (the redo launch skips buckets: it keeps to the plain pop)
-    int ticket = -1;
-    if (own_live && tid == 0) ticket = (int)atomicAdd(own_head, 1u);
     // pending candidate of the lane (pass 2): its position atomic was issued at the end of the previous pair
     unsigned pend_pos = 0xffffffffu, pend_row = 0u;
     size_t pend_col = 0;
@@ -78,49 +59,11 @@ __global__ __launch_bounds__(64 * PS_WAVES, ps_blocks_per_cu(KG)) void pass2_sma
         }
         pend_pos = 0xffffffffu;
     };
-    __syncthreads();
-    for (;;) {
-        P2Item item;
-        if (own_live) {
-            if (tid == 0) {
-                int b = -1, local = 0;
-                if (ticket < own_tot) {
-                    int lo = 0, hi = own_n;
-                    if (prefix_lds) {
-                        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_prefix[mid] <= ticket) lo = mid; else hi = mid; }
-                        local = ticket - s_prefix[lo];
-                    } else {
-                        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (own_base[mid] <= ticket) lo = mid; else hi = mid; }
-                        local = ticket - own_base[lo];
-                    }
-                    b = P.grp_bucket[own * P.L + lo];
-                    ticket = (int)atomicAdd(own_head, 1u);   // the next one: consumed when this item is done
-                }
-                s_item[0] = b;
-                s_item[1] = local;
-            }
-            __syncthreads();
-            const int b = s_item[0], local = s_item[1];
-            __syncthreads();
-            if (b < 0) { own_live = false; grp = (own + 1) & (NGRP - 1); continue; }
-            int qt = 0, ch = 0;
-            bool all_cols = true;
-            if (SAMPLE) {
-                const int nqa = query_tiles(P.m[b], P2_MAXCB), nqp = query_tiles(P.m0[b], P2_MAXCB);
-                all_cols = pass1_decode(local, nqa, nqp, &ch, &qt);
-            }
-            item.m_use = all_cols ? P.m[b] : P.m0[b];
-            const int ncb_b = (item.m_use + 31) >> 5;
-            const int nqt = (ncb_b + P2_MAXCB - 1) / P2_MAXCB;
-            const int per = (ncb_b + nqt - 1) / nqt;
-            if (!SAMPLE) { qt = local % nqt; ch = local / nqt; }
-            item.b = b;
-            item.ch = ch;
-            item.cbt0 = qt * per;
-            item.ncb_tile = min(per, ncb_b - item.cbt0);
-        } else if (!p2_pop_item<SAMPLE>(P, grp, s_item, item)) {
-            break;
-        }
+    // an item is a few microseconds of work: the queue takes the next ticket ahead (P2Queue, lmi_pass2.h)
+    P2Queue<SAMPLE, true, 64 * PS_WAVES> queue{P, s_item, s_prefix};
+    queue.init();
+    P2Item item;
+    while (queue.next(item)) {
         const int b = item.b, ncb = item.ncb_tile;
         const int n_b = P.nb_rows[b];
         const int nrb_b = (n_b + 31) >> 5, rb_last = nrb_b - 1;
