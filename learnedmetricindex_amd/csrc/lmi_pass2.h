@@ -280,6 +280,11 @@ struct Tile2 {
         const int ln = lane_id();
         const int hh = ln >> 5, cc = ln & 31;
         flush_pending(ln);
+#ifdef LMI_ABL_NOEPI   // timing-only ablation: the tile's scores are never tested (no candidates: wrong results)
+#pragma unroll
+        for (int n = 0; n < NCB; ++n) asm volatile("" :: "v"(acc[n]));
+        return;
+#endif
         const unsigned row0 = (unsigned)((rb_tile0 + w) * 32);
         if (row0 + 32u > (unsigned)n_b) {  // wave-uniform: the bucket's ragged end (zero-padded / clamped rows never pass)
             int lim = n_b - (int)row0 - 4 * hh;   // lane's rows (r & 3) + 8 (r >> 2) at or past `lim` are beyond the bucket
