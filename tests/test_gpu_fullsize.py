@@ -190,53 +190,82 @@ def test_c4_one_eighth_shard(oracle):
 
 
 def test_c5_full_size(oracle):
-    """C5 (configs[4]): 10M x 45 (AlphaFind protein-embedding shape; K padded 45 -> 64 in the fp16 slab), 256 leaves, cosine
-    (= unit-norm rows + 1 - ip), top-4, 10 000 queries: both scan modes identical for the whole batch, 256 sampled
-    queries against the oracle (reference call site LearnedIndex.py:360-368)."""
+    """C5 (configs[4]): 10M x 45 (AlphaFind protein-embedding shape; 3 k16-groups = 48 wide in the fp16 slab: the low-dimensional
+    prefilter kernels, lmi_pass2_small.h), 256 leaves, cosine (= unit-norm rows + 1 - ip), top-4, 10 000 queries --
+    END TO END through the MLP: an MLP-4 (45 -> 512 -> 256) places the rows (argmax, LearnedIndexBuilder.py:76) and routes the
+    queries (lmi_search: MLP + top-4 + scan + merge in one call).  Both scan modes identical for the whole batch; for 256
+    sampled queries the bucket order must equal the oracle's (forward_logits + rank_classes) and the neighbours the oracle's
+    per-bucket knn + stable merge (reference call sites model.py:226-241, LearnedIndex.py:107-146, 360-368)."""
     from learnedmetricindex_amd import _capi
 
     _need_hbm(40)
-    d5, L, NB, n, nq, piece = 45, 256, 4, 10_000_000, 10_000, 1 << 20
+    d5, L, NB, n, nq, piece, H = 45, 256, 4, 10_000_000, 10_000, 1 << 20, 512
     dev = torch.device("cuda", 0)
     g0 = torch.Generator(device=dev).manual_seed(555)
     centres = torch.randn(L, d5, generator=g0, device=dev)
+    # an MLP whose classes follow the clusters loosely: hidden = random features, output = their correlation with the centres
+    gw = torch.Generator().manual_seed(556)
+    W1 = (torch.randn(H, d5, generator=gw) / d5 ** 0.5).numpy().astype(np.float32)
+    b1 = (0.1 * torch.randn(H, generator=gw)).numpy().astype(np.float32)
+    hc = np.maximum(torch.nn.functional.normalize(centres, dim=1).cpu().numpy() @ W1.T + b1, 0.0)
+    W2 = (8.0 * (hc - hc.mean(0)) / H ** 0.5).astype(np.float32)
+    b2 = np.zeros(L, dtype=np.float32)
+    layers = [(W1, b1), (W2, b2)]
 
     def rows(p, count):
         g = torch.Generator(device=dev).manual_seed(3000 + p)
         a = torch.randint(0, L, (count,), generator=g, device=dev)
-        return a, torch.nn.functional.normalize(centres[a] + 0.35 * torch.randn(count, d5, generator=g, device=dev), dim=1).contiguous()
+        return torch.nn.functional.normalize(centres[a] + 0.35 * torch.randn(count, d5, generator=g, device=dev), dim=1).contiguous()
 
     pieces = [(p, min(piece, n - p * piece)) for p in range((n + piece - 1) // piece)]
-    labels = torch.cat([rows(p, c)[0] for p, c in pieces]).cpu().numpy().astype(np.int64)
     gq = torch.Generator(device=dev).manual_seed(78)
     Q = torch.nn.functional.normalize(centres[torch.randint(0, L, (nq,), generator=gq, device=dev)]
                                       + 0.35 * torch.randn(nq, d5, generator=gq, device=dev), dim=1).contiguous()
-    order = (Q @ centres.T).topk(NB, dim=1).indices.to(torch.int32).contiguous()
-    Qh, order_h = Q.cpu().numpy(), order.cpu().numpy()
+    Qh = Q.cpu().numpy()
     sel = np.sort(np.random.RandomState(8).choice(nq, 256, replace=False))
     out = []
+    labels = None
     for pf in (True, False):
         idx = _capi.Index(0, prefilter=pf)
         idx.set_stream(torch.cuda.current_stream().cuda_stream)
+        idx.set_mlp(layers)
+        if labels is None:   # placement: argmax MLP(x) over all N with the HIP MLP kernels
+            lab = torch.empty(n, dtype=torch.int32, device=dev)
+            for p, c in pieces:
+                idx.mlp_topk_device(rows(p, c), 1, lab[p * piece: p * piece + c])
+            torch.cuda.synchronize()
+            labels = lab.cpu().numpy().astype(np.int64)
+            del lab
+            # ... and the oracle's placement of a sample agrees
+            xs = rows(3, 4096)
+            got = torch.empty(4096, dtype=torch.int32, device=dev)
+            idx.mlp_topk_device(xs, 1, got)
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(got.cpu().numpy(), oracle.rank_classes(oracle.forward_logits(layers, xs.cpu().numpy(), nthreads=16), 1)[:, 0])
         idx.buckets_begin(labels, d5, L)
         for p, c in pieces:
-            idx.add_rows(rows(p, c)[1], p * piece)
+            idx.add_rows(rows(p, c), p * piece)
             torch.cuda.synchronize()
         idx.buckets_end()
         d = torch.empty((nq, 10), dtype=torch.float32, device=dev)
         i = torch.empty((nq, 10), dtype=torch.int32, device=dev)
-        idx.scan_topk_device(Q, order, NB, 10, d, i)
+        bo = torch.empty((nq, NB), dtype=torch.int32, device=dev)
+        idx.search_device(Q, Q, NB, 10, d, i, None, bo)
         torch.cuda.synchronize()
-        dh, ih = d.cpu().numpy(), i.cpu().numpy().view(np.uint32)
+        dh, ih, order_h = d.cpu().numpy(), i.cpu().numpy().view(np.uint32), bo.cpu().numpy()
         if pf:
+            sizes = idx.bucket_sizes()
+            print(f"C5: bucket sizes min/median/max {sizes.min()}/{int(np.median(sizes))}/{sizes.max()}, empty {int((sizes == 0).sum())}")
+            np.testing.assert_array_equal(order_h[sel], oracle.rank_classes(oracle.forward_logits(layers, Qh[sel], nthreads=16), NB))
             active, survivors, fallbacks = idx.prefilter_stats()
             assert active and survivors >= 10 * nq
             print(f"C5: {survivors / (nq * NB):.2f} survivors per slot, {fallbacks} fallback slots")
             _oracle_check(oracle, idx, Qh, order_h, sel, NB, dh, ih)
-        out.append((dh, ih))
+        out.append((dh, ih, order_h))
         idx.close()
         torch.cuda.empty_cache()
-    (d1, i1), (d0, i0) = out
+    (d1, i1, o1), (d0, i0, o0) = out
+    np.testing.assert_array_equal(o1, o0)
     np.testing.assert_array_equal(i1, i0)
     np.testing.assert_array_equal(d1, d0)
     assert np.all(np.diff(d1, axis=1) >= 0) and np.all(i1 > 0)
