@@ -946,6 +946,12 @@ extern "C" LMI_API int lmi_mlp_proba(lmi_index* h, const float* queries_nav, int
     return 0;
 }
 
+// the exact re-rank runs in its streamed form (select_kernel + rescore_kernel, lmi_rescore.h) for these shapes
+static bool rescore_is_streamed(const lmi_index* h) {
+    return h->rescore_streamed && h->d % 4 == 0 && h->d <= RS_MAXD && RC_WAVES * rc_wave_lds(h->d, 4) <= 160 * 1024;
+}
+static int rescore_group_size(int nb) { return nb % 4 == 0 ? 4 : nb % 3 == 0 ? 3 : nb % 2 == 0 ? 2 : 1; }
+
 // pass 1 (SAMPLE) / pass 2 of the fp16 prefilter: the low-dimensional form for d <= 128 (lmi_pass2_small.h), else lmi_pass2.h
 template <bool SAMPLE>
 static int launch_pass2(lmi_index* h, const PrefilterParams& F) {
@@ -1055,6 +1061,14 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         fill(h->stats.as<long long>() + 2, 4, 0u);
         CHK(h->redo.reserve((size_t)(1 + L) * 4 + ncols));
         fill(h->redo.p, (long long)(1 + L) + (long long)((ncols + 3) / 4), 0u);
+        if (rescore_is_streamed(h)) {   // the streamed re-rank's flags and list counters (lmi_rescore.h): zeroed here, not by a launch of their own
+            const int groups = nslots / rescore_group_size(nb), sub_cap = cdiv(groups, RC_SUB);
+            CHK(h->rs_flag.reserve((size_t)groups * 4));
+            CHK(h->rs_active.reserve((size_t)(RC_SUB + RC_SUB * sub_cap) * 4 + (size_t)(1 + groups) * 4));
+            fill(h->rs_flag.p, groups, 0u);
+            fill(h->rs_active.p, RC_SUB, 0u);
+            fill(h->rs_active.as<int>() + RC_SUB + RC_SUB * sub_cap, 1, 0u);
+        }
     }
     if (!fill_ok) return fail("internal: more than %d fill ranges queued (%s:%d)", FillRanges::MAXR, __FILE__, __LINE__);
     fill_ranges_kernel<<<h->num_cus * 4, 256, 0, h->stream>>>(Z);
@@ -1207,14 +1221,12 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         Q.fallback = h->fallback.as<int>();
         Q.nkeep = h->nkeep.as<int>();
 #ifndef LMI_ABL_NOEMIT  // timing-only ablation builds emit nothing: no re-rank, no fallback
-        if (h->rescore_streamed && h->d % 4 == 0 && h->d <= RS_MAXD && RC_WAVES * rc_wave_lds(h->d, 4) <= 160 * 1024) {
+        if (rescore_is_streamed(h)) {
             // selection at full occupancy, then the survivors' rows streamed through LDS in coalesced pieces (lmi_rescore.h)
-            const int G = nb % 4 == 0 ? 4 : nb % 3 == 0 ? 3 : nb % 2 == 0 ? 2 : 1;  // slots of one query per wave
+            const int G = rescore_group_size(nb);  // slots of one query per wave
             const int groups = nslots / G;
             CHK(h->surv_row.reserve((size_t)nslots * RC_KEEP * 4));
-            CHK(h->rs_flag.reserve((size_t)groups * 4));
             const int sub_cap = cdiv(groups, RC_SUB);
-            CHK(h->rs_active.reserve((size_t)(RC_SUB + RC_SUB * sub_cap) * 4 + (size_t)(1 + groups) * 4));
             SelectOut O;
             O.surv_row = h->surv_row.as<unsigned>();
             O.G = G;
@@ -1222,15 +1234,6 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
             O.active = h->rs_active.as<int>();
             O.sub_cap = sub_cap;
             O.big = O.active + RC_SUB + RC_SUB * sub_cap;
-            {
-                FillRanges Zr;
-                Zr.count = 3;
-                Zr.p[0] = reinterpret_cast<unsigned*>(O.grp_flag); Zr.n[0] = groups; Zr.v[0] = 0u;
-                Zr.p[1] = reinterpret_cast<unsigned*>(O.active); Zr.n[1] = RC_SUB; Zr.v[1] = 0u;
-                Zr.p[2] = reinterpret_cast<unsigned*>(O.big); Zr.n[2] = 1; Zr.v[2] = 0u;
-                fill_ranges_kernel<<<cdiv(groups, 1024), 256, 0, h->stream>>>(Zr);
-                HIPCHK(hipGetLastError());
-            }
             select_kernel<<<cdiv(nslots, 4), 256, 0, h->stream>>>(Q, O);
             HIPCHK(hipGetLastError());
             const int blocks = cdiv(groups, RC_WAVES);
