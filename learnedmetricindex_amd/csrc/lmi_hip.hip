@@ -137,6 +137,7 @@ struct lmi_index {
     bool pf_hw_ok = false;   // fp16 subnormal self-test passed on this device
     bool have16 = false;     // slab16 built by lmi_buckets_end
     int KG16 = 0;
+    int dp = 0;   // row pitch (floats) of `rowmajor`
     DevBuf slab16, rowmajor, xscale, xmaxbits, bnorm, bdelta, qdelta;
     DevBuf qnorm, qscale, qfrag16, eps2, cand_cnt, cand_row, cand_s, fallback, pf_bound, nkeep, surv_row, rs_flag, rs_active;
     DevBuf redo;   // [1] count | [L] bucket flags | [columns] column flags (bytes): overflow_rebound_kernel
@@ -516,6 +517,7 @@ extern "C" LMI_API int lmi_buckets_begin(lmi_index* h, int64_t N, int d, int L, 
     h->d_user = d;
     h->d = h->metric == LMI_METRIC_L2 ? (int)rup(d + 1, 4) : d;  // L2: + the -|x|^2/2 column (sim_to_dist, lmi_kernels.h)
     d = h->d;
+    h->dp = (int)rup(d, 4);   // floats per row of the row-major f32 copy: 16-byte rows for the streamed re-rank (d = 45: 48, zero-filled)
     h->L = L;
     h->KGs = (int)rup(cdiv(d, 8), STAGE_G);
     h->built = false;
@@ -567,7 +569,7 @@ extern "C" LMI_API int lmi_buckets_begin(lmi_index* h, int64_t N, int d, int L, 
     }
     const size_t slab_bytes = (size_t)std::max<int64_t>(h->n_rb_total, 1) * h->KGs * 1024;
     if (h->prefilter) {  // row-major f32 (exact re-rank / fallback / read-back); fp16 fragments at buckets_end
-        const size_t rm_bytes = (size_t)std::max<int64_t>(h->n_rb_total, 1) * 32 * d * 4;
+        const size_t rm_bytes = (size_t)std::max<int64_t>(h->n_rb_total, 1) * 32 * h->dp * 4;
         h->slab.release();
         CHK(h->rowmajor.reserve(rm_bytes));
         HIPCHK(hipMemsetAsync(h->rowmajor.p, 0, rm_bytes, h->stream));
@@ -624,7 +626,7 @@ static int add_rows_impl(lmi_index* h, const float* rows, int64_t row0, const in
         if (h->prefilter) {
             long long total = (long long)n * h->d;
             scatter_rows_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(src, h->d, h->pos.as<int>(), row0 + off, idx, (long long)h->N, n,
-                                                                        h->rowmajor.as<float>());
+                                                                        h->rowmajor.as<float>(), h->dp);
         } else {
             long long total = (long long)n * h->KGs;
             pack_scatter_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(src, h->d, h->pos.as<int>(), row0 + off, idx, (long long)h->N, n,
@@ -682,16 +684,16 @@ extern "C" LMI_API int lmi_buckets_end(lmi_index* h) {
         HIPCHK(hipMemsetAsync(h->xmaxbits.p, 0, 16, h->stream));
         HIPCHK(hipMemsetAsync(h->bnorm.p, 0, (size_t)h->L * 4, h->stream));
         HIPCHK(hipMemsetAsync(h->bdelta.p, 0, (size_t)h->L * 4, h->stream));
-        absmax_kernel<<<h->num_cus * 8, 256, 0, h->stream>>>(h->rowmajor.as<float>(), n_rows * h->d, h->xmaxbits.as<unsigned>());
+        absmax_kernel<<<h->num_cus * 8, 256, 0, h->stream>>>(h->rowmajor.as<float>(), n_rows * h->dp, h->xmaxbits.as<unsigned>());
         HIPCHK(hipGetLastError());
         make_scale_kernel<<<1, 1, 0, h->stream>>>(h->xmaxbits.as<unsigned>(), h->xscale.as<float>());
         HIPCHK(hipGetLastError());
         const long long total = n_rows * h->KG16 * 2;
-        convert16_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(h->rowmajor.as<float>(), h->d, n_rows, h->KG16,
+        convert16_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(h->rowmajor.as<float>(), h->d, h->dp, n_rows, h->KG16,
                                                                  h->xscale.as<float>(), h->slab16.as<uint4>());
         HIPCHK(hipGetLastError());
         dim3 g(64, h->L);
-        bucket_norm_kernel<<<g, 256, 0, h->stream>>>(h->rowmajor.as<float>(), h->d, h->d_rb_start.as<int>(),
+        bucket_norm_kernel<<<g, 256, 0, h->stream>>>(h->rowmajor.as<float>(), h->d, h->dp, h->d_rb_start.as<int>(),
                                                     h->d_nb_rows.as<int>(), h->xscale.as<float>(), h->bnorm.as<unsigned>(),
                                                     h->bdelta.as<unsigned>());
         HIPCHK(hipGetLastError());
@@ -718,7 +720,7 @@ extern "C" LMI_API int lmi_bucket_read(lmi_index* h, int bucket, float* rows, ui
     const int64_t p0 = (int64_t)h->h_rb_start[bucket] * 32;
     const int du = h->d_user;  // the caller's columns (the L2 norm column is not returned)
     if (rows && h->prefilter) {
-        HIPCHK(hipMemcpy2DAsync(rows, (size_t)du * 4, h->rowmajor.as<float>() + (size_t)p0 * h->d, (size_t)h->d * 4, (size_t)du * 4, (size_t)n,
+        HIPCHK(hipMemcpy2DAsync(rows, (size_t)du * 4, h->rowmajor.as<float>() + (size_t)p0 * h->dp, (size_t)h->dp * 4, (size_t)du * 4, (size_t)n,
                                 hipMemcpyDeviceToHost, h->stream));
     } else if (rows) {
         CHK(h->stage.reserve((size_t)n * du * 4));
@@ -948,7 +950,7 @@ extern "C" LMI_API int lmi_mlp_proba(lmi_index* h, const float* queries_nav, int
 
 // the exact re-rank runs in its streamed form (select_kernel + rescore_kernel, lmi_rescore.h) for these shapes
 static bool rescore_is_streamed(const lmi_index* h) {
-    return h->rescore_streamed && h->d % 4 == 0 && h->d <= RS_MAXD && RC_WAVES * rc_wave_lds(h->d, 4) <= 160 * 1024;
+    return h->rescore_streamed && h->dp <= RS_MAXD && RC_WAVES * rc_wave_lds(h->dp, 4) <= 160 * 1024;
 }
 static int rescore_group_size(int nb) { return nb % 4 == 0 ? 4 : nb % 3 == 0 ? 3 : nb % 2 == 0 ? 2 : 1; }
 
@@ -1213,6 +1215,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         Q.cand_s = F.cand_s;
         Q.eps2 = F.eps2;
         Q.rows = h->rowmajor.as<float>();
+        Q.dp = h->dp;
         Q.q = d_qs;
         Q.qn2 = d_qn2;
         Q.ids_slab = h->ids_slab.as<unsigned>();
@@ -1237,7 +1240,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
             select_kernel<<<cdiv(nslots, 4), 256, 0, h->stream>>>(Q, O);
             HIPCHK(hipGetLastError());
             const int blocks = cdiv(groups, RC_WAVES);
-            const int lds = RC_WAVES * rc_wave_lds(h->d, G), lds_s = RC_WAVES * rc_wave_lds(h->d, G, true);
+            const int lds = RC_WAVES * rc_wave_lds(h->dp, G), lds_s = RC_WAVES * rc_wave_lds(h->dp, G, true);
             // first every group in the small-LDS form (three blocks per CU), then the groups it passed on (more survivors than it holds)
 #define LMI_RC_LAUNCH(GV) { rescore_kernel<GV, true><<<blocks, 64 * RC_WAVES, lds_s, h->stream>>>(Q, O); \
                             rescore_kernel<GV, false><<<std::min(blocks, h->num_cus), 64 * RC_WAVES, lds, h->stream>>>(Q, O); }

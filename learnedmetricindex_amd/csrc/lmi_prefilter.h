@@ -46,7 +46,7 @@ constexpr int PF_KEEP = 64;         // survivors re-scored per slot; more -> exa
 //      fragment-major layout, which cost 4x the bytes in 64-B sectors) and the fp16 fragments ----
 __global__ void scatter_rows_kernel(const float* __restrict__ src, int d, const int* __restrict__ pos,
                                     long long row0, const long long* __restrict__ index, long long n_total, long long nrows,
-                                    float* __restrict__ dst) {
+                                    float* __restrict__ dst, int pitch) {   // pitch: floats per row of dst (d rounded up to 4, zero-filled)
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nrows * d) return;
     const long long i = idx / d;
@@ -54,7 +54,7 @@ __global__ void scatter_rows_kernel(const float* __restrict__ src, int d, const 
     const long long o = index ? index[i] : row0 + i;  // index: the objects' original row numbers (owned-only ingest)
     if (o < 0 || o >= n_total) return;
     const long long p = pos[o];
-    if (p >= 0) dst[p * d + k] = src[idx];
+    if (p >= 0) dst[p * pitch + k] = src[idx];
 }
 
 // global max |x| (bits of a non-negative float order like unsigned ints)
@@ -83,7 +83,7 @@ __global__ void make_scale_kernel(const unsigned* __restrict__ maxbits, float* _
 
 // row-major f32 -> fp16 fragment-major (x scale): H[rb][k/16][((k>>3)&1)*32 + r][k&7].
 // One thread per (slab row p, k16-group, half).
-__global__ void convert16_kernel(const float* __restrict__ rows, int d, long long n_rows, int KG16,
+__global__ void convert16_kernel(const float* __restrict__ rows, int d, int pitch, long long n_rows, int KG16,
                                  const float* __restrict__ scale, uint4* __restrict__ dst) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_rows * KG16 * 2) return;
@@ -91,7 +91,7 @@ __global__ void convert16_kernel(const float* __restrict__ rows, int d, long lon
     const int g = (int)((idx >> 1) % KG16);
     const long long p = (idx >> 1) / KG16;
     const float s = scale[0];
-    const float* x = rows + p * d;
+    const float* x = rows + p * pitch;
     half8 h;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -109,7 +109,7 @@ __device__ __forceinline__ float norm_guard(int d) { return 1.0001f + (float)d *
 // per-bucket max of the scaled row norm ||x'|| and of the norm of the row's fp16 rounding error
 // ||x^ - x'|| (x' = x * scale exactly, x^ = the _Float16 image convert16_kernel stores; the difference of
 // the two is exact in binary32), both rounded up (bits of non-negative floats order like ints)
-__global__ void bucket_norm_kernel(const float* __restrict__ rows, int d, const int* __restrict__ rb_start,
+__global__ void bucket_norm_kernel(const float* __restrict__ rows, int d, int pitch, const int* __restrict__ rb_start,
                                    const int* __restrict__ nb_rows, const float* __restrict__ scale,
                                    unsigned* __restrict__ bnorm_bits, unsigned* __restrict__ bdelta_bits) {
     const int b = blockIdx.y;
@@ -118,7 +118,7 @@ __global__ void bucket_norm_kernel(const float* __restrict__ rows, int d, const 
     const float guard = norm_guard(d);
     float best = 0.0f, bestd = 0.0f;
     for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < n_b; row += gridDim.x * blockDim.x) {
-        const float* x = rows + ((size_t)rb_start[b] * 32 + row) * d;
+        const float* x = rows + ((size_t)rb_start[b] * 32 + row) * pitch;
         float acc = 0.0f, dl = 0.0f;
         for (int k = 0; k < d; ++k) {
             const float xs = x[k] * s;
@@ -340,7 +340,8 @@ struct RescoreParams {
     const unsigned* cand_row;
     const float* cand_s;
     const float* eps2;
-    const float* rows;  // bucket-contiguous row-major f32 [slab rows][d]
+    const float* rows;  // bucket-contiguous row-major f32 [slab rows][dp], columns d .. dp - 1 zero
+    int dp;             // floats per row of `rows`: d rounded up to a multiple of 4 (16-byte rows for the streamed re-rank)
     const float* q;     // row-major [nq][d]
     const float* qn2;   // L2 metric: |q|^2 per query (nullptr: inner product)
     const unsigned* ids_slab;
@@ -351,8 +352,8 @@ struct RescoreParams {
 };
 
 // canonical similarity of slab row p with query qv[0..d): acc = fmaf(q[k], x[k], acc), k ascending
-__device__ __forceinline__ float exact_score(const float* __restrict__ rows, size_t p, const float* __restrict__ qv, int d) {
-    const float* x = rows + p * d;
+__device__ __forceinline__ float exact_score(const float* __restrict__ rows, size_t p, const float* __restrict__ qv, int d, int pitch) {
+    const float* x = rows + p * pitch;
     float acc = 0.0f;
     int k = 0;
     if ((d & 3) == 0) {  // rows are 16-byte aligned: vector loads, same k order
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(64 * RS_WAVES) __attribute__((amdgpu_waves_per_eu(L
     unsigned row = NOROW;
     if (lane < (int)nk) {
         row = keep_row[wv][lane];
-        const float* x = P.rows + ((size_t)rb0 * 32 + row) * P.d;
+        const float* x = P.rows + ((size_t)rb0 * 32 + row) * P.dp;
         const float* qv = q_lds ? qs[wv] : qg;
         float acc = 0.0f;
         int k = 0;
@@ -659,7 +660,7 @@ __global__ __launch_bounds__(256) void fallback_kernel(RescoreParams P) {
         const unsigned* cr = P.cand_row + (size_t)ccol * PF_CAP;
         for (unsigned it = tid; it < ccnt; it += 256) {
             const unsigned row = cr[it];
-            const float s = exact_score(P.rows, (size_t)rb0 * 32 + row, qv, P.d);
+            const float s = exact_score(P.rows, (size_t)rb0 * 32 + row, qv, P.d, P.dp);
             if (better(s, row, v[KPB - 1], id[KPB - 1])) {  // candidates come in no order: ties by row here
 #pragma unroll
                 for (int t = KPB - 1; t > 0; --t) {   // list_insert with the (score desc, row asc) order
@@ -673,7 +674,7 @@ __global__ __launch_bounds__(256) void fallback_kernel(RescoreParams P) {
         }
     } else {
     for (unsigned row = tid; row < (unsigned)n_b; row += 256) {
-        const float s = exact_score(P.rows, (size_t)rb0 * 32 + row, qv, P.d);
+        const float s = exact_score(P.rows, (size_t)rb0 * 32 + row, qv, P.d, P.dp);
         if (s > v[KPB - 1]) list_insert(v, id, s, row);  // rows ascend per thread: strict > keeps the earlier
     }
     }

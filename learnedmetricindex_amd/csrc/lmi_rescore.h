@@ -15,7 +15,7 @@
 //                    over chunk c of row r (q broadcast from LDS).  The wave owns its buffers: no barriers, the
 //                    ring is ordered by the wave's own counted `s_waitcnt vmcnt`.  Then, per slot, the 10 best by
 //                    (score desc, row asc) become the slot's rank list exactly as before.
-// Used when d % 4 == 0 and d <= RS_MAXD; other shapes keep select_rescore_kernel.  Results are bit-identical
+// Used when the row pitch (d rounded up to 4: the f32 rows are zero-padded to 16-byte multiples) is <= RS_MAXD; wider shapes keep select_rescore_kernel.  Results are bit-identical
 // (same chain, same selection rule); tests/test_gpu_prefilter.py runs both.
 #pragma once
 #include <type_traits>
@@ -184,7 +184,7 @@ template <int G, bool SMALL>
 __device__ __forceinline__ void rescore_group(const RescoreParams& P, const SelectOut& O, unsigned char* rc_smem, int wv, int lane, int p0) {
     constexpr int RINGB = SMALL ? RC_SMALL_RING : RC_DEPTH * RC_BUF;
     constexpr int KEEPW = SMALL ? 32 : G * RC_KEEP;
-    const int d = P.d;
+    const int d = P.dp;   // the rows' pitch: the chain runs over the zero padding too (+0 * +0 added to the sum changes nothing)
     unsigned char* mine = rc_smem + (size_t)wv * rc_wave_lds(d, G, SMALL);
     float* qs = reinterpret_cast<float*>(mine + RINGB);
     unsigned* krow = reinterpret_cast<unsigned*>(mine + RINGB + d * 4);
@@ -208,8 +208,12 @@ __device__ __forceinline__ void rescore_group(const RescoreParams& P, const Sele
         for (int i = lane; i < nk; i += 64) krow[off[sl] + i] = O.surv_row[(size_t)(p0 + sl) * RC_KEEP + i];
     }
     const int total = off[G];
-    const float* qg = P.q + (size_t)(p0 / P.nb) * d;
-    for (int k = lane * 4; k < d; k += 256) *reinterpret_cast<float4*>(qs + k) = *reinterpret_cast<const float4*>(qg + k);
+    const float* qg = P.q + (size_t)(p0 / P.nb) * P.d;
+    if (P.d == d) {
+        for (int k = lane * 4; k < d; k += 256) *reinterpret_cast<float4*>(qs + k) = *reinterpret_cast<const float4*>(qg + k);
+    } else {   // d not a multiple of 4: the query's rows are not 16-byte aligned, its tail is padded with zeros here
+        for (int k = lane; k < d; k += 64) qs[k] = k < P.d ? qg[k] : 0.0f;
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int nchunks = (d + RC_CHUNK - 1) / RC_CHUNK;

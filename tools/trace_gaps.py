@@ -19,7 +19,7 @@ def main(src, anchor="pack_queries16_kernel"):
         by_q[r["Queue_Id"]].append(r)
     # every queue that carries a scan (the pipelined loop and the resident loop run on different streams)
     for q in sorted(by_q):
-        if any("pass2_kernel" in r["Kernel_Name"] for r in by_q[q]):
+        if any("pass2_" in r["Kernel_Name"] for r in by_q[q]):
             one_queue(q, sorted(by_q[q], key=lambda r: int(r["Start_Timestamp"])), anchor)
 
 
