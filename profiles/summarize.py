@@ -17,8 +17,8 @@ import sys
 
 
 def one(pattern):
-    files = glob.glob(pattern, recursive=True)
-    return files[0] if files else None
+    files = glob.glob(pattern, recursive=True)   # gpurun merges new files into the directory: leftovers of an earlier pass may lie beside them
+    return max(files, key=os.path.getmtime) if files else None
 
 
 DOMINANT = "lmi::scan_kernel("
