@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 tag="$1"; K="${2:-pass2_kernel<false}"
 root="$PWD"; out="$root/gpurun_out/prof_$tag"
 mkdir -p "$out"
-B="python3 $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-recall --no-hard-leg"
+B="python3 $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-recall --no-hard-leg --no-other-configs"
 cd /tmp
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- $B > "$out/bench_under_rocprof.json" 2> "$out/trace.err" || { echo "trace pass failed"; tail -5 "$out/trace.err"; exit 1; }
 echo "trace done"
