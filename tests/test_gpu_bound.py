@@ -55,6 +55,8 @@ def make(kind, d, seed):
 
 
 CASES = [(k, d) for d in (768, 2048, 4096) for k in ("gauss", "positive", "binade_up", "binade_down", "binade_mix", "scales")]
+# d <= 128: the low-dimensional kernels (lmi_pass2_small.h), K padded to whole k16-groups (45 -> 48, 100 -> 112)
+CASES += [(k, d) for d in (45, 100, 128) for k in ("gauss", "positive", "binade_mix", "scales")]
 
 
 @pytest.mark.parametrize("kind,d", CASES)
