@@ -220,7 +220,9 @@ LMI_API int lmi_set_prefilter(lmi_index *h, int on);
  * alternates handles: a batch's kernels start in the tails of the previous batch's).  Destroy the clone before the parent;
  * do not rebuild the parent's index while a clone lives. */
 LMI_API int lmi_clone_view(lmi_index *h, lmi_index **out);
-/* Developer aid: copies the first `bytes` of a named internal device buffer to host memory ("pf_bound"). */
+/* Developer aid: copies the first `bytes` of a named internal device buffer to host memory: "pf_bound" (pass 1's slot maxima),
+ * "pf_stamps" (phase cycles of -DLMI_P2_STAMPS builds), "pf_redo" ([0]: columns whose candidate buffer overflowed in the last scan);
+ * "cand_total" (8 bytes): the candidates pass 2 emitted in the last scan, summed over all columns. */
 LMI_API int lmi_debug_peek(lmi_index *h, const char *name, void *dst, int64_t bytes);
 LMI_API int lmi_prefilter_stats(lmi_index *h, int *active, int64_t *survivors, int64_t *fallbacks);
 /* Tuning: rows per scan chunk (multiple of the 256-row block tile).  Not called: lmi_buckets_begin picks

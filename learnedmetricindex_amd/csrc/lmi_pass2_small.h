@@ -10,7 +10,7 @@
 //   * a wave streams ROW-BLOCKS: it loads the KG fragments of two row-blocks straight from global memory into registers (they
 //     are private to the wave: no LDS, no barrier) one pair ahead, and walks the col-blocks: KG MFMAs per (row-block,
 //     col-block) chained on one 16-register accumulator, tested (pass 2) or reduced to its maximum (pass 1) at once;
-//   * no K loop, no ring, no stage barrier; four waves per block, three blocks per CU;
+//   * no K loop, no ring, no stage barrier; four waves per block, two blocks per CU (three fit the LDS at KG <= 4 but leave pass 2 too few registers);
 //   * pass 2's candidates of a row-block pair are compacted through a wave-private LDS list and go out one pair late (below).
 // Work items, queues, bounds, candidate buffers and the accumulation order (k-groups in order from 0, so shat is bit-identical
 // to pass2_kernel's) are those of lmi_pass2.h: the host picks the kernel by KG16 alone.
@@ -26,9 +26,6 @@ constexpr int PS_MAXKG = 8;
 constexpr int PS_WAVES = 4;
 
 __host__ __device__ constexpr int ps_lds_bytes(int kg) { return P2_MAXCB * kg * 1024 + P2_MAXCB * 32 * 4; }
-#ifndef LMI_PS_AHEAD
-#define LMI_PS_AHEAD 1     // row-block pairs requested ahead of the one being computed (1 or 2: measured equal, 2 costs 32 registers)
-#endif
 #ifndef LMI_PS_BLOCKS4
 #define LMI_PS_BLOCKS4 2   // blocks per CU at KG <= 4 (LDS allows 3, but pass 2 then has 168 registers and spills 175: 0.47 -> 1.06 ms)
 #endif
@@ -227,30 +224,14 @@ __global__ __launch_bounds__(64 * PS_WAVES, ps_blocks_per_cu(KG)) void pass2_sma
             }
             pair_done();
         };
-        // the wave's pairs p = w, w + 4, ..: fragments requested TWO pairs ahead (a pair is ~1 us of work, a load under a full
-        // memory system 2-4 us), three register sets taking turns
-        half8 b0[KG], b1[KG], c0r[KG], c1r[KG];
+        // the wave's pairs p = w, w + 4, ..: the next pair's fragments are requested before the current one is computed, two register
+        // sets taking turns (two pairs ahead with three sets measured equal: profiles/r03_pass2_experiments.txt section 14)
+        half8 b0[KG], b1[KG];
         const int last = npairs - 1;
         int p = w;
 #ifdef LMI_ABL_NOLOAD   // timing-only ablation: the row-blocks are not streamed (wrong results)
         load_pair(min(p, last), a0, a1);
         for (; p < npairs; p += PS_WAVES) do_pair(p, a0, a1);
-#else
-#if LMI_PS_AHEAD == 2
-        if (p < npairs) { load_pair(p, a0, a1); load_pair(min(p + PS_WAVES, last), b0, b1); }
-        while (p < npairs) {
-            load_pair(min(p + 2 * PS_WAVES, last), c0r, c1r);
-            do_pair(p, a0, a1);
-            p += PS_WAVES;
-            if (p >= npairs) break;
-            load_pair(min(p + 2 * PS_WAVES, last), a0, a1);
-            do_pair(p, b0, b1);
-            p += PS_WAVES;
-            if (p >= npairs) break;
-            load_pair(min(p + 2 * PS_WAVES, last), b0, b1);
-            do_pair(p, c0r, c1r);
-            p += PS_WAVES;
-        }
 #else
         if (p < npairs) load_pair(p, a0, a1);
         while (p < npairs) {
@@ -262,8 +243,6 @@ __global__ __launch_bounds__(64 * PS_WAVES, ps_blocks_per_cu(KG)) void pass2_sma
             do_pair(p, b0, b1);
             p += PS_WAVES;
         }
-        (void)c0r; (void)c1r;
-#endif
 #endif
         if (!SAMPLE) flush_pending();
         __syncthreads();   // the query fragments are replaced by the next item's

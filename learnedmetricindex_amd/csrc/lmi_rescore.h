@@ -72,6 +72,10 @@ __device__ __forceinline__ void select_tail(const RescoreParams& P, const Select
                                             const float* __restrict__ cs, const unsigned* __restrict__ cr,
                                             const float (&s_spec)[SPEC], const unsigned (&r_spec)[SPEC]) {
     const int nper = (int)((cnt + 63u) >> 6);
+    // needed after the bisection, requested before it (two dependent loads: they would be a round trip of their own at the end)
+    const float e2 = P.eps2[col];
+    const int bkt = P.bucket_order[p];
+    const unsigned row_base = (unsigned)P.rb_start[bkt] * 32u;
     unsigned key[PERV];  // monotone image of shat; 0 = no candidate
 #pragma unroll
     for (int i = 0; i < PERV; ++i) {
@@ -95,13 +99,12 @@ __device__ __forceinline__ void select_tail(const RescoreParams& P, const Select
         }
         pv = __uint_as_float(T ^ ((T >> 31) ? 0x80000000u : 0xffffffffu));
     }
-    const float cut = pv - P.eps2[col];
+    const float cut = pv - e2;
     const unsigned cbits = __float_as_uint(cut);
     const unsigned kcut = cut != cut ? 1u : cbits ^ ((cbits >> 31) ? 0xffffffffu : 0x80000000u);
     unsigned* out = O.surv_row + (size_t)p * RC_KEEP;
     // survivors are stored as ABSOLUTE slab rows (bucket start + row): the re-rank wave then needs no bucket_order -> rb_start
     // round trips before it can request the rows (its waves run one per SIMD: every dependent load is exposed latency)
-    const unsigned row_base = (unsigned)P.rb_start[P.bucket_order[p]] * 32u;
     unsigned nk = 0;
 #pragma unroll
     for (int i = 0; i < PERV; ++i) {
@@ -118,7 +121,7 @@ __device__ __forceinline__ void select_tail(const RescoreParams& P, const Select
     if (nk == 0u && lane < KPB) {
         // no candidate at all (a query-level bound above everything this bucket holds, query_bound_kernel): no rescore wave
         // may come by, so the slot's list is written here -- all padding (it sorts behind every real entry of the query)
-        const int b = P.bucket_order[p];
+        const int b = bkt;
         const int rb0 = P.rb_start[b], n_b = P.nb_rows[b];
         P.rank_d[(size_t)p * KPB + lane] = P.raw ? -3.402823466e+38f : pad_dist(P.qn2);
         P.rank_id[(size_t)p * KPB + lane] = P.raw ? NOROW : P.ids_slab[(size_t)rb0 * 32 + (n_b - 1)];
@@ -164,7 +167,8 @@ __global__ __launch_bounds__(256) void select_kernel(RescoreParams P, SelectOut 
         if (lane == 0) P.fallback[p] = 1;
         return;
     }
-    if (cnt <= 256u) select_tail<4, SPEC>(P, O, p, col, lane, cnt, cs, cr, s_spec, r_spec);
+    if (cnt <= 64u) select_tail<1, SPEC>(P, O, p, col, lane, cnt, cs, cr, s_spec, r_spec);   // (the columns behind a query's primary one: a handful each)
+    else if (cnt <= 256u) select_tail<4, SPEC>(P, O, p, col, lane, cnt, cs, cr, s_spec, r_spec);
     else select_tail<PER, SPEC>(P, O, p, col, lane, cnt, cs, cr, s_spec, r_spec);
 }
 
