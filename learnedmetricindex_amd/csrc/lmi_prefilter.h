@@ -577,7 +577,7 @@ __global__ __launch_bounds__(64 * RS_WAVES) __attribute__((amdgpu_waves_per_eu(L
 // Candidate-buffer overflow (more than PF_CAP rows passed a column's threshold: the sampled bound was loose, typically many
 // copies of the same vectors near the top).  The PF_CAP candidates that were stored are a subset of the bucket: the 10th best
 // of their scores is a valid -- and much tighter -- lower bound of That.  The column gets that bound, an empty buffer and a
-// flag; prefilter_kernel<false> is launched once more and re-runs the buckets that hold such columns with every other
+// flag; pass 2 (pass2_kernel<false> / pass2_small_kernel<KG, false>) is launched once more and re-runs the buckets that hold such columns with every other
 // column's threshold at +inf.  Without this such a slot took the exact fallback (one block brute-forcing the bucket).
 __global__ void overflow_rebound_kernel(const int* __restrict__ slot_col, const int* __restrict__ bucket_order, int nslots,
                                         unsigned* __restrict__ cand_cnt, const float* __restrict__ cand_s, float* __restrict__ bound1,
