@@ -24,6 +24,7 @@ namespace lmi {
 
 constexpr int PS_MAXKG = 8;
 constexpr int PS_WAVES = 4;
+constexpr int PS_ROW_BITS = 23;   // list entry = column in the tile (9 bits) << 23 | row in the item's chunk (a chunk is at most 2^31 / 1024 rows)
 
 __host__ __device__ constexpr int ps_lds_bytes(int kg) { return P2_MAXCB * kg * 1024 + P2_MAXCB * 32 * 4; }
 #ifndef LMI_PS_BLOCKS4
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(64 * PS_WAVES, ps_blocks_per_cu(KG)) void pass2_sma
                             if (pass) {
                                 const int my = tot + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
                                 if (my < 64) {
-                                    my_list[my] = make_uint2(((unsigned)(n * 32 + c) << 20) | row, __float_as_uint(acc[4 * j + i]));
+                                    my_list[my] = make_uint2(((unsigned)(n * 32 + c) << PS_ROW_BITS) | row, __float_as_uint(acc[4 * j + i]));
                                 } else {   // a pair with more than 64 candidates: the rest goes out at once
                                     const size_t col = col0 + n * 32 + c;
                                     const unsigned pos = atomicAdd(P.cand_cnt + col, 1u);
@@ -184,8 +185,8 @@ __global__ __launch_bounds__(64 * PS_WAVES, ps_blocks_per_cu(KG)) void pass2_sma
             if (tot > 0) {
                 if (lane < min(tot, 64)) {
                     const uint2 e = my_list[lane];
-                    pend_col = col0 + (e.x >> 20);
-                    pend_row = (unsigned)(rb0 * 32) + (e.x & 0xFFFFFu);
+                    pend_col = col0 + (e.x >> PS_ROW_BITS);
+                    pend_row = (unsigned)(rb0 * 32) + (e.x & ((1u << PS_ROW_BITS) - 1u));
                     pend_s = __uint_as_float(e.y);
                     pend_pos = atomicAdd(P.cand_cnt + pend_col, 1u);
                 }
