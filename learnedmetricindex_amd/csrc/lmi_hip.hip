@@ -541,9 +541,10 @@ extern "C" LMI_API int lmi_buckets_begin(lmi_index* h, int64_t N, int d, int L, 
         if (h->chunk_rows_auto) {
             h->chunk_rows = (int)std::min<long long>(2048, std::max<long long>(P2_TILE_ROWS, rup(owned_rows / 4096, P2_TILE_ROWS)));
             // d <= 128 (lmi_pass2_small.h): a 2048-row item is ~5 us of work there, about what taking it from the queue and
-            // staging its query fragments costs: up to 8192 rows per item (10M x 45: pass 2 0.40 -> 0.27 ms)
+            // staging its query fragments costs, while 8192-row items are too few to share out evenly (10M x 45, pass 2 at
+            // 1024 / 2048 / 4096 / 8192 rows per item: 0.590 / 0.441 / 0.385 / 0.412 ms): up to 4096
             if (h->pf_small && cdiv(d, 16) <= PS_MAXKG)
-                h->chunk_rows = (int)std::min<long long>(8192, std::max<long long>(P2_TILE_ROWS, rup(owned_rows / 1024, P2_TILE_ROWS)));
+                h->chunk_rows = (int)std::min<long long>(4096, std::max<long long>(P2_TILE_ROWS, rup(owned_rows / 1024, P2_TILE_ROWS)));
         }
         const int need = (int)rup(cdiv(max_rows, 1024), 256);
         if (need > h->chunk_rows) h->chunk_rows = need;
