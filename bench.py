@@ -130,6 +130,7 @@ class Workload:
         # Expected scan work of a bucket = its rows x the queries it will receive, the latter estimated at build
         # time by routing a sample of the DATA through the MLP (every rank computes the same estimate).
         work_w = estimate_bucket_work(eng, gen_rows(1, 0, pieces[0][1])[: min(20_000, N)], nb, sizes)
+        self.work_w = work_w
         owner = assign_buckets(sizes, world, weights=work_w)
         owned = (owner == rank).astype(np.uint8) if world > 1 else None
         self.shard_world, self.owner_all = world, owner
@@ -610,6 +611,9 @@ def main():
         bo_h = bo_h[(bo_h >= 0) & (bo_h < L)]
         per_rank = np.bincount(wl.owner_all[bo_h], weights=sizes[bo_h].astype(np.float64), minlength=wl.shard_world)
         log(f"[bench] scan work per rank (pairs, share of the mean): {np.round(per_rank / per_rank.mean(), 3).tolist()}")
+        if os.environ.get("LMI_BENCH_DUMP_BUCKETS"):   # developer aid: the assignment's inputs and this batch's real routing
+            np.savez(os.environ["LMI_BENCH_DUMP_BUCKETS"], sizes=sizes, owner_all=wl.owner_all, work_w=getattr(wl, "work_w", None),
+                     m=np.bincount(bo_h, minlength=L))
     # N > 1: the other collective layout (every rank routes the whole batch: ONE all-gather, as north_star words it)
     alt = None
     if world > 1:
