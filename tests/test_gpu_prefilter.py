@@ -217,3 +217,49 @@ def test_low_dimensional_form_every_group_count(capi, oracle, d):
     D, I = oracle.knn_ip(Q[:1], X[rows], 10)
     np.testing.assert_array_equal(i0[:1], (rows[I] + 1).astype(np.uint32))
     np.testing.assert_array_equal(d0[:1], np.float32(1) - D)
+
+
+@pytest.mark.parametrize("d", [160, 256])
+def test_narrow_query_tiles_in_long_chunks(capi, oracle, d):
+    """Most tiles of a real batch are narrow (a bucket receives 0 ... 4 235 queries, median 220, at C2): buckets that receive
+    1 ... 192 queries (1 ... 6 col-blocks) and the first wider ones, bucket sizes around the 256 / 512-row boundaries (one
+    256-row tile, two, two and a ragged row-block, several + a short rest), 2048-row and 512-row chunks, d = 160 (5 stages: a dead
+    ring step per tile) and 256.  Prefilter == exact mode bit for bit; two buckets against the oracle.  (Written for the
+    512-vector tile of profiles/r03_pass2_wide_variant.h.txt, which passed it; kept for the shapes.)"""
+    rs = np.random.RandomState(300 + d)
+    m_per_bucket = [1, 31, 33, 64, 65, 96, 97, 128, 129, 160, 161, 192, 193, 224, 300, 3]
+    sizes = [700, 256, 257, 512, 513, 1000, 2048, 2049, 2048 + 300, 4096 + 33, 511, 1025, 3000, 777, 1500, 5000]
+    L = len(m_per_bucket)
+    labels = np.concatenate([np.full(n, b) for b, n in enumerate(sizes)])
+    rs.shuffle(labels)
+    centres = rs.randn(L, d).astype(np.float32)
+    X = centres[labels] + rs.randn(labels.size, d).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    first = np.concatenate([np.full(m, b) for b, m in enumerate(m_per_bucket)]).astype(np.int32)
+    rs.shuffle(first)
+    nq = first.size
+    second = (first + 1 + rs.randint(0, L - 1, nq)) % L      # a second, different bucket: the query-level bound is in play
+    order = np.stack([first, second], axis=1).astype(np.int32)
+    Q = centres[first] + rs.randn(nq, d).astype(np.float32)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    ref = None
+    for chunk_rows in (2048, 512):
+        (d1, i1, sv, fb), (d0, i0, _, _) = both_modes(capi, X, labels, L, Q, order, chunk_rows=chunk_rows)
+        np.testing.assert_array_equal(i1, i0)
+        np.testing.assert_array_equal(d1, d0)
+        assert fb == 0
+        if ref is None:
+            ref = (d0, i0)
+        np.testing.assert_array_equal(i0, ref[1])
+        np.testing.assert_array_equal(d0, ref[0])
+    # one-bucket routing of two narrow buckets against the oracle
+    for b in (9, 12):
+        qsel = np.flatnonzero(first == b)
+        idx = capi.Index(0, chunk_rows=2048, prefilter=True)
+        idx.set_buckets(X, labels, L)
+        dd, ii = idx.scan_topk(Q[qsel], np.full((qsel.size, 1), b, dtype=np.int32), 10)
+        idx.close()
+        rows = np.flatnonzero(labels == b)
+        D, I = oracle.knn_ip(Q[qsel], X[rows], 10)
+        np.testing.assert_array_equal(ii, (rows[I] + 1).astype(np.uint32))
+        np.testing.assert_array_equal(dd, np.float32(1) - D)
