@@ -10,7 +10,7 @@
 #include <cstdlib>
 
 constexpr int KG = 48;          // k16-groups per row-block (d = 768)
-constexpr int SLOT = 40 * 1024; // ring slot (16 KiB used here)
+constexpr int SLOT = 48 * 1024; // ring slot (vectors at 0 .. 32 KiB, query fragments behind)
 
 __device__ __forceinline__ void glds16(const uint4* g, uint4* lds_wave_base, int off) {
     // LDS destination = wave-uniform base + lane * 16
@@ -22,7 +22,7 @@ __device__ __forceinline__ void glds16(const uint4* g, uint4* lds_wave_base, int
 
 // PBL: query-fragment pieces per loader wave and stage (0, 2, 4, 6 = col-blocks lw, lw + 4, lw + 8 x two k-groups), read from a
 // 576-KiB region per 8-tile chunk that every tile of the chunk re-reads (L2 hits, as in pass 2)
-template <int PATTERN, int PBL, int SPLIT = 0>
+template <int PATTERN, int PBL, int SPLIT = 0, int WIDE = 0>
 __global__ __launch_bounds__(512, 1) void k(const uint4* __restrict__ slab, const uint4* __restrict__ qfrag, long long n_tiles, unsigned* __restrict__ head, float* sink) {
     __shared__ __attribute__((aligned(16))) uint4 ring[3 * SLOT / 16];
     __shared__ long long s_tile;
@@ -52,26 +52,34 @@ __global__ __launch_bounds__(512, 1) void k(const uint4* __restrict__ slab, cons
                 glds16(a0, dst + lw * 128, 1);
                 glds16(a1, dst + (lw + 4) * 128, 0);
                 glds16(a1, dst + (lw + 4) * 128, 1);
+                if (WIDE) {   // the second 256 vectors of a 512-vector tile (the next tile's row-blocks), same stage
+                    const uint4* a2 = src(t + 1, s, lw);
+                    const uint4* a3 = src(t + 1, s, lw + 4);
+                    glds16(a2, dst + (8 + lw) * 128, 0);
+                    glds16(a2, dst + (8 + lw) * 128, 1);
+                    glds16(a3, dst + (12 + lw) * 128, 0);
+                    glds16(a3, dst + (12 + lw) * 128, 1);
+                }
             }
             if (SPLIT && w >= 4) return;
             const uint4* qb = qfrag + ((t0 / 8) % 64) * (12 * KG * 64) + lane;   // the chunk's query tile (64 of them in rotation)
 #pragma unroll
             for (int j = 0; j < PBL / 2; ++j) {
                 const uint4* b = qb + ((lw + 4 * j) * KG + 2 * s) * 64;
-                glds16(b, dst + 1024 + (lw + 4 * j) * 128, 0);
-                glds16(b, dst + 1024 + (lw + 4 * j) * 128, 1);
+                glds16(b, dst + 2048 + (lw + 4 * j) * 128, 0);
+                glds16(b, dst + 2048 + (lw + 4 * j) * 128, 1);
             }
         };
-        const long long total = (t1 - t0) * NS;
+        const long long total = (t1 - t0) * NS / (WIDE ? 2 : 1);   // WIDE: two tiles per turn
         long long issued = 0;
         if (loader) { issue(t0, 0, 0); issue(t0 + 1 / NS, 1 % NS, 1); }
         issued = 2;
         for (long long i = 0; i < total; ++i) {
             if (SPLIT && w < 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PBL) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(SPLIT ? 4 : 4 + PBL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(SPLIT ? 4 : (WIDE ? 8 : 4) + PBL) : "memory");
             __builtin_amdgcn_s_barrier();
             if (issued < total) {
-                if (loader) issue(t0 + issued / NS, (int)(issued % NS), (int)(issued % 3));
+                if (loader) issue(t0 + (issued / NS) * (WIDE ? 2 : 1), (int)(issued % NS), (int)(issued % 3));
                 ++issued;
             } else if (loader) {   // keep the count of outstanding pieces constant for the vmcnt literal
                 issue(t0, 0, (int)((i + 2) % 3));
@@ -99,11 +107,12 @@ int main() {
     (void)hipMalloc(&qfrag, qbytes); (void)hipMalloc(&head, 4); (void)hipMalloc(&sink, 4);
     (void)hipMemset(slab, 0, bytes); (void)hipMemset(qfrag, 0, qbytes);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    const char* names[7] = {"slab as it is (8 x 2 KiB at 48 KiB stride), vectors only", "stage-major (16 KiB contiguous per stage), vectors only",
+    const char* names[9] = {"slab as it is (8 x 2 KiB at 48 KiB stride), vectors only", "stage-major (16 KiB contiguous per stage), vectors only",
                             "slab as it is + query fragments of 4 col-blocks", "slab as it is + query fragments of 8 col-blocks", "slab as it is + query fragments of 12 col-blocks",
-                            "the same, 8 col-blocks, query pieces issued by waves 0-3 and vector pieces by waves 4-7", "the same, 12 col-blocks"};
+                            "the same, 8 col-blocks, query pieces issued by waves 0-3 and vector pieces by waves 4-7", "the same, 12 col-blocks",
+                            "512-vector tiles (8 vector pieces per loader and stage) + query fragments of 4 col-blocks", "512-vector tiles + 8 col-blocks"};
     for (int rep = 0; rep < 2; ++rep)
-        for (int pat = 0; pat < 7; ++pat) {
+        for (int pat = 0; pat < 9; ++pat) {
             (void)hipMemset(head, 0, 4);
             (void)hipEventRecord(e0);
             switch (pat) {
@@ -113,7 +122,9 @@ int main() {
                 case 3: k<0, 4><<<256, 512>>>(slab, qfrag, n_tiles, head, sink); break;
                 case 4: k<0, 6><<<256, 512>>>(slab, qfrag, n_tiles, head, sink); break;
                 case 5: k<0, 4, 1><<<256, 512>>>(slab, qfrag, n_tiles, head, sink); break;
-                default: k<0, 6, 1><<<256, 512>>>(slab, qfrag, n_tiles, head, sink); break;
+                case 6: k<0, 6, 1><<<256, 512>>>(slab, qfrag, n_tiles, head, sink); break;
+                case 7: k<0, 2, 0, 1><<<256, 512>>>(slab, qfrag, n_tiles, head, sink); break;
+                default: k<0, 4, 0, 1><<<256, 512>>>(slab, qfrag, n_tiles, head, sink); break;
             }
             (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
             float ms; (void)hipEventElapsedTime(&ms, e0, e1);
