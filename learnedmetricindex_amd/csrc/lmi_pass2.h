@@ -86,8 +86,12 @@ struct Tile2 {
     // after the other (the matrix pipe goes to the older wave until it has issued all of its MFMAs: stamps, profiles/r03_*), so
     // a piece issued by the older wave (~50 cycles each, in order with its MFMAs) stalls the pipe, while the younger wave issues
     // the whole stage's pieces at the stage's start, in the shadow of its partner's MFMAs.  Loader lw = w - 4 stages
-    // row-blocks lw, lw + 4 and col-blocks lw, lw + 4, lw + 8 (past the tile: the last col-block again), both k-groups.
-    static constexpr int PBL = NCB <= 4 ? 2 : NCB <= 8 ? 4 : 6;
+    // row-blocks lw, lw + 4 (both k-groups) and its share of the query fragments (below).
+    // Query fragments: 2 NCB one-KiB pieces per stage; loader lw takes k-group lw & 1 of col-blocks (lw >> 1), + 2, + 4, ..: PBL =
+    // ceil(NCB / 2) pieces each (a loader past the tile's last col-block repeats it: 4 PBL - 2 NCB is 0 or 2 pieces, where whole
+    // col-blocks per loader -- 2 / 4 / 6 pieces -- issued up to 6 too many; a piece costs the CU ~60 cycles of its LDS-DMA path,
+    // profiles/r03_pass2_experiments.txt section 20).
+    static constexpr int PBL = (NCB + 1) / 2;
     static constexpr int PW = 2 * G + PBL;                  // pieces per loader wave and stage (constant: the vmcnt literal)
     static constexpr int QA = NCB > D + 1 ? NCB - D - 1 : 0;  // A fragment of k-group 1 is requested after MFMA QA
     static_assert(G == 2, "written out for two k-groups per stage");
@@ -176,8 +180,8 @@ struct Tile2 {
     struct Stream {        // wave-uniform source pointers of the NEXT stage to load (loaders)
         const uint4* a0;   // row-block lw of the tile, k-group pair t
         const uint4* a1;   // row-block lw + 4
-        const uint4* b0;   // col-block lw (clamped)
-        int d1, d2;        // offsets (uint4) of col-blocks lw + 4, lw + 8 (clamped to the tile's last) from b0
+        const uint4* b0;   // the tile's first col-block, k-group pair t
+        int bo[PBL];       // offsets (uint4) of this loader's pieces from b0: k-group lw & 1 of col-blocks (lw >> 1) + 2 j (clamped)
     };
     template <int DST>
     __device__ __forceinline__ void dma_all(const Stream& S) {
@@ -190,19 +194,11 @@ struct Tile2 {
         glds16o<1024, LMI_PF_A_AUX>(reinterpret_cast<const float4*>(S.a0 + lane), reinterpret_cast<float4*>(slot + lw * (G * 64)));
         glds16o<0, LMI_PF_A_AUX>(reinterpret_cast<const float4*>(S.a1 + lane), reinterpret_cast<float4*>(slot + (lw + 4) * (G * 64)));
         glds16o<1024, LMI_PF_A_AUX>(reinterpret_cast<const float4*>(S.a1 + lane), reinterpret_cast<float4*>(slot + (lw + 4) * (G * 64)));
-        const int cb0 = lw < NCB ? lw : NCB - 1;
-        glds16o<0>(reinterpret_cast<const float4*>(S.b0 + lane), reinterpret_cast<float4*>(slot + P2_A_BYTES / 16 + cb0 * (G * 64)));
-        glds16o<1024>(reinterpret_cast<const float4*>(S.b0 + lane), reinterpret_cast<float4*>(slot + P2_A_BYTES / 16 + cb0 * (G * 64)));
-        if constexpr (PBL >= 4) {
-            const int cb1 = lw + 4 < NCB ? lw + 4 : NCB - 1;
-            glds16o<0>(reinterpret_cast<const float4*>(S.b0 + S.d1 + lane), reinterpret_cast<float4*>(slot + P2_A_BYTES / 16 + cb1 * (G * 64)));
-            glds16o<1024>(reinterpret_cast<const float4*>(S.b0 + S.d1 + lane), reinterpret_cast<float4*>(slot + P2_A_BYTES / 16 + cb1 * (G * 64)));
-        }
-        if constexpr (PBL >= 6) {
-            const int cb2 = lw + 8 < NCB ? lw + 8 : NCB - 1;
-            glds16o<0>(reinterpret_cast<const float4*>(S.b0 + S.d2 + lane), reinterpret_cast<float4*>(slot + P2_A_BYTES / 16 + cb2 * (G * 64)));
-            glds16o<1024>(reinterpret_cast<const float4*>(S.b0 + S.d2 + lane), reinterpret_cast<float4*>(slot + P2_A_BYTES / 16 + cb2 * (G * 64)));
-        }
+        static_for<0, PBL>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const int cb = min((lw >> 1) + 2 * j, NCB - 1);
+            glds16(reinterpret_cast<const float4*>(S.b0 + S.bo[j] + lane), reinterpret_cast<float4*>(slot + P2_A_BYTES / 16 + (cb * G + (lw & 1)) * 64));
+        });
     }
 
     // One stage: ring slot SLOT computes, the pieces of stage (+2) go to slot DST.  `pend`: the previous stage left its last
@@ -447,8 +443,7 @@ struct Tile2 {
         const int rb_last = nrb_b - 1;
         const bool loader = is_loader();
         const int lw = w & 3;
-        const int cbl0 = lw < NCB ? lw : NCB - 1, cbl1 = lw + 4 < NCB ? lw + 4 : NCB - 1, cbl2 = lw + 8 < NCB ? lw + 8 : NCB - 1;
-        const uint4* bbase0 = P.qfrag16 + ((size_t)(cb_tile + cbl0) * KG) * 64;
+        const uint4* bbase0 = P.qfrag16 + ((size_t)cb_tile * KG) * 64;
         if (!SAMPLE) {
             // thresholds of the tile's columns -> LDS (the caller's barrier made sThr free; the first stage's barrier publishes it)
             for (int i = tid; i < NCB * 32; i += 64 * P2_WAVES) {
@@ -462,8 +457,8 @@ struct Tile2 {
         S.a0 = aslab + (size_t)min(rb0 + lw, rb_last) * rb_stride;
         S.a1 = aslab + (size_t)min(rb0 + lw + 4, rb_last) * rb_stride;
         S.b0 = bbase0;
-        S.d1 = (cbl1 - cbl0) * KG * 64;
-        S.d2 = (cbl2 - cbl0) * KG * 64;
+#pragma unroll
+        for (int j = 0; j < PBL; ++j) S.bo[j] = (min((lw >> 1) + 2 * j, NCB - 1) * KG + (lw & 1)) * 64;
         const int NSR = (NS + P2_RING - 1) / P2_RING * P2_RING;
 #define P2_ADVANCE                                                                               \
         if (++t_n < NS) { S.a0 += G * 64; S.a1 += G * 64; S.b0 += G * 64; }                      \
