@@ -11,6 +11,9 @@
 
 constexpr int KG = 48;          // k16-groups per row-block (d = 768)
 constexpr int SLOT = 48 * 1024; // ring slot (vectors at 0 .. 32 KiB, query fragments behind)
+// query-tile source (round 4): 0 = 64 tiles in rotation by chunk (37 MB in use at any time: NOT L2-resident, as round 3 assumed);
+// 1 = one tile per XCD (real L2 hits, what pass 2's XCD-affine queues arrange)
+__device__ int g_qsrc = 0;
 
 __device__ __forceinline__ void glds16(const uint4* g, uint4* lds_wave_base, int off) {
     // LDS destination = wave-uniform base + lane * 16
@@ -62,7 +65,8 @@ __global__ __launch_bounds__(512, 1) void k(const uint4* __restrict__ slab, cons
                 }
             }
             if (SPLIT && w >= 4) return;
-            const uint4* qb = qfrag + ((t0 / 8) % 64) * (12 * KG * 64) + lane;   // the chunk's query tile (64 of them in rotation)
+            const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7);
+            const uint4* qb = qfrag + (g_qsrc ? (long long)xcc * 8 + ((t0 / 8 / 256) % 8) : (t0 / 8) % 64) * (12 * KG * 64) + lane;   // the chunk's query tile
 #pragma unroll
             for (int j = 0; j < PBL / 2; ++j) {
                 const uint4* b = qb + ((lw + 4 * j) * KG + 2 * s) * 64;
@@ -113,6 +117,8 @@ int main() {
                             "512-vector tiles (8 vector pieces per loader and stage) + query fragments of 4 col-blocks", "512-vector tiles + 8 col-blocks"};
     for (int rep = 0; rep < 2; ++rep)
         for (int pat = 0; pat < 9; ++pat) {
+            const int qsrc = rep;   // first round: 64 tiles in rotation; second round: one tile per XCD
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_qsrc), &qsrc, sizeof(int));
             (void)hipMemset(head, 0, 4);
             (void)hipEventRecord(e0);
             switch (pat) {
@@ -128,7 +134,7 @@ int main() {
             }
             (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
             float ms; (void)hipEventElapsedTime(&ms, e0, e1);
-            printf("%-82s %.3f ms for %.2f GB of vectors -> %.2f TB/s\n", names[pat], ms, bytes / 1e9, bytes / 1e9 / ms);
+            printf("%-82s [%s] %.3f ms for %.2f GB of vectors -> %.2f TB/s\n", names[pat], qsrc ? "one query tile per XCD" : "37 MB of query tiles", ms, bytes / 1e9, bytes / 1e9 / ms);
         }
     return 0;
 }
