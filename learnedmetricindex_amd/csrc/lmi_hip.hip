@@ -967,7 +967,7 @@ static int launch_pass2(lmi_index* h, const PrefilterParams& F) {
         }
 #undef LMI_PS_CASE
     } else {
-        pass2_kernel<SAMPLE><<<h->num_cus, 64 * P2_WAVES, 0, h->stream>>>(F);
+        pass2_kernel<SAMPLE><<<h->num_cus * P2_BLOCKS_PER_CU, 64 * P2_WAVES, 0, h->stream>>>(F);
     }
     HIPCHK(hipGetLastError());
     return 0;

@@ -1,25 +1,25 @@
-// lmi_pass2.h -- the prefilter's scan kernel, round-3 form (gfx950): ONE query tile per bucket chunk.
+// lmi_pass2.h -- the prefilter's scan kernel (gfx950): ONE query tile per bucket chunk, vectors straight into registers.
 //
-// What changed against prefilter_kernel (lmi_prefilter.h, rounds 1-2) and why.  That kernel gave a wave 64 vectors x <= 128
-// queries; a bucket's ~345 routed queries = 11 col-blocks became TWO query tiles (6 + 5), so every vector stage was fetched
-// and staged twice, a stage carried 12 MFMAs per wave against fixed costs of one barrier + 4 LDS-DMA pieces + 10 fragment
-// reads, and the queries' fragments were re-staged for every 256 vectors: 51 GB went through L2 -> LDS per 10 000-query
-// batch for 15.4 GB of index (profiles/r02_pass2_stamps.txt: 26 % of the older wave group's time parked at the barrier,
-// stages under-filled; 0.42 of the HBM roofline).
-// Here a block tile is 256 vectors x <= 384 queries and a WAVE owns one 32-vector row-block x ALL (<= 12) col-blocks:
-//   * a bucket chunk is one tile (up to 384 queries): its vectors are fetched and staged once; the queries' fragments are
-//     re-staged per 256 vectors as before but for one tile instead of two: L2 -> LDS bytes per flop fall by 1.4 x;
-//   * every wave does the same work for any number of col-blocks (NCB MFMAs per k-group): no under-filled group, no
-//     duplicate pieces; a 32-deep stage carries 2 NCB MFMAs per wave (24 at 12 col-blocks) per barrier;
-//   * a wave reads only ITS row-block's vector fragments (1 read per k-group, staged by itself: no other wave depends on
-//     them) + the NCB query fragments: 13 ds_read_b128 per 12 MFMAs = 54 % of the LDS read bandwidth;
-//   * 192 accumulator registers + 2 A fragments + a ring of 4 B fragments: the thresholds live in LDS, not in registers.
-// The B-fragment reads run D = 3 fragments ahead of the MFMAs as ONE stream that continues across the stage barrier: the
-// last D MFMAs of a stage are issued after the next stage's barrier, interleaved with its first reads (a stage's first
-// fragment would otherwise be waited for by both waves of a SIMD at once, MFMA pipe idle).
-// (Also measured, round 3, and removed again: a 2-D wave tiling -- a wave = 2 row-blocks x <= 6 col-blocks, 16 fragment reads per
-// 24 MFMAs instead of 26 -- parity-green and exactly as fast (pass 2 4.18-4.21 ms either way): LDS read traffic is not what the
-// kernel's power budget goes to.  profiles/r03_pass2_experiments.txt, section 13.)
+// Tile (round 3): a block tile is 256 vectors x <= 384 queries (12 col-blocks) and a WAVE owns one 32-vector row-block x ALL
+// the tile's col-blocks (12 x 16 = 192 accumulator registers): a bucket chunk is one tile whenever <= 384 queries are routed to
+// the bucket, every wave does the same work for any number of col-blocks, and a 32-deep stage carries 2 NCB MFMAs per wave.
+//
+// Operand paths (round 4).  A wave's vector fragments are PRIVATE to it (its row-block x the stage's two k-groups = 2 KiB), so
+// they need neither LDS nor a barrier: every wave loads them with two global_load_dwordx4 straight into registers, two stages
+// ahead, into one of three 8-register sets, and waits for them with a counted vmcnt.  hipcc cannot express a load that stays
+// in flight into registers it allocates (round 3, profiles/r03_pass2_experiments.txt section 21: tied waits are preceded by
+// copies, untied ones let the allocator reuse the registers, visible loads are waited for with vmcnt(0)), so the sets live in
+// v[232:255], which the kernel RESERVES from the compiler: __attribute__((amdgpu_num_vgpr(116))) -- the attribute counts the
+// VGPR and AGPR halves of gfx90a+'s unified file, 116 -> hipcc allocates v0..v231 only (it spills rather than touch the rest;
+// round 3 passed the full count, which the backend rejects as over the occupancy limit and silently ignores).  The loads and
+// the MFMAs that read the sets are inline asm naming those registers; everything else is ordinary HIP.
+// The query fragments are shared by the 8 waves and re-streamed (from L2: the XCD-affine queues keep a bucket's tiles on one
+// XCD) for every 256 vectors: LDS ring of three 24-KiB stages filled by LDS-DMA from the younger half of the block, read with
+// ds_read_b128 D fragments ahead of the MFMAs as ONE stream that continues across the stage barrier (the last D MFMAs of a
+// stage are issued after the next stage's barrier, interleaved with its first reads).
+// (Why not everything through LDS-DMA as in round 3: tools/micro/stream_paths.hip / profiles/r04_pass2_experiments.txt -- the
+// two streams overlap either way once the query tiles are L2-resident; what the register path removes is 16 of the loader
+// waves' 16 + 2 NCB pieces per stage, the vector fragments' LDS reads, and 48 KiB of ring that a deeper query ring can use.)
 // Pass 1 (SAMPLE) = the same tile on sampled tiles only; one item per (bucket, query tile, sampled tile); per lane and
 // col-block the MAXIMUM of its 16 scores is all it keeps: the slot maxima of a column come from disjoint rows, so the 10th
 // largest of them is the 10th best of a subset of the bucket = a valid lower bound of That (lmi_prefilter.h, header).
@@ -32,14 +32,26 @@ namespace lmi {
 
 constexpr int P2_G = 2;                                                  // k16-groups per stage (32 k)
 constexpr int P2_MAXCB = 12;                                             // col-blocks per tile
-constexpr int P2_WAVES = 8;
-constexpr int P2_TILE_RB = P2_WAVES;                                     // row-blocks per tile (256 vectors)
+// Waves per block = row-blocks per BLOCK tile.  8: one block per CU (both waves of a SIMD belong to it and meet at its stage barrier);
+// 4: two blocks per CU, a SIMD hosts one wave of each -- what one block loses at its stage barrier or in its epilogue the other can
+// use, at the price of every query fragment staged once per block, i.e. twice per CU (profiles/r04_pass2_experiments.txt).
+#ifndef LMI_P2_WAVES
+#define LMI_P2_WAVES 8
+#endif
+constexpr int P2_WAVES = LMI_P2_WAVES;
+static_assert(P2_WAVES == 4 || P2_WAVES == 8, "");
+constexpr int P2_BLOCKS_PER_CU = 8 / P2_WAVES;
+constexpr int P2_TILE_RB = 8;                                            // row-blocks per sampled tile / chunk granule (256 vectors)
 constexpr int P2_TILE_ROWS = 32 * P2_TILE_RB;
-constexpr int P2_A_BYTES = P2_WAVES * P2_G * 1024;                       // 16 KiB: the stage's vector fragments
-constexpr int P2_SLOT_BYTES = P2_A_BYTES + P2_MAXCB * P2_G * 1024;       // 40 KiB per ring slot
+constexpr int P2_SLOT_BYTES = P2_MAXCB * P2_G * 1024;                    // 24 KiB per ring slot: the stage's query fragments
 constexpr int P2_RING = 3;
 constexpr int P2_NSL = 16;   // pass 1: lists per column (sampled tile j -> list j % P2_NSL), each 16 slot maxima
 constexpr int P2_LIST = 64 + 1;
+// The vector-fragment register sets: v[P2_AREG0 + 8 s + 4 g .. + 3] = k-group g of the stage in ring slot s.  hipcc is kept
+// below P2_AREG0 by the kernels' amdgpu_num_vgpr attribute (= P2_AREG0 / 2: the attribute is per register-file half).
+constexpr int P2_AREG0 = 232;
+#define LMI_P2_NUM_VGPR_ATTR 116
+static_assert(2 * LMI_P2_NUM_VGPR_ATTR == P2_AREG0 && P2_AREG0 + 8 * P2_RING == 256, "three 8-register sets at the top of the file");
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));   // asm operands must be vector types, not HIP's uint2 / uint4 structs
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -78,22 +90,21 @@ template <int NCB, bool SAMPLE>
 struct Tile2 {
     static constexpr int G = P2_G;
     static constexpr int Q = G * NCB;                       // B fragments = MFMAs per stage and wave
-    static constexpr int BR = 6;                            // B-fragment register ring: fragment q of the stage in ring slot s sits in
-                                                            // register (s Q + q) mod 6 -- 3 Q = 6 NCB is a multiple of 6, so the numbering
-                                                            // runs on through the three unrolled stages and closes at the loop's back edge
+#ifndef LMI_P2_BR
+#define LMI_P2_BR 3
+#endif
+    static constexpr int BR = LMI_P2_BR;                    // B-fragment register ring: fragment q of the stage in ring slot s sits in
+                                                            // register (s Q + q) mod BR -- 3 Q = 6 NCB is a multiple of 3 and of 6, so the
+                                                            // numbering runs on through the three unrolled stages and closes at the back edge
+    static_assert(BR == 3 || BR == 6, "3 Q must be a multiple of BR for every NCB");
     static constexpr int D = NCB < BR - 1 ? NCB : BR - 1;   // read-ahead (fragments); the last D MFMAs of a stage are deferred
-    // LDS-DMA is issued by the YOUNGER half of the block only (waves 4..7: "loaders").  The two waves of a SIMD run a stage one
-    // after the other (the matrix pipe goes to the older wave until it has issued all of its MFMAs: stamps, profiles/r03_*), so
-    // a piece issued by the older wave (~50 cycles each, in order with its MFMAs) stalls the pipe, while the younger wave issues
-    // the whole stage's pieces at the stage's start, in the shadow of its partner's MFMAs.  Loader lw = w - 4 stages
-    // row-blocks lw, lw + 4 (both k-groups) and its share of the query fragments (below).
-    // Query fragments: 2 NCB one-KiB pieces per stage; loader lw takes k-group lw & 1 of col-blocks (lw >> 1), + 2, + 4, ..: PBL =
-    // ceil(NCB / 2) pieces each (a loader past the tile's last col-block repeats it: 4 PBL - 2 NCB is 0 or 2 pieces, where whole
-    // col-blocks per loader -- 2 / 4 / 6 pieces -- issued up to 6 too many; a piece costs the CU ~60 cycles of its LDS-DMA path,
-    // profiles/r03_pass2_experiments.txt section 20).
+    // LDS-DMA (query fragments only) is issued by the YOUNGER half of the block (waves 4..7: "loaders"): the two waves of a SIMD
+    // run a stage one after the other (the matrix pipe goes to the older wave until it has issued all of its MFMAs: stamps,
+    // profiles/r03_*), so the younger wave issues the stage's pieces at its start, in the shadow of its partner's MFMAs.
+    // 2 NCB one-KiB pieces per stage; loader lw takes k-group lw & 1 of col-blocks (lw >> 1), + 2, + 4, ..: PBL = ceil(NCB / 2)
+    // pieces each (a loader past the tile's last col-block repeats it: 4 PBL - 2 NCB is 0 or 2 pieces).
     static constexpr int PBL = (NCB + 1) / 2;
-    static constexpr int PW = 2 * G + PBL;                  // pieces per loader wave and stage (constant: the vmcnt literal)
-    static constexpr int QA = NCB > D + 1 ? NCB - D - 1 : 0;  // A fragment of k-group 1 is requested after MFMA QA
+    static constexpr int PA = G;                            // vector-fragment loads per wave and stage (one per k-group)
     static_assert(G == 2, "written out for two k-groups per stage");
 
     const PrefilterParams& P;
@@ -103,9 +114,9 @@ struct Tile2 {
     float* sThr;         // [P2_MAXCB * 32] emission thresholds of the tile's columns (pass 2)
     uint4* sPend;        // [8 waves][64] (column, row, score) of the candidate whose position atomic is in flight (pass 2)
     int lane, w;
-    unsigned lds_lane;   // ring + lane * 16
+    unsigned lds_lane;   // ring + lane * 16: the lane's LDS read address AND its byte offset in the vector loads (whose SGPR base has
+                         // `ring` subtracted): one register for both
     f32x16 acc[NCB];
-    half8 a[2];          // vector fragment of k-group 0 / 1
     half8 b[BR];         // query-fragment ring
     unsigned pend_pos;
 #ifdef LMI_P2_STAMPS
@@ -113,14 +124,13 @@ struct Tile2 {
 #endif
 
     static constexpr int breg(int slot, int q) { return (slot * Q + q) % BR; }
-    // LDS reads issued after B(q)'s and before MFMA q waits for it: the younger B fragments + k-group 1's A fragment
+    static constexpr int areg(int set, int g) { return P2_AREG0 + 8 * set + 4 * g; }
+    // LDS reads issued after B(q)'s and before MFMA q waits for it: the younger B fragments
     static constexpr int younger(int q) {
 #if defined(LMI_ABL_NOLDSB) || defined(LMI_ABL_NOLGKM) || defined(LMI_ABL_NOLDS)
         return 15;   // timing-only ablations: never wait for a fragment
 #endif
-        int nb = (q + D - 1 < Q - 1 ? q + D - 1 : Q - 1) - q;
-        if (q >= QA + 1 && q <= QA + D - 1) nb += 1;
-        return nb;
+        return (q + D - 1 < Q - 1 ? q + D - 1 : Q - 1) - q;
     }
 
     template <int OFF>
@@ -128,31 +138,24 @@ struct Tile2 {
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
     }
     template <int N>
-    static __device__ __forceinline__ void lgkm_wait(half8& x, half8& y) {
-        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(y) : "n"(N) : "memory");
+    static __device__ __forceinline__ void lgkm_wait(half8& y) {
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(y) : "n"(N) : "memory");
     }
 
+    // The MFMAs read their vector fragment from the reserved set by NAME (hipcc knows nothing of v[232:255]); being volatile asm
+    // they keep their program order against the fragment reads, the waits and the loads.  Consecutive MFMAs go to different
+    // accumulators (or chain C -> D on the same one): no wait states needed between them; the tile's epilogue is preceded by
+    // the states an MFMA result needs before a VALU read (end of run()'s K loop).
     template <int SLOT, int QI>
     __device__ __forceinline__ void mfma_q() {
-        constexpr int g = QI / NCB, n = QI % NCB;
-#ifdef LMI_ABL_MFMA16   // timing-only ablation: the same flops and operand registers issued as two v_mfma_f32_16x16x32_f16 (garbage results)
-        typedef float f32x4v __attribute__((ext_vector_type(4)));
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            f32x4v c = {acc[n][8 * g + 4 * i], acc[n][8 * g + 4 * i + 1], acc[n][8 * g + 4 * i + 2], acc[n][8 * g + 4 * i + 3]};
-            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[g], b[breg(SLOT, QI)], c, 0, 0, 0);
-            acc[n][8 * g + 4 * i] = c[0]; acc[n][8 * g + 4 * i + 1] = c[1]; acc[n][8 * g + 4 * i + 2] = c[2]; acc[n][8 * g + 4 * i + 3] = c[3];
-        }
-        return;
-#endif
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[g], b[breg(SLOT, QI)], acc[n], 0, 0, 0);
+        constexpr int g = QI / NCB, n = QI % NCB, R = areg(SLOT, g);
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, v[%c2:%c3], %1, %0" : "+v"(acc[n]) : "v"(b[breg(SLOT, QI)]), "n"(R), "n"(R + 3));
     }
     // the tile's first k-group starts the accumulators at 0 (srcC = the inline constant: no clearing pass, no zero registers)
     template <int SLOT, int QI>
     __device__ __forceinline__ void mfma_q0() {
-        constexpr int n = QI % NCB;
-        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[breg(SLOT, QI)], zero, 0, 0, 0);
+        constexpr int n = QI % NCB, R = areg(SLOT, 0);
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, v[%c2:%c3], %1, 0" : "=&v"(acc[n]) : "v"(b[breg(SLOT, QI)]), "n"(R), "n"(R + 3));
     }
     template <int SLOT, int QI>
     __device__ __forceinline__ void read_b() {  // query fragment QI of the stage in ring slot SLOT
@@ -163,77 +166,69 @@ struct Tile2 {
 #ifdef LMI_ABL_NOLDS    // timing-only ablation: no fragment reads at all
         asm volatile("" : "+v"(b[breg(SLOT, QI)])); return;
 #endif
-        lds_rd<P2_A_BYTES + (n * G + g) * 1024>(b[breg(SLOT, QI)], lds_lane + SLOT * P2_SLOT_BYTES);
-    }
-    template <int SLOT, int GI>
-    __device__ __forceinline__ void read_a() {
-#ifdef LMI_ABL_NOLDS
-        asm volatile("" : "+v"(a[GI])); return;
-#endif
-        lds_rd<GI * 1024>(a[GI], lds_lane + SLOT * P2_SLOT_BYTES + (unsigned)w * (G * 1024));
+        lds_rd<(n * G + g) * 1024>(b[breg(SLOT, QI)], lds_lane + SLOT * P2_SLOT_BYTES);
     }
 
-#ifndef LMI_P2_LOADER_OLD
-#define LMI_P2_LOADER_OLD 0   // 1 (A/B): the OLDER half (waves 0..3) issues the LDS-DMA instead
-#endif
-    __device__ __forceinline__ bool is_loader() const { return LMI_P2_LOADER_OLD ? w < 4 : w >= 4; }
-    struct Stream {        // wave-uniform source pointers of the NEXT stage to load (loaders)
-        const uint4* a0;   // row-block lw of the tile, k-group pair t
-        const uint4* a1;   // row-block lw + 4
-        const uint4* b0;   // the tile's first col-block, k-group pair t
+    __device__ __forceinline__ bool is_loader() const { return P2_WAVES == 4 ? true : w >= 4; }
+    struct Stream {        // wave-uniform source pointers of the NEXT stage to load
+        const char* a;     // the wave's row-block of the tile, k-group pair t, MINUS `ring` (the lane offset register is lds_lane)
+        const uint4* b0;   // the tile's first col-block, k-group pair t (loaders)
         int bo[PBL];       // offsets (uint4) of this loader's pieces from b0: k-group lw & 1 of col-blocks (lw >> 1) + 2 j (clamped)
     };
+    // this wave's vector fragments of the stage S points at -> register set SET (both k-groups; 1 KiB apart in the slab).
+    // The leading s_nop: the SGPR base may come fresh from a v_readlane (an SGPR spill reload) -- VALU-written SGPR -> VMEM
+    // address needs 5 wait states and hipcc pads nothing in front of an asm statement's contents.
+    template <int SET>
+    __device__ __forceinline__ void load_a(const Stream& S) {
+#ifdef LMI_ABL_NOLOAD
+        return;
+#endif
+        constexpr int R = areg(SET, 0);
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 v[%c2:%c3], %0, %1\n\tglobal_load_dwordx4 v[%c4:%c5], %0, %1 offset:1024"
+                     :: "v"(lds_lane), "s"(S.a), "n"(R), "n"(R + 3), "n"(R + 4), "n"(R + 7) : "memory");
+    }
     template <int DST>
-    __device__ __forceinline__ void dma_all(const Stream& S) {
+    __device__ __forceinline__ void dma_b(const Stream& S) {   // loaders: their pieces of the stage S points at -> ring slot DST
 #ifdef LMI_ABL_NOLOAD
         return;
 #endif
         uint4* slot = ring_p + DST * (P2_SLOT_BYTES / 16);
         const int lw = w & 3;
-        glds16o<0, LMI_PF_A_AUX>(reinterpret_cast<const float4*>(S.a0 + lane), reinterpret_cast<float4*>(slot + lw * (G * 64)));
-        glds16o<1024, LMI_PF_A_AUX>(reinterpret_cast<const float4*>(S.a0 + lane), reinterpret_cast<float4*>(slot + lw * (G * 64)));
-        glds16o<0, LMI_PF_A_AUX>(reinterpret_cast<const float4*>(S.a1 + lane), reinterpret_cast<float4*>(slot + (lw + 4) * (G * 64)));
-        glds16o<1024, LMI_PF_A_AUX>(reinterpret_cast<const float4*>(S.a1 + lane), reinterpret_cast<float4*>(slot + (lw + 4) * (G * 64)));
         static_for<0, PBL>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             const int cb = min((lw >> 1) + 2 * j, NCB - 1);
-            glds16(reinterpret_cast<const float4*>(S.b0 + S.bo[j] + lane), reinterpret_cast<float4*>(slot + P2_A_BYTES / 16 + (cb * G + (lw & 1)) * 64));
+            glds16(reinterpret_cast<const float4*>(S.b0 + S.bo[j] + lane), reinterpret_cast<float4*>(slot + (cb * G + (lw & 1)) * 64));
         });
     }
 
-    // One stage: ring slot SLOT computes, the pieces of stage (+2) go to slot DST.  `pend`: the previous stage left its last
-    // D MFMAs (operands in a[1], b[]) to be issued here; `last`: this stage issues all of its own (tile end / dead stage next).
-    // (Tried and dropped, profiles/r03_pass2_experiments.txt: an LDS counter with split arrive / wait instead of s_barrier, so
-    // that the last arriver never stalls -- the polling waves' detection latency cost more than the barrier's round trip:
-    // K loop of a tile 43.9 k -> 55.4 k cycles.)
+    // One stage: ring slot / register set SLOT computes, stage (+2) is requested into slot / set DST.  `pend`: the previous
+    // stage left its last D MFMAs (they read set DST's k-group 1 and the b[] ring) to be issued here -- the vector loads into
+    // DST follow them; `last`: this stage issues all of its own (tile end / dead stage next).
     template <int SLOT, int DST>
     __device__ __forceinline__ void stage(const Stream& S, bool loader, bool pend, bool last, bool first) {
         constexpr int PS = (SLOT + P2_RING - 1) % P2_RING;   // the previous stage's slot: its fragments' register numbering
-        if (loader) dma_all<DST>(S);
-        read_a<SLOT, 0>();
+        static_assert(PS == DST, "ring of three: the stage two ahead reuses the previous stage's slot");
+        if (loader) dma_b<DST>(S);
         static_for<0, D>([&](auto i) {
             constexpr int I = decltype(i)::value;
             if (pend) mfma_q<PS, Q - D + I>();
             read_b<SLOT, I>();
         });
-        __builtin_amdgcn_sched_barrier(0);
+        load_a<DST>(S);
         static_for<0, Q - D>([&](auto qi) {
             constexpr int q = decltype(qi)::value;
-            lgkm_wait<younger(q)>(a[q / NCB], b[breg(SLOT, q)]);
+            lgkm_wait<younger(q)>(b[breg(SLOT, q)]);
             if constexpr (SLOT == 0 && q < NCB) {
                 if (first) mfma_q0<SLOT, q>(); else mfma_q<SLOT, q>();
             } else {
                 mfma_q<SLOT, q>();
             }
-            if constexpr (q == QA) read_a<SLOT, 1>();
             read_b<SLOT, q + D>();
-            __builtin_amdgcn_sched_barrier(0);
         });
-        if constexpr (QA >= Q - D) read_a<SLOT, 1>();  // tiny tiles: the steady loop above is shorter than QA
         if (last) {
             static_for<Q - D, Q>([&](auto qi) {
                 constexpr int q = decltype(qi)::value;
-                lgkm_wait<0>(a[q / NCB], b[breg(SLOT, q)]);
+                lgkm_wait<0>(b[breg(SLOT, q)]);
                 if constexpr (SLOT == 0 && q < NCB) {   // (one-stage tiles of one or two col-blocks)
                     if (first) mfma_q0<SLOT, q>(); else mfma_q<SLOT, q>();
                 } else {
@@ -251,15 +246,15 @@ struct Tile2 {
         asm volatile("" : "+v"(z));
         return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
     }
-    // A candidate's position atomic (previous tile) is OLDER than every LDS-DMA piece of the tile that has run since (24
-    // stages x PW pieces): once at most the two stages in flight are outstanding it has returned.  Written as asm so that
+    // A candidate's position atomic (previous tile) is OLDER than every load of the tile that has run since (24 stages x
+    // (PA [+ PBL]) requests): once at most the two stages in flight are outstanding it has returned.  Written as asm so that
     // hipcc does not put `s_waitcnt vmcnt(0)` in front of the first use.  Column, row and score of that candidate wait in
     // the wave's LDS table (entry = lane), not in registers; LDS is touched by asm only (hipcc orders every LDS access it
     // sees behind ALL pending LDS-DMA).
     __device__ __forceinline__ void flush_pending(int ln) {
-        // (a wave that loads nothing has only its own candidate traffic outstanding: it waits for all of it)
-        if (is_loader()) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(pend_pos) : "n"(2 * PW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(pend_pos) :: "memory");
+        // (two stages of the next tile are in flight: 2 PA vector loads, the loaders' 2 PBL pieces on top)
+        if (is_loader()) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(pend_pos) : "n"(2 * (PA + PBL)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(pend_pos) : "n"(2 * PA) : "memory");
         if (pend_pos < (unsigned)PF_CAP) {
             u32x4 e;
             const unsigned pa = (unsigned)reinterpret_cast<uintptr_t>(sPend + w * 64) + (unsigned)ln * 16u;
@@ -381,7 +376,7 @@ struct Tile2 {
     }
 
     // pass 1: per lane and col-block the maximum of its 16 scores -> bound[col][list][w * 2 + h]
-    __device__ __forceinline__ void epilogue_sample(int rb_tile0, int n_b, size_t col0, int m_left, int list_j, bool use_atomic) {
+    __device__ __forceinline__ void epilogue_sample(int rb_tile0, int n_b, size_t col0, int m_left, int list_j, bool use_atomic, int rb_in_tile) {
         const int ln = lane_id();
         const int h = ln >> 5, c = ln & 31;
         const unsigned row0 = (unsigned)((rb_tile0 + w) * 32);
@@ -407,7 +402,7 @@ struct Tile2 {
             const float mx = m0;
             if (n * 32 + c < m_left) {
                 // lists are COLUMN-minor: [list][slot = w * 2 + h][column] -- a wave's store is two runs of 32 consecutive floats
-                float* dst = P.bound + ((size_t)(list_j * 16 + w * 2 + h)) * (size_t)P.ncols + (col0 + n * 32 + c);
+                float* dst = P.bound + ((size_t)(list_j * 16 + (rb_in_tile + w) * 2 + h)) * (size_t)P.ncols + (col0 + n * 32 + c);
                 if (!use_atomic) *dst = mx;
                 else {  // more sampled tiles than lists: monotone float max through the order-preserving integer image
                     if (mx >= 0.0f) atomicMax(reinterpret_cast<int*>(dst), __float_as_int(mx));
@@ -419,7 +414,11 @@ struct Tile2 {
 
     // The tile = col-blocks [cbt0, cbt0 + NCB) of bucket b.  !SAMPLE: `ch` = chunk of the bucket, every tile of it;
     // SAMPLE: `ch` = sampled tile j of the bucket (tile j * stride), one tile.
-    __device__ __forceinline__ void run(int b, int cbt0, int ch, int m_use) {
+    __device__ __forceinline__ void run(int b_, int cbt0_, int ch_, int m_use_) {
+        // the item came through LDS (s_item): tell the compiler it is wave-uniform, so that every address derived from it is
+        // scalar (the vector loads take their base as an "s" operand)
+        const int b = __builtin_amdgcn_readfirstlane(b_), cbt0 = __builtin_amdgcn_readfirstlane(cbt0_);
+        const int ch = __builtin_amdgcn_readfirstlane(ch_), m_use = __builtin_amdgcn_readfirstlane(m_use_);
 #ifdef LMI_P2_STAMPS
         for (int i = 0; i < 12; ++i) st_acc[i] = 0;
         st_last = __builtin_readcyclecounter();
@@ -434,7 +433,7 @@ struct Tile2 {
         const int stride = SAMPLE ? sample_stride(n_b) : 1;
         const int rb0 = SAMPLE ? ch * stride * P2_TILE_RB : ch * P.chunk_rb;
         const int nrb_all = SAMPLE ? min(P2_TILE_RB, nrb_b - rb0) : min(P.chunk_rb, nrb_b - rb0);
-        const int nvt = (nrb_all + P2_TILE_RB - 1) / P2_TILE_RB;
+        const int nvt = (nrb_all + P2_WAVES - 1) / P2_WAVES;   // block tiles of P2_WAVES row-blocks
         const int cb_tile = P.cb_start[b] + cbt0;
         const int m_left = m_use - cbt0 * 32;   // live columns of the tile from its first one (pass 1: m or m0, see the kernel)
         const size_t col0 = (size_t)cb_tile * 32;
@@ -454,29 +453,36 @@ struct Tile2 {
         pend_pos = 0xffffffffu;
         int vt_n = 0, t_n = 0;
         Stream S;
-        S.a0 = aslab + (size_t)min(rb0 + lw, rb_last) * rb_stride;
-        S.a1 = aslab + (size_t)min(rb0 + lw + 4, rb_last) * rb_stride;
+        // the wave's own row-block of the tile (rows past the bucket's end: the last row-block again, masked in the epilogues)
+        const char* abase = reinterpret_cast<const char*>(aslab) - ring;
+        S.a = abase + ((size_t)min(rb0 + w, rb_last) * rb_stride) * 16;
         S.b0 = bbase0;
 #pragma unroll
         for (int j = 0; j < PBL; ++j) S.bo[j] = (min((lw >> 1) + 2 * j, NCB - 1) * KG + (lw & 1)) * 64;
         const int NSR = (NS + P2_RING - 1) / P2_RING * P2_RING;
 #define P2_ADVANCE                                                                               \
-        if (++t_n < NS) { S.a0 += G * 64; S.a1 += G * 64; S.b0 += G * 64; }                      \
+        if (++t_n < NS) { S.a += G * 1024; S.b0 += G * 64; }                                     \
         else if (t_n == NSR) {                                                                   \
             t_n = 0;                                                                             \
             if (vt_n + 1 < nvt) {                                                                \
                 ++vt_n; S.b0 = bbase0;                                                           \
-                S.a0 = aslab + (size_t)min(rb0 + vt_n * P2_TILE_RB + lw, rb_last) * rb_stride;   \
-                S.a1 = aslab + (size_t)min(rb0 + vt_n * P2_TILE_RB + lw + 4, rb_last) * rb_stride; \
+                S.a = abase + ((size_t)min(rb0 + vt_n * P2_WAVES + w, rb_last) * rb_stride) * 16;   \
             }                                                                                    \
         }
+        // stage u's requests are older than stage u + 1's PA (+ PBL) requests: all but those have landed
 #ifdef LMI_ABL_NOWAIT
 #define P2_WAIT_LANDED
+#elif defined(LMI_DBG_VM0)
+#define P2_WAIT_LANDED asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
-#define P2_WAIT_LANDED asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PW) : "memory");
+#define P2_WAIT_LANDED if (loader) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PA + PBL) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PA) : "memory");
 #endif
-#ifdef LMI_ABL_NOBAR
+#if defined(LMI_ABL_NOBAR) && defined(LMI_ABL_NOBARLGKM)   // timing-only ablations (garbage results)
+#define P2_BARRIER
+#elif defined(LMI_ABL_NOBAR)
 #define P2_BARRIER asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#elif defined(LMI_ABL_NOBARLGKM)
+#define P2_BARRIER __builtin_amdgcn_s_barrier();
 #else
 #define P2_BARRIER asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier();
 #endif
@@ -489,15 +495,18 @@ struct Tile2 {
             stage<SLOT, (SLOT + P2_RING - 1) % P2_RING>(S, loader, pend, (LAST), SLOT == 0 && t == 0); \
             pend = !(LAST);                                                                      \
         } else {                                                                                 \
-            if (loader) dma_all<(SLOT + P2_RING - 1) % P2_RING>(S);                              \
+            if (loader) dma_b<(SLOT + P2_RING - 1) % P2_RING>(S);                                \
+            load_a<(SLOT + P2_RING - 1) % P2_RING>(S);                                           \
         }                                                                                        \
         P2_ADVANCE                                                                               \
         P2_STAMP_FINE(2)
         P2_STAMP(4)
         if (nvt > 0) {
-            if (loader) dma_all<0>(S);
+            if (loader) dma_b<0>(S);
+            load_a<0>(S);
             P2_ADVANCE
-            if (loader) dma_all<1>(S);
+            if (loader) dma_b<1>(S);
+            load_a<1>(S);
             P2_ADVANCE
         }
         for (int vt = 0; vt < nvt; ++vt) {
@@ -507,9 +516,11 @@ struct Tile2 {
                 P2_STEP(1, t + 1 < NS, t + 2 >= NS)
                 P2_STEP(2, t + 2 < NS, t + 3 >= NS)
             }
+            // an MFMA's result needs 18 wait states before a VALU reads it (16-pass worst case); hipcc pads nothing behind asm
+            asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
             P2_STAMP(2)   // (coarse builds: the whole K loop of the tile, waits and barriers included)
-            if (SAMPLE) epilogue_sample(rb0 + vt * P2_TILE_RB, n_b, col0, m_left, ch % P2_NSL, ch >= P2_NSL);
-            else epilogue_emit(rb0 + vt * P2_TILE_RB, n_b, col0);
+            if (SAMPLE) epilogue_sample(rb0 + vt * P2_WAVES, n_b, col0, m_left, ch % P2_NSL, ch >= P2_NSL, vt * P2_WAVES);
+            else epilogue_emit(rb0 + vt * P2_WAVES, n_b, col0);
             P2_STAMP(3)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the look-ahead before the LDS is reused
@@ -667,11 +678,12 @@ __device__ __forceinline__ bool p2_pop_item(const PrefilterParams& P, int& grp, 
 // the atomic's round trip hides behind the item (costs a live register across the item: not for pass2_kernel's K loop).
 // Once the own group is used up the block falls back to p2_pop_item's walk over the other groups (the tail of the launch).
 constexpr int P2_PREFIX_CAP = 1025;   // buckets + 1 of a group held in LDS (more: the global prefix is searched)
-template <bool SAMPLE, bool PREFETCH, int NTHREADS>
+constexpr int P2_PREFIX_CAP_K = P2_WAVES == 4 ? 116 : P2_PREFIX_CAP;   // pass2_kernel at two blocks per CU: 80 KiB of LDS per block, to the byte
+template <bool SAMPLE, bool PREFETCH, int NTHREADS, int PREFIX_CAP = P2_PREFIX_CAP>
 struct P2Queue {
     const PrefilterParams& P;
     int* s_item;     // [2] LDS
-    int* s_prefix;   // [P2_PREFIX_CAP] LDS
+    int* s_prefix;   // [PREFIX_CAP] LDS
     int grp, own, own_tot, own_n, ticket;
     const int* own_base;
     unsigned* own_head;
@@ -683,7 +695,7 @@ struct P2Queue {
         own_tot = (SAMPLE ? P.grp_total1 : P.grp_total)[own];
         own_n = P.grp_n[own];
         own_base = (SAMPLE ? P.grp_base1 : P.grp_base) + own * (P.L + 1);
-        prefix_lds = own_n + 1 <= P2_PREFIX_CAP;
+        prefix_lds = own_n + 1 <= PREFIX_CAP;
         if (prefix_lds)
             for (int i = threadIdx.x; i <= own_n; i += NTHREADS) s_prefix[i] = own_base[i];
         own_live = own_tot > 0 && !(!SAMPLE && P.redo_bucket);   // (the redo launch skips buckets: it keeps to the plain pop)
@@ -723,15 +735,20 @@ struct P2Queue {
 };
 
 template <bool SAMPLE>
-__global__ __launch_bounds__(64 * P2_WAVES, 1) void pass2_kernel(PrefilterParams P) {
+__global__ __launch_bounds__(64 * P2_WAVES, 2) __attribute__((amdgpu_num_vgpr(LMI_P2_NUM_VGPR_ATTR))) void pass2_kernel(PrefilterParams P) {
+    // v[232:255] are reserved from the compiler (file header); naming the last one makes the kernel descriptor allocate all 256
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    asm volatile("" ::: "v255");
+#pragma clang diagnostic pop
     __shared__ __attribute__((aligned(16))) uint4 ring[P2_RING * P2_SLOT_BYTES / 16];
     __shared__ uint2 sList[SAMPLE ? 1 : P2_WAVES * P2_LIST];
     __shared__ float sThr[SAMPLE ? 1 : P2_MAXCB * 32];
     __shared__ __attribute__((aligned(16))) uint4 sPend[SAMPLE ? 1 : P2_WAVES * 64];
     __shared__ int s_item[2];
-    __shared__ int s_prefix[P2_PREFIX_CAP];
+    __shared__ int s_prefix[P2_PREFIX_CAP_K];
     if (!SAMPLE && P.redo_count && *P.redo_count == 0u) return;  // the redo launch of a batch without overflowed columns
-    P2Queue<SAMPLE, false, 64 * P2_WAVES> queue{P, s_item, s_prefix};
+    P2Queue<SAMPLE, false, 64 * P2_WAVES, P2_PREFIX_CAP_K> queue{P, s_item, s_prefix};
     queue.init();
     P2Item item;
     while (queue.next(item)) {
