@@ -46,18 +46,16 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def lib_source_sha16() -> str:
-    """sha256 over the library's sources (csrc/*.h, *.hip, include/*.h): ties a PMC summary under profiles/ to the kernels
-    it was collected from (profiles/summarize.py stamps the same value into the summary)."""
-    import glob
-    import hashlib
+def lib_provenance() -> dict:
+    """Which library this process LOADED: path, sha256/16 of the .so file, the source hash baked into it at build time
+    (lmi_build_info) and the hash of the sources in the working tree.  PMC summaries under profiles/ carry the same fields
+    (profiles/summarize.py copies them from the bench line of the profiled run) and are replayed only when they match."""
+    from learnedmetricindex_amd import _capi, _srchash
 
-    hsh = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "learnedmetricindex_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "learnedmetricindex_amd", "csrc", "*.hip"))
-                    + glob.glob(os.path.join(ROOT, "include", "*.h"))):
-        hsh.update(os.path.basename(f).encode())
-        hsh.update(open(f, "rb").read())
-    return hsh.hexdigest()[:16]
+    info = _capi.lib().lmi_build_info().decode()
+    built = dict(kv.split("=", 1) for kv in info.split() if "=" in kv)
+    return {"path": os.path.relpath(_capi.LIB_PATH, ROOT), "so_sha16": _srchash.file_sha16(_capi.LIB_PATH),
+            "built_from_source_sha16": built.get("src"), "tree_source_sha16": _srchash.source_sha16(ROOT), "build_info": info}
 
 
 class Workload:
@@ -66,7 +64,7 @@ class Workload:
     generator), `zipf` > 0 draws the cluster of an object with probability ~ 1/(1 + c/zipf) (heavy-tailed
     bucket sizes), `centre_scale` < 1 pulls the centres together (overlapping clusters)."""
 
-    def __init__(self, args, cfg, dev, rank, world, local_rank, sigma=1.0, zipf=0.0, centre_scale=1.0, tag="main"):
+    def __init__(self, args, cfg, dev, rank, world, local_rank, sigma=1.0, zipf=0.0, centre_scale=1.0, tag="main", exact=None, layers=None, label=None):
         import torch
         import torch.distributed as dist
 
@@ -75,6 +73,7 @@ class Workload:
         from learnedmetricindex_amd.sharded import assign_buckets, estimate_bucket_work
 
         self.args, self.cfg, self.dev, self.rank, self.world, self.tag = args, cfg, dev, rank, world, tag
+        self.exact = args.exact if exact is None else exact   # all-f32 scan_kernel instead of fp16 prefilter + exact re-rank
         N, d, L, nb, nq = cfg["n"], cfg["d"], cfg["leaves"], cfg["nb"], cfg["nq"]
         t_setup = time.time()
         gcpu = torch.Generator().manual_seed(args.seed + (0 if tag == "main" else 7919))
@@ -99,7 +98,9 @@ class Workload:
 
         # ---- MLP: k-means labels -> Adam/CE (the reference's hyper-parameters: 200 epochs, lr 0.01)
         net = NeuralNetwork(input_dim=d, output_dim=L, lr=0.01, model_type=cfg["model"])
-        if rank == 0:
+        if layers is not None:   # a second index over the same data with the weights of the first (the exact leg)
+            pass
+        elif rank == 0:
             torch.manual_seed(args.seed)
             ntr = min(args.train_rows, N)
             xtr = torch.cat([gen_rows(1, p, n) for p, n in pieces[: (ntr + CHUNK - 1) // CHUNK]])[:ntr]
@@ -111,13 +112,13 @@ class Workload:
             lab = (xtr @ cent.T).argmax(1)
             net.train(xtr, lab, epochs=args.epochs)
             del xtr, lab, cent
-        if world > 1:
+        if world > 1 and layers is None:
             for p_ in net.model.parameters():
                 dist.broadcast(p_.data, src=0)
-        self.layers = linear_layers(net.model)
+        self.layers = layers if layers is not None else linear_layers(net.model)
 
         # ---- placement: argmax MLP(x) over all N (LearnedIndexBuilder.py:76) with the HIP MLP kernels
-        eng = _capi.Index(local_rank, chunk_rows=args.chunk_rows, prefilter=not args.exact)
+        eng = _capi.Index(local_rank, chunk_rows=args.chunk_rows, prefilter=not self.exact)
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
         eng.set_mlp(self.layers)
         eng.set_timing(args.timing_level)
@@ -159,7 +160,7 @@ class Workload:
         torch.cuda.empty_cache()
         self.eng = eng
         if rank == 0:
-            log(f"[bench:{tag}] index built in {time.time() - t_setup:.1f}s: N={N} d={d} L={L} bucket sizes "
+            log(f"[bench:{label or tag}] index built in {time.time() - t_setup:.1f}s: N={N} d={d} L={L} bucket sizes "
                 f"min/median/max = {sizes.min()}/{int(np.median(sizes))}/{sizes.max()}, empty={int((sizes == 0).sum())}")
 
     # ------------------------------------------------------------------------------------------------
@@ -253,11 +254,11 @@ class Workload:
         res["scan_stats"] = eng.scan_stats()
         res["pf_stats"] = eng.prefilter_stats()
         try:   # candidates pass 2 emitted for the last batch (all columns)
-            res["pf_candidates"] = int(eng.debug_peek("cand_total", 8).view(np.uint64)[0]) if not self.args.exact else 0
+            res["pf_candidates"] = int(eng.debug_peek("cand_total", 8).view(np.uint64)[0]) if not self.exact else 0
         except Exception:  # noqa: BLE001
             res["pf_candidates"] = None
         try:   # columns whose candidate buffer overflowed in the last batch (they get a second run of pass 2)
-            res["pf_redo_columns"] = int(eng.debug_peek("pf_redo", 4).view(np.uint32)[0]) if not self.args.exact else 0
+            res["pf_redo_columns"] = int(eng.debug_peek("pf_redo", 4).view(np.uint32)[0]) if not self.exact else 0
         except Exception:  # noqa: BLE001
             res["pf_redo_columns"] = None
         return res
@@ -313,8 +314,10 @@ def oracle_check_sample(wl, res, args, ns, nthr):
     return round(ns / t_cpu, 3)
 
 
-def cpu_baselines(wl, res, args):
-    """rank 0, N = 1: the CPU restatements timed on this box's host cores, on the same index and queries."""
+def cpu_baselines(wl, res, args, reference_full=True, reference_sample=True, oracle_queries=None, ref_deadline_s=75.0):
+    """rank 0, N = 1: the CPU restatements timed on this box's host cores, on the same index and queries as the GPU leg
+    `wl` / `res`.  reference_full: the reference-structured pandas loop run IN FULL over the whole index (SURVEY 8d);
+    reference_sample: the same loop on a few whole buckets, scaled by rows (1 core; the cross-check of round 1-3)."""
     import torch
 
     from oracle import cpu_baseline as cb
@@ -323,12 +326,13 @@ def cpu_baselines(wl, res, args):
     eng, layers = wl.eng, wl.layers
     N, d, L, nb, nq, k = wl.cfg["n"], wl.cfg["d"], wl.cfg["leaves"], wl.cfg["nb"], wl.cfg["nq"], args.k
     host_cores = os.cpu_count() or 1
-    nthr = args.cpu_threads or min(16, host_cores)  # the GPU box's CPU share for one GPU is 16 cores
+    usable = cb.usable_cpus()
+    nthr = args.cpu_threads or min(16, usable)  # the GPU box's CPU share for one GPU is 16 cores (os.cpu_count() shows the host's 256)
     out_d, out_i, bo = res["out_d"], res["out_i"], res["bo"]
     variants = {}
 
     # ---- (0) the bit-exact checker: oracle/lmi_oracle.c on a query sample (canonical fmaf chains; slow by design)
-    ns = min(args.cpu_queries, nq)
+    ns = min(args.cpu_queries if oracle_queries is None else oracle_queries, nq)
     qh_all = wl.queries.cpu().numpy()
     qh = qh_all[:ns]
     t_cpu = time.perf_counter()
@@ -368,6 +372,7 @@ def cpu_baselines(wl, res, args):
     assert np.array_equal(fi, out_i[:ns]) and np.array_equal(fd, out_d[:ns].astype(np.float64)), \
         "CPU oracle and GPU results differ on the sampled queries"
     variants["oracle_checker"] = {"value": round(ns / t_cpu, 3), "unit": "queries/s", "cores": nthr, "queries": ns,
+                                  "identical_ids_and_distances": True,
                                   "what": "oracle/lmi_oracle.c: canonical k-ordered fmaf chains (bit-exact with the GPU, "
                                           "asserted); a checker, not a tuned CPU implementation"}
 
@@ -380,83 +385,108 @@ def cpu_baselines(wl, res, args):
         "id_set_agreement_with_gpu": round(cb.id_agreement(bi, out_i[:nq_b]), 6),
         "what": "bucket-contiguous slab in host memory, torch-CPU addmm/relu/topk routing, per visited bucket ONE "
                 "matmul for all its (query, rank) slots + topk(10), stable sort merge; full index, no pandas"}
+    # ---- (1b) the same arithmetic parallel over BUCKETS: one single-threaded product per worker thread
+    bd2, bi2, _, secs2 = cb.best_effort_bucket_parallel(slab, offsets, ids_all, layers, qt, nb, k, workers=nthr)
+    assert cb.id_agreement(bi2, bi) > 0.9999, "the two best-effort CPU variants disagree"
+    variants["best_effort_bucket_parallel"] = {
+        "value": round(nq_b / secs2, 2), "unit": "queries/s", "cores": nthr, "queries": nq_b, "seconds": round(secs2, 3),
+        "what": f"the best-effort variant with {nthr} worker threads each taking whole buckets (single-threaded matmul + topk per "
+                f"bucket) instead of {nthr} BLAS threads per product; same results (ids equal outside float32 near-ties)"}
+    del bd, bd2, bi2
 
-    # ---- (1b) the same best-effort variant on ALL host cores of the box (north_star: "the same box's host cores")
-    if host_cores > nthr:
-        nq_a = min(args.cpu_best_queries, nq)
-        bd2, bi2, _, secs2 = cb.best_effort(slab, offsets, ids_all, layers, torch.from_numpy(qh_all[:nq_a]), nb, k, threads=host_cores)
-        variants["best_effort_torch_allcores"] = {
-            "value": round(nq_a / secs2, 2), "unit": "queries/s", "cores": host_cores, "queries": nq_a, "seconds": round(secs2, 3),
-            "id_set_agreement_with_gpu": round(cb.id_agreement(bi2, out_i[:nq_a]), 6),
-            "what": f"the best-effort variant with torch / BLAS threads = os.cpu_count() = {host_cores}"}
-
-    # ---- (2) reference-structured: pandas groupby + .loc gather + BLAS + partial sort, per rank x bucket.
-    # Its cost is linear in the rows it touches (75 % is pandas data movement) and the whole 10M-row
-    # batch takes minutes on a CPU (reference README: 220 s), so it runs on a BOUNDED sample: `--cpu-ref-buckets`
-    # whole buckets at their full size (all ranks, real routing of the first `--cpu-ref-queries` queries), and
-    # the batch rate is the measured time scaled by rows(all buckets) / rows(sampled buckets).
     import pandas as pd
     from threadpoolctl import threadpool_limits
 
+    # ---- (2) reference-structured, measured IN FULL: pandas groupby + .loc gather + BLAS + partial sort, per rank x bucket,
+    # over the whole index (LearnedIndex.py:101-157, 328-373).  Its cost is data movement (75 % pandas) and
+    # hardly depends on the number of queries, so a query SUBSAMPLE keeps it inside the bench's budget; a deadline stops it after
+    # the first rank that ends past it (every rank moves the same data: scaled by nb / ranks done and flagged).
     nq_r = min(args.cpu_ref_queries, nq)
-    order_r = bo[:nq_r]
-    visited = np.bincount(order_r.ravel(), minlength=L)
-    cand = np.flatnonzero((sizes > 0) & (visited > 0))
-    pick = np.sort(np.random.RandomState(args.seed).choice(cand, size=min(args.cpu_ref_buckets, cand.size), replace=False))
-    rows_s = np.concatenate([slab_np[offsets[b]: offsets[b + 1]] for b in pick])
-    labels_s = np.concatenate([ids_all[offsets[b]: offsets[b + 1]] for b in pick]).astype(np.int64)
-    dp_s = np.concatenate([np.full(int(sizes[b]), b, dtype=np.int64) for b in pick])
-    scale = float(offsets[-1]) / float(rows_s.shape[0])
-    for name, thr in (("reference_structured_1core", 1), ("reference_structured_allcores", nthr)):
-        nav = pd.DataFrame(rows_s, index=labels_s, copy=False)
-        srch = pd.DataFrame(rows_s, index=labels_s, copy=False)   # a distinct frame object
-        torch.set_num_threads(thr)
-        with threadpool_limits(limits=thr):
+    if reference_full:
+        dp_all = np.repeat(np.arange(L, dtype=np.int64), sizes)
+        labels_all = ids_all.astype(np.int64)
+        nav = pd.DataFrame(slab_np, index=labels_all, copy=False)
+        srch = pd.DataFrame(slab_np, index=labels_all, copy=False)   # a distinct frame object
+        torch.set_num_threads(nthr)
+        with threadpool_limits(limits=nthr):
             t1 = time.perf_counter()
-            t_mlp = time.perf_counter()
-            cb.mlp_order_numpy(layers, qh_all[:nq_r], nb)
-            t_mlp = time.perf_counter() - t_mlp
-            rd, rn, parts = cb.reference_structured(nav, srch, qh_all[:nq_r], order_r, dp_s, k)
+            order_r = cb.mlp_order_numpy(layers, qh_all[:nq_r], nb)
+            t_mlp = time.perf_counter() - t1
+            rd, rn, parts = cb.reference_structured(nav, srch, qh_all[:nq_r], order_r, dp_all, k, deadline_s=ref_deadline_s)
             t_meas = time.perf_counter() - t1
-        est = t_mlp + (t_meas - t_mlp) * scale
-        variants[name] = {
-            "value": round(nq_r / est, 3), "unit": "queries/s", "cores": thr, "queries": nq_r, "estimated": True,
-            "measured_seconds": round(t_meas, 3), "sampled_buckets": int(pick.size), "sampled_rows": int(rows_s.shape[0]),
-            "scale_rows_total_over_sampled": round(scale, 3),
+        done = int(parts.pop("ranks_done"))
+        complete = done == nb
+        t_full = t_meas if complete else t_mlp + (t_meas - t_mlp) * nb / done
+        variants["reference_structured_measured"] = {
+            "value": round(nq_r / t_full, 3), "unit": "queries/s", "cores": nthr, "queries": nq_r, "estimated": not complete,
+            "measured_seconds": round(t_meas, 3), "ranks_run": done, "ranks": nb, "rows": int(offsets[-1]),
             "seconds_by_part": {kk: round(v, 3) for kk, v in parts.items()},
-            "what": "the reference's loop (LearnedIndex.py:101-157, 328-373): per rank groupby materialising every "
-                    "group, label-based .loc gather copy of each visited bucket, BLAS sgemm + partial sort (faiss.knn "
-                    "stand-in), 1 - sim, stable merge; measured on whole sampled buckets, scaled by rows to the full index"}
-    best = variants["best_effort_torch"]
-    if "best_effort_torch_allcores" in variants and variants["best_effort_torch_allcores"]["value"] > best["value"]:
-        best = variants["best_effort_torch_allcores"]   # `value` = the faster of the two thread counts, `cores` says which
+            # its data movement does not depend on the batch size, its k-NN part scales with it: the whole batch's rate from these parts
+            "whole_batch_estimate_queries_per_s": round(nq / (t_full + parts.get("knn", 0.0) * (nq / nq_r - 1.0) * (1.0 if complete else nb / done)), 3),
+            "id_set_agreement_with_gpu": round(cb.id_agreement(rn, out_i[:nq_r]), 6) if complete else None,
+            "what": "the reference's loop (LearnedIndex.py:101-157, 328-373) over the WHOLE index: per rank a groupby "
+                    "materialising every group, a label-based .loc gather copy of each visited bucket, BLAS sgemm + partial sort "
+                    "(faiss.knn stand-in), 1 - sim, stable merge" + ("" if complete else f"; stopped by the {ref_deadline_s:.0f}-s "
+                    f"deadline after {done} of {nb} ranks, scaled")}
+        del nav, srch, dp_all, labels_all
+
+    # ---- (2b) the cross-check of rounds 1-3: the same loop on a few whole buckets, one core, scaled by rows
+    if reference_sample:
+        order_s = bo[:nq]
+        visited = np.bincount(order_s.ravel(), minlength=L)
+        cand = np.flatnonzero((sizes > 0) & (visited > 0))
+        pick = np.sort(np.random.RandomState(args.seed).choice(cand, size=min(args.cpu_ref_buckets, cand.size), replace=False))
+        rows_s = np.concatenate([slab_np[offsets[b]: offsets[b + 1]] for b in pick])
+        labels_s = np.concatenate([ids_all[offsets[b]: offsets[b + 1]] for b in pick]).astype(np.int64)
+        dp_s = np.concatenate([np.full(int(sizes[b]), b, dtype=np.int64) for b in pick])
+        scale = float(offsets[-1]) / float(rows_s.shape[0])
+        nav = pd.DataFrame(rows_s, index=labels_s, copy=False)
+        srch = pd.DataFrame(rows_s, index=labels_s, copy=False)
+        torch.set_num_threads(1)
+        with threadpool_limits(limits=1):
+            t1 = time.perf_counter()
+            cb.mlp_order_numpy(layers, qh_all[:nq], nb)
+            t_mlp = time.perf_counter() - t1
+            _, _, parts = cb.reference_structured(nav, srch, qh_all[:nq], order_s, dp_s, k)
+            t_meas = time.perf_counter() - t1
+        torch.set_num_threads(nthr)
+        parts.pop("ranks_done", None)
+        variants["reference_structured_1core_sampled"] = {
+            "value": round(nq / (t_mlp + (t_meas - t_mlp) * scale), 3), "unit": "queries/s", "cores": 1, "queries": nq, "estimated": True,
+            "measured_seconds": round(t_meas, 3), "sampled_buckets": int(pick.size), "sampled_rows": int(rows_s.shape[0]),
+            "scale_rows_total_over_sampled": round(scale, 3), "seconds_by_part": {kk: round(v, 3) for kk, v in parts.items()},
+            "what": "the same loop on whole sampled buckets with all the batch's queries, ONE core, scaled by rows to the full index "
+                    "(the reference publishes ~45 q/s on one core of a Xeon 6130, README.md:54-68)"}
+        del nav, srch, rows_s
+    best = max((variants["best_effort_torch"], variants["best_effort_bucket_parallel"]), key=lambda v: v["value"])
+    best_name = "best_effort_torch" if best is variants["best_effort_torch"] else "best_effort_bucket_parallel"
     return {"value": best["value"], "unit": "queries/s", "cores": best["cores"], "kind": "port",
-            "sample": f"value = best-effort CPU variant: all {N} x {d} rows resident in host memory, first {nq_b} of {nq} queries, "
-                      f"all {nb} ranks, {best['cores']} threads (torch-CPU matmul + topk over the bucket-contiguous slab; the better of "
-                      f"{nthr} threads and all {host_cores} host cores); "
-                      f"`variants` holds the reference-structured pandas/BLAS loop on 1 core and on {nthr} cores "
-                      f"(bounded bucket sample, scaled) and the bit-exact oracle used as the checker",
-            "host_cpu_count": host_cores, "index_copy_to_host_s": round(t_copy, 2), "variants": variants}
+            "sample": f"value = `{best_name}` on {best['cores']} threads (this job's CPU share: {usable} usable of the host's {host_cores} cores): "
+                      f"all {N} x {d} rows resident in host memory, first {nq_b} of {nq} queries, all {nb} ranks, torch-CPU matmul + topk over "
+                      f"the bucket-contiguous slab; `variants` also holds the reference-structured pandas/BLAS loop measured over the whole "
+                      f"index on a {nq_r}-query subsample, its one-core figure from a bucket sample, and the bit-exact oracle used as the checker",
+            "host_cpu_count": host_cores, "usable_cpus": usable, "index_copy_to_host_s": round(t_copy, 2), "variants": variants}
 
 
-def dominant_roofline(args, cfg, res, sizes, owner, rank, capi):
+def dominant_roofline(args, cfg, res, sizes, owner, rank, capi, exact=None):
     """Roofline of the dominant kernel of one timed leg.  Algorithmic work per launch: flops = 2*d*sum over (query, rank)
     slots of the bucket size (sharded runs: this rank's slots); bytes = every visited bucket read once in the kernel's
     operand type + the packed queries once.  The larger of the two floors names the bound."""
     d, L, nb, nq = cfg["d"], cfg["leaves"], cfg["nb"], cfg["nq"]
+    exact = args.exact if exact is None else exact
     phases, bo = res["phases"], res["bo"]
     flops = res["scan_stats"][0]
-    dom_slot = capi.T_SCAN if args.exact else capi.T_PF_EMIT
+    dom_slot = capi.T_SCAN if exact else capi.T_PF_EMIT
     dom_s = max(float(phases[dom_slot]) * 1e-3, 1e-12)  # 0 when --timing-level < 2: the roofline fields are meaningless then
     visited = np.unique(bo)
     visited = visited[(visited >= 0) & (owner[np.clip(visited, 0, L - 1)] == rank)]
     rows_visited = float(sizes[visited].sum())
-    if args.exact:
+    if exact:
         kernel, op_bytes, peak_tf = "lmi::scan_kernel", 4, PEAK_F32_MFMA_TFLOPS
     else:
         kernel, op_bytes, peak_tf = ("lmi::pass2_kernel<false>" if d > 128 else "lmi::pass2_small_kernel<KG, false>"), 2, PEAK_F16_MFMA_TFLOPS
     # the fp16 slab pads K to whole k16-groups (d <= 128, lmi_pass2_small.h) or to pairs of them (a stage of pass2_kernel holds two)
-    dpad = d if args.exact else (-(-d // 16) * 16 if d <= 128 else -(-d // 32) * 32)
+    dpad = d if exact else (-(-d // 16) * 16 if d <= 128 else -(-d // 32) * 32)
     alg_bytes = op_bytes * d * (rows_visited + nq * nb)
     t_mfma, t_hbm = flops / (peak_tf * 1e12), alg_bytes / (PEAK_HBM_GBS * 1e9)
     if t_mfma >= t_hbm:
@@ -538,7 +568,7 @@ def main():
     ap.add_argument("--recall-queries", type=int, default=1000)
     ap.add_argument("--cpu-queries", type=int, default=256, help="queries re-computed by the bit-exact oracle (the checker)")
     ap.add_argument("--cpu-best-queries", type=int, default=10_000, help="queries of the best-effort torch-CPU baseline")
-    ap.add_argument("--cpu-ref-queries", type=int, default=10_000, help="queries of the reference-structured pandas baseline")
+    ap.add_argument("--cpu-ref-queries", type=int, default=1_000, help="query subsample of the reference-structured pandas baseline run over the whole index")
     ap.add_argument("--cpu-ref-buckets", type=int, default=6, help="whole buckets the reference-structured baseline is measured on")
     ap.add_argument("--cpu-threads", type=int, default=0, help="CPU baseline threads (0: min(16, host cores))")
     ap.add_argument("--rotate-batches", type=int, default=4, help="distinct query batches rotated through the timed loop")
@@ -546,6 +576,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-hard-leg", action="store_true", help="skip the second, harder workload (overlapping clusters)")
+    ap.add_argument("--no-exact-leg", action="store_true", help="skip the all-f32 leg (the same workload with lmi_set_prefilter(0))")
     ap.add_argument("--hard-sigma", type=float, default=1.0)
     ap.add_argument("--hard-centre-scale", type=float, default=0.26)
     ap.add_argument("--hard-zipf", type=float, default=20.0)
@@ -651,7 +682,7 @@ def main():
         hard_checked = None
         if rank == 0 and not args.no_cpu_baseline:   # the checker on the HARD workload too: small score gaps, the bound's window matters
             nthr_h = args.cpu_threads or min(16, os.cpu_count() or 1)
-            hq = min(args.cpu_queries, nq, 128)
+            hq = min(args.cpu_queries, nq, 256)
             hard_checked = {"queries": hq, "identical_ids_and_distances": True,
                             "checker_queries_per_s": oracle_check_sample(wh, rh, args, hq, nthr_h)}
         hard = {"generator": f"centres x{args.hard_centre_scale}, sigma {args.hard_sigma}, cluster weights ~ 1/(1 + c/{args.hard_zipf})",
@@ -665,6 +696,37 @@ def main():
                 "scan_pairs": int(rh["scan_stats"][1]), "oracle_check": hard_checked,
                 "phases_ms": {"pf_sample": round(float(rh["phases"][5]), 4), "pf_emit": round(float(rh["phases"][6]), 4),
                               "rescore": round(float(rh["phases"][7]), 4), "fallback": round(float(rh["phases"][8]), 4)}}
+
+    # ---- the SAME workload at the reference's own precision: all-f32 scan (lmi_set_prefilter(0): scan_kernel, f32 MFMA with
+    # the canonical chain, no prefilter, no re-rank), same MLP weights, same index data, same batch -- its answers must be
+    # byte-identical to the default leg's (LearnedIndex.py:360-368 computes in f32 end to end)
+    exact_leg = None
+    if world == 1 and args.config == "c2" and not args.exact and not args.no_exact_leg and not args.emulate_shard:
+        for w_ in (wl, locals().get("wh")):
+            if w_ is not None and getattr(w_, "eng", None) is not None:
+                w_.eng.close()
+                w_.eng = None
+        torch.cuda.empty_cache()
+        we = Workload(args, cfg, dev, rank, world, local_rank, tag="main", exact=True, layers=wl.layers, label="exact")
+        esteps = max(3, args.steps // 4)
+        re_ = we.run(esteps, 1, measure_resident=True)
+        eroof, eflops, _ = dominant_roofline(args, cfg, re_, we.sizes, we.owner, rank, _capi, exact=True)
+        same = bool(np.array_equal(re_["out_i"], out_i) and np.array_equal(re_["out_d"], out_d))
+        assert same, "the all-f32 leg and the default leg returned different results"
+        echeck = None
+        if rank == 0 and not args.no_cpu_baseline:
+            eq_ = min(args.cpu_queries, nq, 64)
+            echeck = {"queries": eq_, "identical_ids_and_distances": True,
+                      "checker_queries_per_s": oracle_check_sample(we, re_, args, eq_, args.cpu_threads or 16)}
+        exact_leg = {"what": "lmi_set_prefilter(0): all-f32 scan_kernel (f32 MFMA, canonical k-ordered chain), same weights / index / batch",
+                     "dtype": "f32", "value": round(nq * esteps / re_["elapsed"], 2), "unit": "queries/s", "steps": esteps,
+                     "ms_per_step": round(re_["elapsed"] / esteps * 1e3, 4),
+                     "resident_ms_per_step": round(re_["resident_elapsed"] / esteps * 1e3, 4),
+                     "identical_to_default_leg": same, "roofline": eroof, "oracle_check": echeck,
+                     "phases_ms": {"inference": round(float(re_["phases_resident"][0]), 4), "route_pack": round(float(re_["phases"][1]), 4),
+                                   "scan": round(float(re_["phases"][2]), 4), "merge": round(float(re_["phases"][3]), 4)}}
+        we.eng.close()
+        we.eng = None
 
     # ---- the other single-GPU configurations of BASELINE.json, each as a short leg of its own: C1 (configs[0]: 100k x 768,
     # 1 000 queries -- the reference's CPU-runnable case) and C5 (configs[4]: 10M x 45, 256 leaves, cosine)
@@ -682,6 +744,16 @@ def main():
             osteps = max(10, args.steps)
             ro = wo.run(osteps, 3, measure_resident=False)
             oroof, _, _ = dominant_roofline(args, ocfg, ro, wo.sizes, wo.owner, rank, _capi)
+            otj = os.path.join(ROOT, "profiles", f"scan_pmc_{cname}.json")
+            oroof["traffic"] = None
+            if os.path.exists(otj):
+                opj = json.load(open(otj))
+                osame = ((opj.get("lib") or {}).get("built_from_source_sha16") == lib_provenance()["built_from_source_sha16"]
+                         and str(opj.get("kernel", "")).split("<")[0] in oroof["kernel"])
+                oroof["traffic"] = opj.get("hbm_bytes_per_launch") if osame else None
+                oroof["mfma_pipe_busy_frac"] = opj.get("mfma_pipe_busy_frac") if osame else None
+                oroof["traffic_source"] = {"file": os.path.relpath(otj, ROOT), "collected_utc": opj.get("collected_utc"), "commit": opj.get("commit"),
+                                           "matches_loaded_library": bool(osame), "how": "replayed from separate rocprofv3 --pmc passes of bench.py --config " + cname}
             others[cname] = {"workload": f"{ocfg['n']}x{ocfg['d']}, {ocfg['leaves']} leaves, top-{ocfg['nb']}, {ocfg['nq']}-query batch",
                              "value": round(ocfg["nq"] * osteps / ro["elapsed"], 2), "unit": "queries/s",
                              "ms_per_step": round(ro["elapsed"] / osteps * 1e3, 4),
@@ -691,9 +763,41 @@ def main():
                                            "pf_sample": round(float(ro["phases"][5]), 4), "pf_emit": round(float(ro["phases"][6]), 4),
                                            "rescore": round(float(ro["phases"][7]), 4), "merge": round(float(ro["phases"][3]), 4)}}
             if rank == 0 and not args.no_cpu_baseline:
-                oq = min(args.cpu_queries, ocfg["nq"], 128)
-                others[cname]["oracle_check"] = {"queries": oq, "identical_ids_and_distances": True,
-                                                 "checker_queries_per_s": oracle_check_sample(wo, ro, args, oq, args.cpu_threads or min(16, os.cpu_count() or 1))}
+                # C1 is the reference's own CPU-runnable case: everything in full (all 1 000 queries through the reference-structured
+                # loop on 16 and on 1 core); C5: the best-effort variants and the checker (its pandas loop moves 10M rows per rank)
+                ocpu = cpu_baselines(wo, ro, args, reference_full=(cname == "c1"), reference_sample=False, oracle_queries=128, ref_deadline_s=20.0)
+                if cname == "c1":
+                    import pandas as pd
+                    from threadpoolctl import threadpool_limits
+                    from oracle import cpu_baseline as cb_
+                    sizes_o = wo.eng.bucket_sizes()
+                    off_o = np.concatenate([[0], np.cumsum(sizes_o)]).astype(np.int64)
+                    rows_o = np.empty((int(off_o[-1]), ocfg["d"]), dtype=np.float32)
+                    ids_o = np.empty(int(off_o[-1]), dtype=np.uint32)
+                    for b_ in range(ocfg["leaves"]):
+                        if sizes_o[b_]:
+                            wo.eng.read_bucket(b_, rows_out=rows_o[off_o[b_]: off_o[b_ + 1]], ids_out=ids_o[off_o[b_]: off_o[b_ + 1]])
+                    qo = wo.queries.cpu().numpy()
+                    torch.set_num_threads(1)
+                    with threadpool_limits(limits=1):
+                        t1 = time.perf_counter()
+                        order_1 = cb_.mlp_order_numpy(wo.layers, qo, ocfg["nb"])
+                        _, rn1, parts1 = cb_.reference_structured(pd.DataFrame(rows_o, index=ids_o.astype(np.int64), copy=False),
+                                                                  pd.DataFrame(rows_o, index=ids_o.astype(np.int64), copy=False),
+                                                                  qo, order_1, np.repeat(np.arange(ocfg["leaves"], dtype=np.int64), sizes_o), args.k)
+                        t_1 = time.perf_counter() - t1
+                    torch.set_num_threads(args.cpu_threads or 16)
+                    parts1.pop("ranks_done", None)
+                    ocpu["variants"]["reference_structured_measured_1core"] = {
+                        "value": round(ocfg["nq"] / t_1, 3), "unit": "queries/s", "cores": 1, "queries": ocfg["nq"], "estimated": False,
+                        "measured_seconds": round(t_1, 3), "seconds_by_part": {kk: round(v, 3) for kk, v in parts1.items()},
+                        "id_set_agreement_with_gpu": round(cb_.id_agreement(rn1, ro["out_i"]), 6),
+                        "what": "the reference's loop over the whole C1 index, all 1 000 queries, ONE core -- the configuration the reference "
+                                "publishes ~45 q/s for (README.md:54-68: LAION 10M; here 100k rows)"}
+                    del rows_o, ids_o
+                others[cname]["cpu_baseline"] = ocpu
+                others[cname]["oracle_check"] = {"queries": ocpu["variants"]["oracle_checker"]["queries"], "identical_ids_and_distances": True,
+                                                 "checker_queries_per_s": ocpu["variants"]["oracle_checker"]["value"]}
             wo.eng.close()
             wo.eng = None
 
@@ -705,14 +809,19 @@ def main():
         # `rocprofv3 --pmc` passes of this same command (tools/profile_round.sh + profiles/summarize.py), and only when that
         # summary was collected from the library sources this run was built from -- otherwise they are null.
         traffic = mfma_busy = None
+        prov = lib_provenance()
         tj = args.traffic_json or os.path.join(ROOT, "profiles", f"scan_pmc_{args.config}{'_exact' if args.exact else ''}.json")
         overridden = any(getattr(args, key) is not None for key in ("n", "nq", "nb", "leaves", "emulate_shard"))
         traffic_source = None
         if world == 1 and not overridden and os.path.exists(tj):
             pj = json.load(open(tj))
-            same = pj.get("lib_source_sha16") == lib_source_sha16() and str(pj.get("kernel", "")) in roof["kernel"]
+            # the summary carries the provenance the PROFILED bench run reported about the library it had loaded (not a hash taken
+            # later from some working tree): replay only for the same build
+            pl = pj.get("lib") or {}
+            same = (pl.get("built_from_source_sha16") is not None and pl.get("built_from_source_sha16") == prov["built_from_source_sha16"]
+                    and str(pj.get("kernel", "")) in roof["kernel"])
             traffic_source = {"file": os.path.relpath(tj, ROOT), "collected_utc": pj.get("collected_utc"), "commit": pj.get("commit"),
-                              "lib_source_sha16": pj.get("lib_source_sha16"), "matches_this_build": bool(same),
+                              "lib": pl, "matches_loaded_library": bool(same),
                               "how": "replayed from separate rocprofv3 --pmc passes of this command, not measured in this run"}
             if same:
                 traffic, mfma_busy = pj.get("hbm_bytes_per_launch"), pj.get("mfma_pipe_busy_frac")
@@ -762,7 +871,10 @@ def main():
             "sharded_alt_mode": alt,
             "per_rank": per_rank,
             "hard_leg": hard,
+            "exact_leg": exact_leg,
             "other_configs": others,
+            "lib": prov,
+            "collected_utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
             "rotated_batches": args.rotate_batches,
             **({"diagnostic": f"emulated shard {args.emulate_shard}: NOT a bench line"} if args.emulate_shard else {}),
             "phases_ms": {"inference": round(float(res["phases_resident"][0] if res.get("overlapped") and "phases_resident" in res else phases[0]), 4), "route_pack": round(float(phases[1]), 4),

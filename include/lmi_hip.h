@@ -69,6 +69,11 @@ enum {
 
 LMI_API int lmi_abi_version(void);
 LMI_API const char *lmi_last_error(void);
+/* Provenance (no reference counterpart): "src=<sha256/16 of the library's sources this binary was built from> p2_waves=..
+ * p2_bring=.. pf_cap=.." -- csrc/build.sh bakes the hash in (learnedmetricindex_amd/_srchash.py: every .h / .hip under csrc
+ * and every .h under include); bench.py and profiles/summarize.py tie PMC summaries to the library that was really
+ * LOADED with it (not to whatever sources lie in the working tree). */
+LMI_API const char *lmi_build_info(void);
 
 /* Lifetime. */
 LMI_API int lmi_create(int device, lmi_index **out);

@@ -31,6 +31,7 @@ _vp = ctypes.c_void_p
 SIGNATURES = {
     "lmi_abi_version": (ctypes.c_int, []),
     "lmi_last_error": (ctypes.c_char_p, []),
+    "lmi_build_info": (ctypes.c_char_p, []),
     "lmi_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
     "lmi_destroy": (ctypes.c_int, [_vp]),
     "lmi_set_stream": (ctypes.c_int, [_vp, _vp]),

@@ -4,10 +4,12 @@ set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="${LMI_OUT:-${here}/../liblmi_hip.so}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+# the hash of the sources this binary is built from: lmi_build_info() reports it (learnedmetricindex_amd/_srchash.py)
+SRC_SHA16="$(python3 "${here}/../_srchash.py")"
 "${HIPCC}" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fvisibility=hidden \
   -I"${here}/../../include" -I"${here}" \
   -Wall -Wno-unused-function \
-  ${LMI_EXTRA_FLAGS:-} \
+  -DLMI_SOURCE_SHA16="\"${SRC_SHA16}\"" ${LMI_EXTRA_FLAGS:-} \
   -o "${out}" "${here}/lmi_hip.hip" \
   -Wl,-rpath,/opt/rocm/lib -Wl,-Bsymbolic
 echo "built ${out}"

@@ -176,6 +176,14 @@ static int set_dev(lmi_index* h) {
 }
 
 extern "C" LMI_API int lmi_abi_version(void) { return LMI_ABI_VERSION; }
+#ifndef LMI_SOURCE_SHA16
+#define LMI_SOURCE_SHA16 "unknown"
+#endif
+#define LMI_STR2(x) #x
+#define LMI_STR(x) LMI_STR2(x)
+extern "C" LMI_API const char* lmi_build_info(void) {
+    return "src=" LMI_SOURCE_SHA16 " p2_waves=" LMI_STR(LMI_P2_WAVES) " p2_bring=" LMI_STR(LMI_P2_BR) " pf_cap=" LMI_STR(LMI_PF_CAP);
+}
 extern "C" LMI_API const char* lmi_last_error(void) { return g_err.c_str(); }
 
 extern "C" LMI_API int lmi_create(int device, lmi_index** out) {
@@ -225,7 +233,9 @@ extern "C" LMI_API int lmi_create(int device, lmi_index** out) {
 #define LMI_PS_ATTR(K) \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pass2_small_kernel<K, false>), hipFuncAttributeMaxDynamicSharedMemorySize, ps_lds_bytes(K))); \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pass2_small_kernel<K, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ps_lds_bytes(K)));
-    LMI_PS_ATTR(6) LMI_PS_ATTR(7) LMI_PS_ATTR(8)
+    // every K: the dynamic part alone stays under 64 KiB up to K = 5, but the static arrays beside it (queue prefix, candidate
+    // list, item) put the block's total above it from K = 5 on
+    LMI_PS_ATTR(1) LMI_PS_ATTR(2) LMI_PS_ATTR(3) LMI_PS_ATTR(4) LMI_PS_ATTR(5) LMI_PS_ATTR(6) LMI_PS_ATTR(7) LMI_PS_ATTR(8)
 #undef LMI_PS_ATTR
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));

@@ -519,7 +519,10 @@ struct Tile2 {
             // an MFMA's result needs 18 wait states before a VALU reads it (16-pass worst case); hipcc pads nothing behind asm
             asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
             P2_STAMP(2)   // (coarse builds: the whole K loop of the tile, waits and barriers included)
-            if (SAMPLE) epilogue_sample(rb0 + vt * P2_WAVES, n_b, col0, m_left, ch % P2_NSL, ch >= P2_NSL, vt * P2_WAVES);
+            // (a bucket with more sampled tiles than lists: EVERY tile that shares a list folds with the monotone atomic -- a plain
+            // store from tile j could land behind tile j + 16's atomic and discard it: still a valid bound, but a different one from
+            // run to run)
+            if (SAMPLE) epilogue_sample(rb0 + vt * P2_WAVES, n_b, col0, m_left, ch % P2_NSL, p2_sample_tiles(n_b) > P2_NSL, vt * P2_WAVES);
             else epilogue_emit(rb0 + vt * P2_WAVES, n_b, col0);
             P2_STAMP(3)
         }

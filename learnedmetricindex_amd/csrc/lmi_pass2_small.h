@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64 * PS_WAVES, ps_blocks_per_cu(KG)) void pass2_sma
         const uint4* aslab = P.slab16 + (size_t)P.rb_start[b] * KG * 64 + lane;
         const int npairs = (nrb + 1) >> 1;
         const int list_j = item.ch % P2_NSL;
-        const bool use_atomic = item.ch >= P2_NSL;   // more sampled tiles than lists
+        const bool use_atomic = SAMPLE && p2_sample_tiles(n_b) > P2_NSL;   // more sampled tiles than lists: every tile folds with the atomic
         half8 a0[KG], a1[KG];
         auto load_pair = [&](int pp, half8 (&x0)[KG], half8 (&x1)[KG]) __attribute__((always_inline)) {
             const uint4* pa = aslab + (size_t)min(rb0 + 2 * pp, rb_last) * (KG * 64);

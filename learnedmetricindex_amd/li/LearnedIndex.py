@@ -49,6 +49,68 @@ def _feature_columns(df: pd.DataFrame) -> list:
     return [c for c in df.columns if not (isinstance(c, str) and c.startswith("category_L"))]
 
 
+class _Hasher:
+    """Streamed 64-bit content hash: xxh3 when the wheel is there (~10 GB/s), zlib.crc32 + adler32 otherwise."""
+
+    def __init__(self):
+        try:
+            import xxhash
+            self._h, self._z = xxhash.xxh3_64(), None
+        except ImportError:  # pragma: no cover
+            self._h, self._z = None, [0, 1]
+
+    def update(self, a) -> None:
+        a = np.ascontiguousarray(a)   # logical (row-major) element order, whatever the array's memory layout
+        buf = memoryview(a.reshape(-1).view(np.uint8)) if a.size else b""
+        if self._h is not None:
+            self._h.update(buf)
+        else:  # pragma: no cover
+            import zlib
+            self._z = [zlib.crc32(buf, self._z[0]), zlib.adler32(buf, self._z[1])]
+
+    def digest(self) -> int:
+        return self._h.intdigest() if self._h is not None else (self._z[0] << 32) | self._z[1]
+
+
+def _array_fingerprint(a) -> int:
+    h = _Hasher()
+    h.update(a)
+    return h.digest()
+
+
+def _frame_bytes(df: pd.DataFrame) -> int:
+    return int(df.shape[0]) * int(df.shape[1]) * 4
+
+
+def _frame_fingerprint(df: pd.DataFrame, full: bool) -> int:
+    """Hash of the frame's values: every byte (`full`: blocks of the frame as they lie in memory, no copy for a single-dtype
+    frame) or 4 096 evenly spaced whole rows."""
+    h = _Hasher()
+    if not full:
+        rows = np.unique(np.linspace(0, max(0, df.shape[0] - 1), num=min(4096, max(1, df.shape[0])), dtype=np.int64))
+        h.update(df.iloc[rows].to_numpy() if df.shape[0] else np.empty(0))
+        return h.digest()
+    # rows in order, every row's columns in order -- independent of how pandas lays the frame out.  A single-dtype frame made
+    # from a row-major array (the usual case) is one block whose transposed values ARE that array: hashed in place, no copy;
+    # any other layout is hashed through row-chunk copies.
+    vals = None
+    try:
+        blocks = list(df._mgr.blocks)
+        if len(blocks) == 1 and blocks[0].values.ndim == 2 and blocks[0].values.T.flags.c_contiguous \
+                and np.array_equal(np.asarray(blocks[0].mgr_locs.as_array), np.arange(df.shape[1])):
+            vals = blocks[0].values.T
+    except Exception:  # noqa: BLE001  (pandas internals: best effort)
+        vals = None
+    if vals is not None:
+        h.update(vals)
+    else:
+        step = max(1, (64 << 20) // max(1, 8 * df.shape[1]))
+        for r0 in range(0, df.shape[0], step):
+            h.update(df.iloc[r0: r0 + step].to_numpy())
+    h.update(np.asarray([str(c) for c in df.columns]).astype("U"))
+    return h.digest()
+
+
 class LearnedIndex(Logger):
     _WORKSPACE_BYTES = 6 << 30  # per-call device workspace budget of one search chunk
     _NAV_QUEUE_BYTES = 4 << 30  # multi-level walk: per-query priority queues hold one 8-byte entry per child of every node
@@ -97,8 +159,14 @@ class LearnedIndex(Logger):
         self._engine = None
         self._engine_key = None
 
+    #: "auto": full-content fingerprint of the scan frame for frames up to _STRICT_BYTES, a row sample above; True: always full;
+    #: False: always the sample (an in-place edit of unsampled rows is then only caught by `invalidate()`)
+    strict_cache = "auto"
+    _STRICT_BYTES = 1 << 30
+
     def prepare(self, data_navigation: pd.DataFrame, data_search: pd.DataFrame,
-                data_prediction: npt.NDArray[np.int64], n_categories: List[int], device: int = 0, metric: str = "ip"):
+                data_prediction: npt.NDArray[np.int64], n_categories: List[int], device: int = 0, metric: str = "ip",
+                assume_unchanged: bool = False):
         """Uploads the scan vectors bucket-contiguously (the one-time replacement of the
         reference's per-call groupby + `.loc` gather).  Called by `search` when needed."""
         assert self.root_model is not None, "Model is not trained, call `build` first."
@@ -106,38 +174,25 @@ class LearnedIndex(Logger):
         if dp.ndim == 1:
             dp = dp[:, None]
         assert dp.shape[0] == data_navigation.shape[0] == data_search.shape[0]
-        # What the resident copy was built from.  The reference re-reads the frames on every call; here the key is the
-        # frames' identity (object id, shape, address of a single-block frame's values) AND an order-sensitive CRC of
-        # content samples (strided rows of the vectors, labels, placement) and of EVERY model's weights: an in-place
-        # edit at a sampled position, a re-labelled, re-placed or re-trained index misses the cache instead of being
-        # answered from a stale slab.  An in-place edit of unsampled rows of the same frame object is the one case
-        # only `invalidate()` catches.
-        import zlib
-
-        def _crc(a, n=65536):
-            a = np.ascontiguousarray(np.asarray(a).reshape(-1))
-            if a.size > n:
-                a = np.ascontiguousarray(a[:: a.shape[0] // n])
-            return zlib.crc32(a.view(np.uint8)) if a.size else 0
-
-        def _addr(df):
-            try:
-                mgr = df._mgr
-                if len(mgr.blocks) == 1:
-                    return int(mgr.blocks[0].values.__array_interface__["data"][0])
-            except Exception:  # noqa: BLE001  (pandas internals: best effort)
-                pass
-            return 0
-
-        rows = np.linspace(0, max(0, data_search.shape[0] - 1), num=min(256, max(1, data_search.shape[0])), dtype=np.int64)
-        w_crc = 0
+        # What the resident copy was built from.  The reference re-reads both frames on every call (LearnedIndex.py:350-357), so a
+        # drop-in must never answer from a slab the caller has since edited: the key is a CONTENT fingerprint -- a streamed 64-bit
+        # hash of every byte of the scan vectors, of the labels, of the placement and of every model's weights -- and not the
+        # frames' identity: an equal-content frame built afresh (`df[cols]`, `.copy()`) hits the cache, an in-place edit of any row
+        # misses it.  Hashing costs ~0.1 s per GB and call; frames above `_STRICT_BYTES` (1 GiB) are fingerprinted by a row sample
+        # instead unless `strict_cache` is True, and `assume_unchanged=True` skips the vectors' fingerprint altogether (the caller
+        # then vouches that the frames are the ones the resident index was built from; `invalidate()` drops it).
+        full = self.strict_cache is True or (self.strict_cache == "auto" and _frame_bytes(data_search) <= self._STRICT_BYTES)
+        if assume_unchanged and self._engine is not None:
+            content = self._engine_key[0] if self._engine_key else None
+        else:
+            content = _frame_fingerprint(data_search, full)
+        w_h = _Hasher()
         for net in [self.root_model] + list(self.internal_models.values()):
             for W, b in linear_layers(net.model):
-                w_crc = zlib.crc32(np.ascontiguousarray(b).view(np.uint8), zlib.crc32(np.ascontiguousarray(W).view(np.uint8), w_crc))
-        key = (id(data_search), id(data_navigation), _addr(data_search), tuple(data_search.shape),
-               _crc(data_search.iloc[rows].to_numpy(dtype=np.float32)) if data_search.shape[0] else 0,
-               _crc(data_navigation.index.to_numpy()), dp.shape, _crc(dp), w_crc,
-               tuple(tuple(int(v) for v in p) for p in self.internal_models), tuple(n_categories), device, metric)
+                w_h.update(W)
+                w_h.update(b)
+        key = (content, tuple(data_search.shape), _array_fingerprint(data_navigation.index.to_numpy()), dp.shape, _array_fingerprint(dp),
+               w_h.digest(), tuple(tuple(int(v) for v in p) for p in self.internal_models), tuple(n_categories), device, metric)
         if self._engine is not None and key == self._engine_key:
             return self._engine
         self.close()
@@ -194,12 +249,15 @@ class LearnedIndex(Logger):
         n_buckets: int = 1,
         k: int = 10,
         metric: str = "ip",
+        assume_unchanged: bool = False,
     ) -> Tuple[npt.NDArray, npt.NDArray[np.uint32], Dict[str, float]]:
         """Searches for `k` nearest neighbors of every query in its `n_buckets` most probable buckets.
         Parameters and return values as the reference (LearnedIndex.py:41-83).  `metric` (an extension; the
-        reference scans with `1 - inner product` only): "ip" (default) or "l2" -- squared Euclidean distances."""
+        reference scans with `1 - inner product` only): "ip" (default) or "l2" -- squared Euclidean distances.
+        `assume_unchanged` (an extension): the caller vouches that `data_search` still holds what the HBM-resident copy was
+        built from, so its bytes are not fingerprinted again (see `prepare`); the default re-checks them on every call."""
         s = time.time()
-        eng = self.prepare(data_navigation, data_search, data_prediction, n_categories, metric=metric)
+        eng = self.prepare(data_navigation, data_search, data_prediction, n_categories, metric=metric, assume_unchanged=assume_unchanged)
         return self._search_with(eng, queries_navigation, queries_search, n_categories, n_buckets, k, s)
 
     def _search_with(self, eng, queries_navigation, queries_search, n_categories, n_buckets, k, s):

@@ -56,15 +56,21 @@ def _knn_blas(xq: np.ndarray, xb: np.ndarray, k: int) -> Tuple[np.ndarray, np.nd
 
 
 def reference_structured(data_navigation, data_search, queries_search: np.ndarray, bucket_order: np.ndarray,
-                         data_prediction: np.ndarray, k: int = 10) -> Tuple[np.ndarray, np.ndarray, Dict[str, float]]:
+                         data_prediction: np.ndarray, k: int = 10, deadline_s: float = None) -> Tuple[np.ndarray, np.ndarray, Dict[str, float]]:
     """The reference's search loop on pandas frames (see the module docstring for the line map).
     `data_navigation`/`data_search`: DataFrames with the objects' labels as index (distinct objects, SURVEY Q1);
-    `bucket_order` int32 [nq, nb] from the MLP; `data_prediction` int64 [N] bucket of every object."""
-    t = {"groupby": 0.0, "gather": 0.0, "knn": 0.0, "merge": 0.0}
+    `bucket_order` int32 [nq, nb] from the MLP; `data_prediction` int64 [N] bucket of every object.
+    `deadline_s` (bench only): stop after the first rank that ends past it; `t["ranks_done"]` then says how many of the nb
+    ranks ran (every rank costs the same data movement: the caller scales) and the merged result covers those ranks only."""
+    t = {"groupby": 0.0, "gather": 0.0, "knn": 0.0, "merge": 0.0, "ranks_done": 0.0}
+    t_start = time.perf_counter()
     nq, nb = bucket_order.shape
     data_navigation["category_L1"] = data_prediction                       # :101-104
     dists_final = anns_final = None
     for r in range(nb):                                                     # :107
+        if deadline_s is not None and r > 0 and time.perf_counter() - t_start > deadline_s:
+            break
+        t["ranks_done"] += 1
         nns = np.zeros((nq, K_PER_BUCKET), dtype=np.uint32)                # :340-341
         dists = np.full((nq, K_PER_BUCKET), np.inf, dtype=float)
         t0 = time.perf_counter()
@@ -142,6 +148,91 @@ def best_effort(slab, offsets: np.ndarray, ids: np.ndarray, layers: Sequence, qu
         out_d = torch.gather(d, 1, o).double().numpy()
         out_i = torch.gather(rank_i.reshape(nq, -1), 1, o).numpy().astype(np.uint32)
     return out_d, out_i, order.numpy().astype(np.int32), time.perf_counter() - t0
+
+
+def best_effort_bucket_parallel(slab, offsets: np.ndarray, ids: np.ndarray, layers: Sequence, queries, nb: int, k: int, workers: int):
+    """`best_effort` with the parallelism turned round: `workers` Python threads each take whole buckets (one single-threaded
+    matmul + topk per bucket; torch releases the GIL inside its kernels) instead of every product being split over the BLAS
+    threads.  Same arithmetic and results as `best_effort`; returns the same tuple."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+
+    old = torch.get_num_threads()
+    t0 = time.perf_counter()
+    try:
+        with torch.no_grad():
+            torch.set_num_threads(workers)
+            h = queries
+            for li, (W, b) in enumerate(layers):
+                h = torch.addmm(torch.from_numpy(b), h, torch.from_numpy(W).T)
+                if li + 1 < len(layers):
+                    h = torch.relu(h)
+            order = h.topk(nb, dim=1).indices
+            torch.set_num_threads(1)
+            nq = queries.shape[0]
+            rank_s = torch.full((nq, nb, K_PER_BUCKET), -torch.finfo(torch.float32).max)
+            rank_i = torch.zeros((nq, nb, K_PER_BUCKET), dtype=torch.int64)
+            visited = torch.zeros((nq, nb), dtype=torch.bool)
+            flat = order.reshape(-1)
+            perm = torch.argsort(flat, stable=True)
+            counts = torch.bincount(flat, minlength=offsets.shape[0] - 1)
+            starts = torch.cumsum(counts, 0) - counts
+            ids_t = torch.from_numpy(ids.astype(np.int64))
+
+            def one(b):
+                lo, hi = int(offsets[b]), int(offsets[b + 1])
+                if hi == lo:
+                    return
+                slots = perm[starts[b]: starts[b] + counts[b]]
+                qi, ri = slots // nb, slots % nb
+                sim = queries[qi] @ slab[lo:hi].T
+                kk = min(K_PER_BUCKET, hi - lo)
+                v, i = sim.topk(kk, dim=1)
+                rank_s[qi, ri, :kk] = v          # (distinct (query, rank) slots per bucket: the threads write disjoint rows)
+                rank_i[qi, ri, :kk] = ids_t[lo + i]
+                if kk < K_PER_BUCKET:
+                    rank_i[qi, ri, kk:] = ids_t[hi - 1]
+                visited[qi, ri] = True
+
+            todo = torch.nonzero(counts).flatten().tolist()
+            todo.sort(key=lambda b: -(int(counts[b]) * int(offsets[b + 1] - offsets[b])))   # heaviest first
+            with ThreadPoolExecutor(max_workers=workers) as ex:
+                list(ex.map(one, todo))
+            torch.set_num_threads(workers)
+            d = 1 - rank_s
+            d[~visited] = float("inf")
+            rank_i[~visited] = 0
+            d = d.reshape(nq, nb * K_PER_BUCKET)
+            o = torch.sort(d, dim=1, stable=True).indices[:, : (K_PER_BUCKET if nb == 1 else k)]
+            out_d = torch.gather(d, 1, o).double().numpy()
+            out_i = torch.gather(rank_i.reshape(nq, -1), 1, o).numpy().astype(np.uint32)
+    finally:
+        torch.set_num_threads(old)
+    return out_d, out_i, order.numpy().astype(np.int32), time.perf_counter() - t0
+
+
+def usable_cpus() -> int:
+    """CPUs this process may really use: the affinity mask, capped by the cgroup's CPU quota (a GPU box of the pool shows all
+    256 host cores in os.cpu_count() while a one-GPU job is given 16)."""
+    import math
+    import os
+
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, math.ceil(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, math.ceil(q / per)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
 
 
 def id_agreement(a: np.ndarray, b: np.ndarray) -> float:

@@ -99,21 +99,29 @@ def main(src, tag, dominant=None):
         pmc["note"] = ("(2 * FETCH_SIZE + WRITE_SIZE) KiB -> bytes; FETCH_SIZE counts L2 misses, Infinity-Cache "
                        "hits included, so this is an upper bound on true HBM reads")
     pmc["kernel"] = DOMINANT
-    # provenance (bench.py replays hbm_bytes_per_launch / mfma_pipe_busy_frac only for the library build they were collected from)
-    import datetime
+    # provenance: what the PROFILED bench run itself reported about the library it had loaded (path, sha256/16 of the .so, the
+    # source hash baked into it by csrc/build.sh) and when it ran -- copied, never recomputed here: this script runs later and in
+    # another container than the collection (tools/profile_round.sh).  bench.py replays hbm_bytes_per_launch / mfma_pipe_busy_frac
+    # into a bench line only when the library IT loaded reports the same built-from hash.
     import subprocess
-    sys.path.insert(0, os.path.dirname(out_dir))
-    try:
-        import bench
-        pmc["lib_source_sha16"] = bench.lib_source_sha16()
-    except Exception as e:  # noqa: BLE001
-        pmc["lib_source_sha16"] = None
-        print("no source hash:", e, file=sys.stderr)
+    bj = one(os.path.join(src, "*bench_under_rocprof.json"))
+    pmc["lib"], pmc["collected_utc"] = None, None
+    if bj:
+        for ln in open(bj):
+            ln = ln.strip()
+            if ln.startswith("{"):
+                try:
+                    j = json.loads(ln)
+                except ValueError:
+                    continue
+                pmc["lib"], pmc["collected_utc"] = j.get("lib"), j.get("collected_utc")
+    if pmc["lib"] is None:
+        print("no provenance: the profiled bench line carries no `lib` field; bench.py will not replay this summary", file=sys.stderr)
     try:
         pmc["commit"] = subprocess.run(["git", "-C", os.path.dirname(out_dir), "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
     except Exception:  # noqa: BLE001
         pmc["commit"] = None
-    pmc["collected_utc"] = datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ")
+    pmc["commit_is"] = "HEAD when this summary was written (the collection's own stamp is `lib` / `collected_utc`)"
     with open(os.path.join(out_dir, f"{tag}_scan_pmc.json"), "w") as fh:
         json.dump(pmc, fh, indent=1)
     print(json.dumps(pmc, indent=1))

@@ -36,3 +36,13 @@ def test_cpu_baselines_match_reference_fixture(oracle, name):
     np.testing.assert_array_equal(o2, order)
     compare_modulo_near_ties(g["ref_dists"], g["ref_nns"], d2, n2)
     assert cb.id_agreement(n2, g["ref_nns"]) > 0.995  # G4 holds 21 duplicate vectors: exact ties
+    # the bucket-parallel form of the same baseline: same answers (BLAS blocks a product differently on one thread: last-bit
+    # differences of a distance, ids equal outside float32 near-ties)
+    d3, n3, o3, _ = cb.best_effort_bucket_parallel(slab, offsets, ids, layers, torch.from_numpy(Qs), nb, k, workers=3)
+    np.testing.assert_array_equal(o3, order)
+    compare_modulo_near_ties(g["ref_dists"], g["ref_nns"], d3, n3)
+    np.testing.assert_allclose(d3, d2, rtol=0, atol=1e-6)
+    # a deadline that has already passed stops the reference-structured loop after its first rank
+    nav2 = pd.DataFrame(Xn.copy()); nav2.index += 1
+    _, _, t2 = cb.reference_structured(nav2, srch, Qs, order, dp, k, deadline_s=0.0)
+    assert t2["ranks_done"] == 1 and t["ranks_done"] == nb and cb.usable_cpus() >= 1

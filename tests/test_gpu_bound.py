@@ -12,7 +12,9 @@ s_c; s' = xscale*qscale*s_c is exact (powers of two).  Asserted: max |shat - s'|
   * ALL-POSITIVE vectors (sum|terms| = |sum terms|: the worst case for accumulation error),
   * magnitudes that straddle binades inside one vector (partial sums cross many exponents, both growing
     and shrinking term order), and rows/queries spread over four orders of magnitude,
-  * d in {768, 2048, 4096}.
+  * d in {768, 2048, 4096},
+  * directed adversarial shapes at K = 16 / 32 / 48 / 768: alternating-sign nearly cancelling products, one term 2^14 x the
+    rest, all-subnormal fp16 images, max |x'| exactly 0.5 and just below 1.
 The max ratio per case is printed (pytest -s) and returned in the assertion message."""
 import numpy as np
 import pytest
@@ -44,6 +46,31 @@ def make(kind, d, seed):
     elif kind == "scales":         # un-normalised rows and queries over four orders of magnitude
         X = X * (10.0 ** rs.uniform(-2, 2, size=(n, 1))).astype(np.float32)
         Q = Q * (10.0 ** rs.uniform(-2, 2, size=(NQ, 1))).astype(np.float32)
+    # ---- directed adversarial shapes (VERDICT r03 "Next" 5c): where a wrong model of the MFMA's internal accumulation shows first
+    elif kind == "cancel":         # alternating-sign, nearly cancelling products: the sum is ~2^-10 of sum|terms|
+        X, Q = np.abs(X) + 0.5, np.abs(Q) + 0.5
+        X[:, 1::2] = X[:, 0:d - (d % 2):2] * (1.0 + rs.uniform(-1, 1, size=(n, d // 2)).astype(np.float32) * 2.0 ** -10)
+        Q[:, 1::2] = -Q[:, 0:d - (d % 2):2]
+    elif kind == "one_huge":       # one term 2^14 x the rest (a different coordinate per row / query: some pairs meet, most do not)
+        X *= np.float32(2.0 ** -14)
+        Q *= np.float32(2.0 ** -14)
+        X[np.arange(n), rs.randint(0, d, size=n)] = rs.choice([-1.0, 1.0], size=n).astype(np.float32)
+        Q[np.arange(NQ), rs.randint(0, d, size=NQ)] = rs.choice([-1.0, 1.0], size=NQ).astype(np.float32)
+    elif kind == "subnormal":      # every fp16 image but one per index / per query is SUBNORMAL (or flushed to 0 by the rounding)
+        X = X * np.exp2(rs.randint(-24, -15, size=X.shape)).astype(np.float32)
+        Q = Q * np.exp2(rs.randint(-24, -15, size=Q.shape)).astype(np.float32)
+        X[0, 0] = 0.75             # sets the index's power-of-two scale: everything else lies 2^15 .. 2^24 below it
+        Q[:, 0] = 0.75             # ... and every query's
+    elif kind == "edge_half":      # max |x'| EXACTLY 0.5 (the index's and every query's largest magnitude is a power of two)
+        X = np.clip(X, -3.9, 3.9) / np.float32(4.0)
+        Q = np.clip(Q, -3.9, 3.9) / np.float32(4.0)
+        X[0, 0] = 1.0
+        Q[:, 0] = -1.0
+    elif kind == "edge_one":       # max |x'| just below 1: the largest binary32 below a power of two (its fp16 image rounds UP to 1.0)
+        X = np.clip(X, -3.9, 3.9) / np.float32(4.0)
+        Q = np.clip(Q, -3.9, 3.9) / np.float32(4.0)
+        X[0, 0] = np.nextafter(np.float32(1.0), np.float32(0.0))
+        Q[:, 0] = np.nextafter(np.float32(1.0), np.float32(0.0))
     else:
         raise ValueError(kind)
     if kind in ("gauss", "positive"):
@@ -57,6 +84,8 @@ def make(kind, d, seed):
 CASES = [(k, d) for d in (768, 2048, 4096) for k in ("gauss", "positive", "binade_up", "binade_down", "binade_mix", "scales")]
 # d <= 128: the low-dimensional kernels (lmi_pass2_small.h), K padded to whole k16-groups (45 -> 48, 100 -> 112)
 CASES += [(k, d) for d in (45, 100, 128) for k in ("gauss", "positive", "binade_mix", "scales")]
+# directed adversarial shapes at K = 16 / 32 / 48 (one to three MFMA k-steps: the low-dimensional kernels) and 768 (pass2_kernel)
+CASES += [(k, d) for d in (16, 32, 48, 768) for k in ("cancel", "one_huge", "subnormal", "edge_half", "edge_one")]
 
 
 @pytest.mark.parametrize("kind,d", CASES)

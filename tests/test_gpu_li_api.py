@@ -236,3 +236,45 @@ def test_resident_cache_key_and_query_chunks(oracle):
     li.search(df, Qn, df, Qs, dp_sw, [12], 3, 10)
     assert li._engine is not eng
     li.close()
+
+
+def test_in_place_edit_of_any_row_is_never_answered_from_the_stale_copy(oracle):
+    """the reference re-reads its frames on every call (LearnedIndex.py:350-357).  By default the resident copy is
+    keyed on EVERY byte of the scan frame: an in-place edit of a row no sample would see rebuilds it; a frame with equal content
+    but another identity / memory layout does not; `assume_unchanged=True` and `strict_cache=False` are the documented opt-outs."""
+    g = load_golden("G1")
+    Xn, Qn, Xs, Qs = inputs_for("G1", g)
+    li, _ = make_index("G1", g)
+    dp = g["data_prediction"].astype(np.int64)
+    df = frame(Xs.copy())
+    d, n, _ = li.search(df, Qn, df, Qs, dp, [12], 3, 10)
+    eng = li._engine
+    li.search(df.copy(), Qn, df[list(df.columns)], Qs, dp, [12], 3, 10)      # fresh objects, equal content: no rebuild
+    assert li._engine is eng
+    row = int(np.setdiff1d(np.arange(Xs.shape[0]), np.unique(np.linspace(0, Xs.shape[0] - 1, num=4096, dtype=np.int64)))[100])
+    bo = oracle.precompute_bucket_order(layers_from(g), Qn, 3, nthreads=4)[:, :, 0]
+    qv = int(np.flatnonzero(bo[:, 0] == dp[row, 0])[0])                       # a query whose first bucket holds that row
+    df.iloc[row, :] = Qs[qv]                                                  # a row the sampled fingerprint does not look at
+    d_stale, n_stale, _ = li.search(df, Qn, df, Qs, dp, [12], 3, 10, assume_unchanged=True)
+    assert li._engine is eng                                                  # the caller vouched: answered from the resident copy
+    np.testing.assert_array_equal(n_stale, n)
+    d2, n2, _ = li.search(df, Qn, df, Qs, dp, [12], 3, 10)                    # default: every byte fingerprinted -> rebuilt
+    assert li._engine is not eng
+    X2 = Xs.copy()
+    X2[row] = Qs[qv]
+    do, no, _ = oracle.search(layers_from(g), Qn, X2, Qs, dp, 3, 10, nthreads=4)
+    np.testing.assert_array_equal(n2, no)
+    np.testing.assert_array_equal(d2, do)
+    assert n2[qv, 0] == df.index[row] and n[qv, 0] != df.index[row]          # (that query now finds its own copy first)
+    # the sampled mode (what frames above 1 GiB get unless strict_cache is True) does not see such an edit: documented, opt-in
+    li.strict_cache = False
+    li.search(df, Qn, df, Qs, dp, [12], 3, 10)
+    eng = li._engine
+    df.iloc[row, :] = Xs[row]
+    li.search(df, Qn, df, Qs, dp, [12], 3, 10)
+    assert li._engine is eng
+    li.strict_cache = True
+    d3, n3, _ = li.search(df, Qn, df, Qs, dp, [12], 3, 10)
+    assert li._engine is not eng
+    np.testing.assert_array_equal(n3, n)
+    li.close()

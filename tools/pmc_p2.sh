@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 # Developer aid (GPU box): SQ counter passes of the pass-2 kernel of bench.py.
-#   bash tools/pmc_p2.sh out_dir [kernel-regex]        (LMI_LIB / LMI_PF_V1 select the build / the round-2 kernel)
+
 set -uo pipefail
 export TMPDIR=/tmp
 out="$PWD/$1"; K="${2:-pass2_kernel<false}"
