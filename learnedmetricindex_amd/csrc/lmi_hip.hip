@@ -969,7 +969,7 @@ static int rescore_group_size(int nb) { return nb % 4 == 0 ? 4 : nb % 3 == 0 ? 3
 template <bool SAMPLE>
 static int launch_pass2(lmi_index* h, const PrefilterParams& F) {
     if (h->pf_small && F.KG16 <= PS_MAXKG) {
-        const int grid = h->num_cus * ps_blocks_per_cu(F.KG16), lds = ps_lds_bytes(F.KG16);
+        const int grid = h->num_cus * ps_blocks_per_cu(F.KG16), lds = ps_lds_bytes(F.KG16) - (SAMPLE ? ps_spill_bytes(F.KG16) : 0);
 #define LMI_PS_CASE(K) case K: pass2_small_kernel<K, SAMPLE><<<grid, 64 * PS_WAVES, lds, h->stream>>>(F); break;
         switch (F.KG16) {
             LMI_PS_CASE(1) LMI_PS_CASE(2) LMI_PS_CASE(3) LMI_PS_CASE(4) LMI_PS_CASE(5) LMI_PS_CASE(6) LMI_PS_CASE(7) LMI_PS_CASE(8)

@@ -70,6 +70,8 @@ def main():
           "ms; prefilter stats", idx.prefilter_stats(), "scan stats", idx.scan_stats())
     raw = idx.debug_peek("pf_stamps", 8 * 12 * 8).view(np.uint64).reshape(8, 12).astype(np.float64)
     names = ["wait", "bar", "stage", "epi", "start", "end"]
+    if args.d <= 128:   # the low-dimensional kernel's phases (lmi_pass2_small.h, PS_STAMP)
+        names = ["start", "ldwait", "blocks", "drain", "end", "-"]
     tiles = raw[:, 7]
     print(f"-- {tiles[0]:.0f} tiles per wave (all CUs), {raw[:, :6].sum(axis=1).mean() / max(1.0, tiles[0]):.0f} cycles per tile and wave")
     print("   wave " + " ".join(f"{n:>7s}" for n in names) + "   cycles/tile: " + " ".join(f"{n:>7s}" for n in names))
