@@ -140,6 +140,9 @@ struct lmi_index {
     int dp = 0;   // row pitch (floats) of `rowmajor`
     DevBuf slab16, rowmajor, xscale, xmaxbits, bnorm, bdelta, qdelta;
     DevBuf qnorm, qscale, qfrag16, eps2, cand_cnt, cand_row, cand_s, fallback, pf_bound, nkeep, surv_row, rs_flag, rs_active;
+    DevBuf x_log, x_ext, x_off, fb_list;  // the candidates' overflow log, its by-column sorted form and offsets (lmi_prefilter.h, OverflowLog);
+                                          // the fallback list: [count, fail0, fail1, log head, sorted total, pad x 3 | nslots slots]
+    unsigned x_cap = 0;                   // entries of the log (0: not allocated yet)
     DevBuf redo;   // [1] count | [L] bucket flags | [columns] column flags (bytes): overflow_rebound_kernel
     size_t stamps_off = 0;         // developer builds: byte offset of the phase stamps inside pf_bound
     bool pf_small = true;          // d <= 128: pass2_small_kernel (LMI_PF_SMALL=0 in the environment: pass2_kernel for every d)
@@ -265,7 +268,7 @@ extern "C" LMI_API int lmi_destroy(lmi_index* h) {
                       &h->act[0], &h->act[1], &h->xfrag, &h->logits, &h->order, &h->q_nav, &h->q_srch, &h->m,
                       &h->cb_start, &h->item_base, &h->part_base, &h->stats, &h->head, &h->slot_local,
                       &h->slot_col, &h->colmap, &h->qfrag, &h->grp, &h->col_thr, &h->slab16, &h->rowmajor, &h->xscale, &h->xmaxbits, &h->bnorm, &h->bdelta, &h->qdelta, &h->qnorm, &h->qscale, &h->qfrag16, &h->eps2, &h->cand_cnt, &h->cand_row, &h->cand_s, &h->fallback, &h->pf_bound, &h->nkeep, &h->redo, &h->part_score, &h->part_row, &h->rank_d,
-                      &h->rank_id, &h->out_d, &h->out_id, &h->out_key};
+                      &h->rank_id, &h->out_d, &h->out_id, &h->out_key, &h->x_log, &h->x_ext, &h->x_off, &h->fb_list};
     for (DevBuf* b : bufs) b->release();
     for (auto& m : h->node_models) { for (auto& b : m.Wf) b.release(); for (auto& b : m.bias) b.release(); }
     DevBuf* nav[] = {&h->d_models, &h->d_child_offset, &h->d_child_model, &h->d_child_bucket, &h->pq_prob, &h->pq_ent, &h->pq_len, &h->surv_row, &h->rs_flag, &h->rs_active, &h->gather_send, &h->gather_recv, &h->aug_rows, &h->q_aug, &h->qn2,
@@ -305,8 +308,9 @@ extern "C" LMI_API int lmi_clone_view(lmi_index* h, lmi_index** out) {
                      &c->surv_row, &c->rs_flag, &c->rs_active, &c->act[0], &c->act[1], &c->xfrag, &c->logits, &c->order, &c->q_nav,
                      &c->q_srch, &c->m, &c->cb_start, &c->item_base, &c->part_base, &c->stats, &c->head, &c->slot_local, &c->slot_col,
                      &c->colmap, &c->qfrag, &c->grp, &c->col_thr, &c->part_score, &c->part_row, &c->rank_d, &c->rank_id, &c->out_d,
-                     &c->out_id, &c->out_key};
+                     &c->out_id, &c->out_key, &c->x_log, &c->x_ext, &c->x_off, &c->fb_list};
     for (DevBuf* b : own) b->forget();
+    c->x_cap = 0;
     memset(c->ev_ring, 0, sizeof(c->ev_ring));
     memset(c->valid_ring, 0, sizeof(c->valid_ring));
     c->ev_cur = 0; c->ev_calls = 0;
@@ -1074,6 +1078,15 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         fill(h->stats.as<long long>() + 2, 4, 0u);
         CHK(h->redo.reserve((size_t)(1 + L) * 4 + ncols));
         fill(h->redo.p, (long long)(1 + L) + (long long)((ncols + 3) / 4), 0u);
+        CHK(h->fb_list.reserve((size_t)(8 + nslots) * 4));
+        fill(h->fb_list.p, 8, 0u);   // fallback count, fail flags of the two pass-2 launches, log head, sorted total
+        if (h->x_cap == 0) {         // the overflow log (16 B an entry) and its sorted form (8 B): allocated with the first prefilter batch
+            const size_t cap = (size_t)1 << LMI_PF_X_LOG2;
+            CHK(h->x_log.reserve(cap * 16));
+            CHK(h->x_ext.reserve(cap * 8));
+            h->x_cap = (unsigned)cap;
+        }
+        CHK(h->x_off.reserve(ncols * 4));
         if (rescore_is_streamed(h)) {   // the streamed re-rank's flags and list counters (lmi_rescore.h): zeroed here, not by a launch of their own
             const int groups = nslots / rescore_group_size(nb), sub_cap = cdiv(groups, RC_SUB);
             CHK(h->rs_flag.reserve((size_t)groups * 4));
@@ -1172,6 +1185,12 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         F.cand_row = h->cand_row.as<unsigned>();
         F.cand_s = h->cand_s.as<float>();
         F.redo_count = nullptr; F.redo_bucket = nullptr; F.redo_col = nullptr;
+        unsigned* fbw = h->fb_list.as<unsigned>();   // [0] fallback count, [1] / [2] fail flags, [3] log head, [4] sorted total
+        F.x.log = h->x_log.as<uint4>();
+        F.x.cap = h->x_cap;
+        F.x.head = fbw + 3;
+        F.x.fail = fbw + 1;
+        F.x.launch = 0;
         h->stamps_off = (ncols * P2_NSL * 16 * 4 + 255) / 256 * 256;
         F.stamps = reinterpret_cast<unsigned long long*>(static_cast<char*>(h->pf_bound.p) + h->stamps_off);
 #if defined(LMI_P2_STAMPS)
@@ -1205,9 +1224,12 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
             int* rb = reinterpret_cast<int*>(rc + 1);
             unsigned char* rcol = reinterpret_cast<unsigned char*>(rc + 1 + L);
             overflow_rebound_kernel<<<cdiv(nslots, 256), 256, 0, h->stream>>>(h->slot_col.as<int>(), d_order, nslots, F.cand_cnt, F.cand_s,
-                                                                             F.bound1, rc, rb, rcol);
+                                                                             F.bound1, rc, rb, rcol, F.x.fail, F.x.cap, h->x_off.as<unsigned>(), fbw + 4);
             HIPCHK(hipGetLastError());
             PrefilterParams F2 = F;
+            F2.x.cap = 0;          // (only runs when the first launch filled the log: what overflows again takes the exact fallback)
+            F2.x.fail = fbw + 2;
+            F2.x.launch = 1;
             F2.head = F.head + 16;
             F2.redo_count = rc; F2.redo_bucket = rb; F2.redo_col = rcol;
             CHK(launch_pass2<false>(h, F2));
@@ -1234,6 +1256,16 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         Q.rank_id = h->rank_id.as<unsigned>();
         Q.fallback = h->fallback.as<int>();
         Q.nkeep = h->nkeep.as<int>();
+        Q.fb_count = reinterpret_cast<int*>(fbw);
+        Q.fb_list = reinterpret_cast<int*>(fbw + 8);
+        const bool sorted_overflow = h->pf_redo && !h->debug_emit_all;   // (overflow_rebound_kernel hands out the ranges)
+        Q.x_fail = fbw + 1;
+        Q.x_off = sorted_overflow ? h->x_off.as<unsigned>() : nullptr;
+        Q.x_ext = h->x_ext.as<uint2>();
+        Q.x_log = F.x.log;
+        Q.x_head = F.x.head;
+        Q.x_cap = F.x.cap;
+        Q.redo_col = sorted_overflow ? reinterpret_cast<const unsigned char*>(h->redo.as<unsigned>() + 1 + L) : nullptr;
 #ifndef LMI_ABL_NOEMIT  // timing-only ablation builds emit nothing: no re-rank, no fallback
         if (rescore_is_streamed(h)) {
             // selection at full occupancy, then the survivors' rows streamed through LDS in coalesced pieces (lmi_rescore.h)
@@ -1265,7 +1297,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
 #endif
         CHK(record(h, 7));
 #ifndef LMI_ABL_NOEMIT
-        fallback_kernel<<<cdiv(nslots, 256), 256, 0, h->stream>>>(Q);
+        fallback_kernel<<<std::min(cdiv(nslots, 4), h->num_cus * 4), 256, 0, h->stream>>>(Q);
         HIPCHK(hipGetLastError());
 #endif
         CHK(record(h, 3));
@@ -1326,6 +1358,7 @@ extern "C" LMI_API int lmi_workspace_bytes(lmi_index* h, int nq, int nb, int64_t
         t += ncols * (4 + 4 + 2ll * PF_CAP * 4 + 1);             // eps2, candidate counts + buffers, redo flags
         t += ncols * P2_NSL * 16 * 4 + 4096;                     // pass-1 lists
         t += nslots * (4 + 4 + (long long)RC_KEEP * 4) + nslots; // fallback, nkeep, survivor rows, re-rank lists
+        t += nslots * 4 + 32 + ncols * 4;                        // fallback list, overflow offsets (the 96-MiB overflow log is per handle, not per call)
     } else {
         t += std::max<long long>(1, (long long)nb * max_nch * nq) * KPB * 8;   // chunk partial lists of the exact scan
     }
@@ -1830,6 +1863,9 @@ extern "C" LMI_API int lmi_debug_peek(lmi_index* h, const char* name, void* dst,
         return 0;
     }
     if (!strcmp(name, "pf_redo")) b = &h->redo;   // [0]: columns whose candidate buffer overflowed in the last scan (second run of pass 2)
+    // 32 bytes: [0] slots fallback_kernel handled, [1] / [2] fail flags of the overflow log (pass 2 / its redo launch), [3] entries
+    // appended to the log, [4] entries sorted by column, [5] slots that scanned their WHOLE bucket (the rest re-scored candidates)
+    if (!strcmp(name, "pf_fallback")) b = &h->fb_list;
     if (!b) return fail("lmi_debug_peek: unknown buffer '%s'", name);
     if (bytes < 0 || off + (size_t)bytes > b->cap) return fail("lmi_debug_peek: %lld bytes asked of a %zu-byte buffer", (long long)bytes, b->cap);
     if (bytes) HIPCHK(hipMemcpy(dst, static_cast<char*>(b->p) + off, (size_t)bytes, hipMemcpyDeviceToHost));

@@ -255,12 +255,11 @@ struct Tile2 {
         // (two stages of the next tile are in flight: 2 PA vector loads, the loaders' 2 PBL pieces on top)
         if (is_loader()) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(pend_pos) : "n"(2 * (PA + PBL)) : "memory");
         else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(pend_pos) : "n"(2 * PA) : "memory");
-        if (pend_pos < (unsigned)PF_CAP) {
+        if (pend_pos != 0xffffffffu) {
             u32x4 e;
             const unsigned pa = (unsigned)reinterpret_cast<uintptr_t>(sPend + w * 64) + (unsigned)ln * 16u;
             asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(e) : "v"(pa) : "memory");
-            P.cand_row[(size_t)e.x * PF_CAP + pend_pos] = e.y;
-            P.cand_s[(size_t)e.x * PF_CAP + pend_pos] = __uint_as_float(e.z);
+            cand_store(P, (size_t)e.x, pend_pos, e.y, __uint_as_float(e.z));   // (past the column's buffer: the shared overflow log)
         }
         pend_pos = 0xffffffffu;
     }
@@ -270,7 +269,6 @@ struct Tile2 {
     __device__ __forceinline__ void epilogue_emit(int rb_tile0, int n_b, size_t col0) {
         const int ln = lane_id();
         const int hh = ln >> 5, cc = ln & 31;
-        flush_pending(ln);
 #ifdef LMI_ABL_NOEPI   // timing-only ablation: the tile's scores are never tested (no candidates: wrong results)
 #pragma unroll
         for (int n = 0; n < NCB; ++n) asm volatile("" :: "v"(acc[n]));
@@ -338,6 +336,9 @@ struct Tile2 {
                 }
             }
         }
+        // the PREVIOUS tile's candidates (their position atomics have long returned) leave here, behind the tests: the accumulators are
+        // dead now, the stores' / the overflow log's temporaries cost the epilogue no spill; the wave's sPend entries are free after it
+        flush_pending(ln);
         if (tot > 0 && tot <= 64) {
             if (ln < tot) {
                 u32x2 e;
@@ -366,10 +367,7 @@ struct Tile2 {
                     if (acc[n][r] >= thr) {
                         const size_t col = col0 + n * 32 + cc;
                         const unsigned pos = atomicAdd(P.cand_cnt + col, 1u);
-                        if (pos < (unsigned)PF_CAP) {
-                            P.cand_row[col * PF_CAP + pos] = rowh + (unsigned)((r & 3) + 8 * (r >> 2));
-                            P.cand_s[col * PF_CAP + pos] = acc[n][r];
-                        }
+                        cand_store(P, col, pos, rowh + (unsigned)((r & 3) + 8 * (r >> 2)), acc[n][r]);
                     }
             }
         }

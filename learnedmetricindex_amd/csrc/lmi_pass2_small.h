@@ -50,7 +50,7 @@ constexpr int PS_PREFIX_CAP = 257;   // buckets + 1 of a queue group held in LDS
 #define LMI_PS_BLOCKS4 2   // blocks per CU at KG <= 4 (LDS allows 3, but pass 2 then has 168 registers and spills 175: 0.47 -> 1.06 ms)
 #endif
 __host__ __device__ constexpr int ps_blocks_per_cu(int kg) { return kg <= 4 ? LMI_PS_BLOCKS4 : kg <= 6 ? 2 : 1; }   // LDS: 160 KiB per CU
-static_assert(2 * (ps_lds_bytes(6) + 4096) <= 160 * 1024 && 2 * (ps_lds_bytes(4) + 4096) <= 160 * 1024 && ps_lds_bytes(PS_MAXKG) + 4096 <= 160 * 1024, "LDS budget (dynamic + ~3 KiB static)");
+static_assert(PS_SPILL >= 128 - 32 && 2 * (ps_lds_bytes(6) + 4096) <= 160 * 1024 && 2 * (ps_lds_bytes(4) + 4096) <= 160 * 1024 && ps_lds_bytes(PS_MAXKG) + 4096 <= 160 * 1024, "LDS budget (dynamic + ~3 KiB static)");
 
 template <int KG, bool SAMPLE>
 __global__ __launch_bounds__(64 * PS_WAVES, ps_blocks_per_cu(KG) * PS_WAVES / 4) void pass2_small_kernel(PrefilterParams P) {
@@ -73,16 +73,10 @@ __global__ __launch_bounds__(64 * PS_WAVES, ps_blocks_per_cu(KG) * PS_WAVES / 4)
     size_t pend_col = 0, pend2_col = 0;
     float pend_s = 0.0f, pend2_s = 0.0f;
     auto flush_pending = [&]() __attribute__((always_inline)) {
-        if (pend_pos < (unsigned)PF_CAP) {
-            P.cand_row[pend_col * PF_CAP + pend_pos] = pend_row;
-            P.cand_s[pend_col * PF_CAP + pend_pos] = pend_s;
-        }
+        if (pend_pos != 0xffffffffu) cand_store(P, pend_col, pend_pos, pend_row, pend_s);
         pend_pos = 0xffffffffu;
         if (SPILL) {
-            if (pend2_pos < (unsigned)PF_CAP) {
-                P.cand_row[pend2_col * PF_CAP + pend2_pos] = pend2_row;
-                P.cand_s[pend2_col * PF_CAP + pend2_pos] = pend2_s;
-            }
+            if (pend2_pos != 0xffffffffu) cand_store(P, pend2_col, pend2_pos, pend2_row, pend2_s);
             pend2_pos = 0xffffffffu;
         }
     };
@@ -204,10 +198,7 @@ __global__ __launch_bounds__(64 * PS_WAVES, ps_blocks_per_cu(KG) * PS_WAVES / 4)
                                 } else {   // a pair with more than 64 candidates: the rest goes out at once
                                     const size_t col = col0 + n * 32 + c;
                                     const unsigned pos = atomicAdd(P.cand_cnt + col, 1u);
-                                    if (pos < (unsigned)PF_CAP) {
-                                        P.cand_row[col * PF_CAP + pos] = (unsigned)(rb0 * 32) + row;
-                                        P.cand_s[col * PF_CAP + pos] = acc[4 * j + i];
-                                    }
+                                    cand_store(P, col, pos, (unsigned)(rb0 * 32) + row, acc[4 * j + i]);
                                 }
                             }
                             tot += (int)__popcll(mask);
@@ -233,39 +224,7 @@ __global__ __launch_bounds__(64 * PS_WAVES, ps_blocks_per_cu(KG) * PS_WAVES / 4)
         // a candidate of column `col` that cannot wait (ring full / a lane's third hit): position atomic and stores at once
         auto emit_now = [&](size_t col, unsigned row, float sc) __attribute__((always_inline)) {
             const unsigned pos = atomicAdd(P.cand_cnt + col, 1u);
-            if (pos < (unsigned)PF_CAP) {
-                P.cand_row[col * PF_CAP + pos] = row;
-                P.cand_s[col * PF_CAP + pos] = sc;
-            }
-        };
-        // K <= 64, pass 2: a lane whose block column holds a score >= thr parks its 16 scores in the wave's ring
-        auto spill = [&](const f32x16& acc, float mx, float thr, int rb, int n) __attribute__((always_inline)) {
-            bool any = mx >= thr;   // thr = +inf for idle columns, NaN (masked rows) never passes
-#ifdef LMI_ABL_NOEMIT
-            any = any && thr == 12345.678f;
-#endif
-            const unsigned long long mask = __ballot(any);
-            if (__builtin_expect(mask != 0ull, 0)) {
-                const int my = tot + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                const unsigned rowb = (unsigned)((rb - rb0) * 32 + 4 * h);   // the lane's first row, in the chunk
-                if (any) {
-                    if (my < PS_SPILL) {
-                        int slot = head + my;
-                        if (slot >= PS_SPILL) slot -= PS_SPILL;
-                        float4* e = my_spill + slot * 4;
-                        e[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-                        e[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-                        e[2] = make_float4(acc[8], acc[9], acc[10], acc[11]);
-                        e[3] = make_float4(acc[12], acc[13], acc[14], acc[15]);
-                        my_tag[slot] = (unsigned)(n * 32 + c) | (rowb << 9);
-                    } else {   // more than PS_SPILL hit lanes since the last drain: this lane's candidates go out at once
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            if (acc[r] >= thr) emit_now(col0 + n * 32 + c, (unsigned)(rb0 * 32) + rowb + (unsigned)((r & 3) + 8 * (r >> 2)), acc[r]);
-                    }
-                }
-                tot = min(tot + (int)__popcll(mask), PS_SPILL);
-            }
+            cand_store(P, col, pos, row, sc);
         };
         // ... and the wave drains up to 64 entries at a time, one per lane: the lane's hits (one, rarely two, hardly ever more) get their
         // position atomics now and their stores at the NEXT drain (pend / pend2)
@@ -311,6 +270,30 @@ __global__ __launch_bounds__(64 * PS_WAVES, ps_blocks_per_cu(KG) * PS_WAVES / 4)
             head += nbatch;
             if (head >= PS_SPILL) head -= PS_SPILL;
             tot -= nbatch;
+        };
+        // K <= 64, pass 2: a lane whose block column holds a score >= thr parks its 16 scores in the wave's ring (a block adds at most
+        // 64 entries: the ring is drained first whenever fewer than 64 are free)
+        auto spill = [&](const f32x16& acc, float mx, float thr, int rb, int n) __attribute__((always_inline)) {
+            bool any = mx >= thr;   // thr = +inf for idle columns, NaN (masked rows) never passes
+#ifdef LMI_ABL_NOEMIT
+            any = any && thr == 12345.678f;
+#endif
+            const unsigned long long mask = __ballot(any);
+            if (__builtin_expect(mask != 0ull, 0)) {
+                if (tot > PS_SPILL - 64) drain();
+                const int my = tot + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                if (any) {
+                    int slot = head + my;
+                    if (slot >= PS_SPILL) slot -= PS_SPILL;
+                    float4* e = my_spill + slot * 4;
+                    e[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                    e[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+                    e[2] = make_float4(acc[8], acc[9], acc[10], acc[11]);
+                    e[3] = make_float4(acc[12], acc[13], acc[14], acc[15]);
+                    my_tag[slot] = (unsigned)(n * 32 + c) | ((unsigned)((rb - rb0) * 32 + 4 * h) << 9);   // column in the tile | the lane's first row in the chunk
+                }
+                tot += (int)__popcll(mask);
+            }
         };
         // zero-padded rows past the bucket's end are not scores.  pass 1: -inf, the maximum ignores them; pass 2: NaN -- a bucket
         // of fewer than ten rows has the bound -inf, which -inf would pass, and NaN >= x is false

@@ -286,6 +286,32 @@ __global__ void slot_bound_kernel(const int* __restrict__ bucket_order, const in
 #define LMI_PF_A_AUX 0  // cache policy of the vector-fragment DMA (2 = nt)
 #endif
 
+// Where a column's candidates past its own PF_CAP entries go (round 4): ONE append-only log shared by all columns -- an entry is
+// (column, index past the buffer | launch << 31, row, score), a position comes from one bump atomic: a dozen instructions at the
+// emission sites (anything heavier inlined into their unrolled register loops sent the accumulators to scratch).  Behind pass 2
+// overflow_rebound_kernel gives every overflowed column a range of the sorted array (one bump atomic per column), the selection
+// kernel's blocks first scatter the log into those ranges (pf_x_scatter: nothing to do on an empty log -- every batch of the
+// bench), and fallback_kernel re-scores a slot with thousands of rows inside 2 eps' of its top ten (duplicate-heavy data) from
+// its candidates instead of brute-forcing its bucket.  A launch that found the log full sets its fail flag and is handled as
+// in round 3 (tighter bound + second run of pass 2 without a log, then the exact fallback).
+#ifndef LMI_PF_X_LOG2
+#define LMI_PF_X_LOG2 22   // 4 M entries: 64 MiB of log + 32 MiB sorted, per handle, allocated when first needed... (lmi_hip.hip)
+#endif
+struct OverflowLog {
+    uint4* log;          // [cap]
+    unsigned cap;        // 0: no log
+    unsigned* head;      // [1] entries appended by this batch's launches (may run past cap)
+    unsigned* fail;      // [1] this launch's flag: an append found the log full
+    unsigned launch;     // 0: pass 2, 1: its redo launch (the columns it emits again start from index 0)
+};
+__device__ __forceinline__ void pf_x_append(const OverflowLog& X, size_t col, unsigned e, unsigned row, float s) {
+    // (one bump atomic per lane; aggregating them per wave-instruction -- ballot, leader, shuffle -- was measured on duplicate-heavy
+    // batches of ~480 k appends: 2.9 against 3.0 ms, and it costs the scan kernels registers around every emission site)
+    const unsigned i = X.cap ? atomicAdd(X.head, 1u) : 0xffffffffu;
+    if (i < X.cap) X.log[i] = make_uint4((unsigned)col, e | (X.launch << 31), row, __float_as_uint(s));
+    else atomicOr(X.fail, 1u);
+}
+
 struct PrefilterParams {
     const uint4* slab16;
     const uint4* qfrag16;
@@ -317,7 +343,17 @@ struct PrefilterParams {
     const unsigned* redo_count;      // [1] columns to redo: 0 -> the launch returns at once
     const int* redo_bucket;          // [L] the bucket has such a column: its items are run again, the others skipped
     const unsigned char* redo_col;   // [columns] only these columns keep a finite threshold
+    OverflowLog x;                   // where a column's candidates past PF_CAP go
 };
+// a candidate of column `col` whose position atomic returned `pos`
+__device__ __forceinline__ void cand_store(const PrefilterParams& P, size_t col, unsigned pos, unsigned row, float s) {
+    if (__builtin_expect(pos < (unsigned)PF_CAP, 1)) {
+        P.cand_row[col * PF_CAP + pos] = row;
+        P.cand_s[col * PF_CAP + pos] = s;
+    } else {
+        pf_x_append(P.x, col, pos - (unsigned)PF_CAP, row, s);
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // Select + exact re-rank: one wave per (query, rank) slot.
@@ -349,7 +385,37 @@ struct RescoreParams {
     unsigned* rank_id;
     int* fallback;
     int* nkeep;  // [nslots] survivors re-scored (statistics; summed on request)
+    // fallback slots (select_kernel / rescore appends; fallback_kernel's blocks stride over the list) and where their candidates
+    // past PF_CAP are (the shared overflow table: epoch of the first pass-2 launch, + 1 for the redo launch's columns)
+    int* fb_list;              // [nslots]
+    int* fb_count;             // [1]
+    const unsigned* x_fail;    // [2] fail flags of pass 2 / its redo launch (an append found the overflow log full)
+    const unsigned* x_off;     // [columns] nullable: offset of the column's sorted overflow entries in x_ext (overflow_rebound_kernel)
+    uint2* x_ext;              // (row, score) of the candidates past PF_CAP, grouped by column, in emission order
+    const uint4* x_log;        // the batch's overflow log and its length (pf_x_scatter)
+    const unsigned* x_head;
+    unsigned x_cap;
+    const unsigned char* redo_col;   // [columns] nullable: columns emitted again by the redo launch
 };
+
+// The overflow log -> the columns' ranges of x_ext (every block of the selection kernel's grid calls this first; the ranges were
+// handed out by overflow_rebound_kernel; fallback_kernel, a later launch, reads them).  Empty log: one cached scalar load.
+__device__ __forceinline__ void pf_x_scatter(const RescoreParams& P, unsigned first, unsigned stride) {
+    if (!P.x_off || P.x_fail[0]) return;
+    const unsigned n = min(*P.x_head, P.x_cap);
+    for (unsigned i = first; i < n; i += stride) {
+        const uint4 e = P.x_log[i];
+        const unsigned col = e.x, idx = e.y & 0x7fffffffu;
+        if (idx + (unsigned)PF_CAP < P.cand_cnt[col]) P.x_ext[P.x_off[col] + idx] = make_uint2(e.z, e.w);
+    }
+}
+
+// flags slot p for fallback_kernel (called by one lane)
+__device__ __forceinline__ void flag_fallback(const RescoreParams& P, int p) {
+    P.fallback[p] = 1;
+    P.fb_list[atomicAdd(P.fb_count, 1)] = p;
+}
+
 
 // canonical similarity of slab row p with query qv[0..d): acc = fmaf(q[k], x[k], acc), k ascending
 __device__ __forceinline__ float exact_score(const float* __restrict__ rows, size_t p, const float* __restrict__ qv, int d, int pitch) {
@@ -399,6 +465,7 @@ constexpr int RS_WAVES = 4;
 constexpr int RS_MAXD = 1024;  // queries up to this many dims are staged in LDS (else read from L2)
 
 __global__ __launch_bounds__(64 * RS_WAVES) __attribute__((amdgpu_waves_per_eu(LMI_RS_WAVES_PER_EU))) void select_rescore_kernel(RescoreParams P) {
+    pf_x_scatter(P, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
     __shared__ unsigned keep_row[RS_WAVES][PF_KEEP];
     __shared__ __attribute__((aligned(16))) float qs[RS_WAVES][RS_MAXD];
     __shared__ unsigned sink[RS_WAVES][64];  // destination of the prefetching LDS-DMA loads (never read)
@@ -416,7 +483,7 @@ __global__ __launch_bounds__(64 * RS_WAVES) __attribute__((amdgpu_waves_per_eu(L
     }
     const unsigned cnt = P.cand_cnt[col];
     if (cnt > (unsigned)PF_CAP) {
-        if (lane == 0) P.fallback[p] = 1;
+        if (lane == 0) flag_fallback(P, p);
         return;
     }
     // stage the query (coalesced) while the candidates load
@@ -476,7 +543,7 @@ __global__ __launch_bounds__(64 * RS_WAVES) __attribute__((amdgpu_waves_per_eu(L
         }
     }
     if (nk > (unsigned)PF_KEEP) {
-        if (lane == 0) P.fallback[p] = 1;
+        if (lane == 0) flag_fallback(P, p);
         return;
     }
     if (lane == 0) P.nkeep[p] = (int)nk;
@@ -579,13 +646,21 @@ __global__ __launch_bounds__(64 * RS_WAVES) __attribute__((amdgpu_waves_per_eu(L
 // of their scores is a valid -- and much tighter -- lower bound of That.  The column gets that bound, an empty buffer and a
 // flag; pass 2 (pass2_kernel<false> / pass2_small_kernel<KG, false>) is launched once more and re-runs the buckets that hold such columns with every other
 // column's threshold at +inf.  Without this such a slot took the exact fallback (one block brute-forcing the bucket).
+// Round 4: when the launch's overflow log did not run full (x_cap != 0, fail flag clear) none of this is needed -- every column's
+// candidates are complete and fallback_kernel re-scores them.
 __global__ void overflow_rebound_kernel(const int* __restrict__ slot_col, const int* __restrict__ bucket_order, int nslots,
                                         unsigned* __restrict__ cand_cnt, const float* __restrict__ cand_s, float* __restrict__ bound1,
-                                        unsigned* __restrict__ redo_count, int* __restrict__ redo_bucket, unsigned char* __restrict__ redo_col) {
+                                        unsigned* __restrict__ redo_count, int* __restrict__ redo_bucket, unsigned char* __restrict__ redo_col,
+                                        const unsigned* __restrict__ x_fail, unsigned x_mask /* the log's capacity: 0 = none */,
+                                        unsigned* __restrict__ x_off, unsigned* __restrict__ x_total) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= nslots) return;
     const int col = slot_col[p];
     if (col < 0 || cand_cnt[col] <= (unsigned)PF_CAP) return;
+    if (x_mask != 0u && x_fail[0] == 0u) {   // everything past the buffer is in the overflow log: the column's range of the sorted array
+        x_off[col] = atomicAdd(x_total, cand_cnt[col] - (unsigned)PF_CAP);
+        return;
+    }
     float v[KPB];
 #pragma unroll
     for (int j = 0; j < KPB; ++j) v[j] = -INFINITY;
@@ -631,19 +706,12 @@ __global__ __launch_bounds__(256) void fallback_kernel(RescoreParams P) {
     __shared__ float fs[256 * KPB];
     __shared__ unsigned fr[256 * KPB];
     const int tid = threadIdx.x, lane = tid & 63;
-    // a block looks at 256 slots' flags at once and works through the flagged ones (a launch of one block
-    // per slot spent 13 us finding nothing to do)
-    __shared__ int todo[256], ntodo;
-    if (tid == 0) ntodo = 0;
-    __syncthreads();
-    {
-        const int mine = blockIdx.x * 256 + tid;
-        if (mine < P.nslots && P.fallback[mine]) todo[atomicAdd(&ntodo, 1)] = mine;
-    }
-    __syncthreads();
-    const int nt = ntodo;
-    for (int ti = 0; ti < nt; ++ti) {
-    const int p = todo[ti];
+    // the flagged slots are on a list (select_kernel / the re-rank append): the blocks stride over it -- one block per slot at a
+    // time, every block of the grid busy when thousands of slots are flagged (duplicate-heavy data); an empty list costs one
+    // round of blocks reading the count
+    const int nt = *P.fb_count;
+    for (int ti = blockIdx.x; ti < nt; ti += gridDim.x) {
+    const int p = P.fb_list[ti];
     const int b = P.bucket_order[p];
     const int rb0 = P.rb_start[b], n_b = P.nb_rows[b];
     const float* qv = P.q + (size_t)(p / P.nb) * P.d;
@@ -651,28 +719,36 @@ __global__ __launch_bounds__(256) void fallback_kernel(RescoreParams P) {
     unsigned id[KPB];
 #pragma unroll
     for (int j = 0; j < KPB; ++j) { v[j] = -INFINITY; id[j] = NOROW; }
-    // A slot whose candidate buffer did NOT overflow is here for its survivor count only (more rows within 2 eps' of its
-    // top-10 than the re-rank holds: hundreds of copies of a vector): its candidates are a complete superset of the
-    // canonical top-10, so re-scoring those <= PF_CAP rows is exact and ~100 x cheaper than the whole bucket.
+    // A slot whose candidates are COMPLETE is here for its survivor count only (more rows within 2 eps' of its top-10 than the
+    // re-rank holds: hundreds of copies of a vector): its candidates are a superset of the canonical top-10, so re-scoring
+    // them is exact and far cheaper than the whole bucket.  Complete = everything past the column's own PF_CAP entries made it
+    // into the overflow log (the launch that emitted the column never found it full) and was sorted by column behind pass 2.
     const int ccol = P.slot_col[p];
     const unsigned ccnt = ccol >= 0 ? P.cand_cnt[ccol] : 0xffffffffu;
-    if (ccnt <= (unsigned)PF_CAP) {
-        const unsigned* cr = P.cand_row + (size_t)ccol * PF_CAP;
-        for (unsigned it = tid; it < ccnt; it += 256) {
-            const unsigned row = cr[it];
-            const float s = exact_score(P.rows, (size_t)rb0 * 32 + row, qv, P.d, P.dp);
-            if (better(s, row, v[KPB - 1], id[KPB - 1])) {  // candidates come in no order: ties by row here
+    const int launch = (P.redo_col && ccol >= 0 && P.redo_col[ccol]) ? 1 : 0;   // which pass-2 launch filled the column last
+    const bool in_table = ccol >= 0 && ccnt > (unsigned)PF_CAP && P.x_off != nullptr && launch == 0 && P.x_fail[0] == 0u;
+    auto consider = [&](unsigned row) {
+        const float s = exact_score(P.rows, (size_t)rb0 * 32 + row, qv, P.d, P.dp);
+        if (better(s, row, v[KPB - 1], id[KPB - 1])) {  // candidates come in no order: ties by row here
 #pragma unroll
-                for (int t = KPB - 1; t > 0; --t) {   // list_insert with the (score desc, row asc) order
-                    const bool shift = better(s, row, v[t - 1], id[t - 1]);
-                    const bool here = better(s, row, v[t], id[t]);
-                    id[t] = shift ? id[t - 1] : (here ? row : id[t]);
-                    v[t] = shift ? v[t - 1] : (here ? s : v[t]);
-                }
-                if (better(s, row, v[0], id[0])) { v[0] = s; id[0] = row; }
+            for (int t = KPB - 1; t > 0; --t) {   // list_insert with the (score desc, row asc) order
+                const bool shift = better(s, row, v[t - 1], id[t - 1]);
+                const bool here = better(s, row, v[t], id[t]);
+                id[t] = shift ? id[t - 1] : (here ? row : id[t]);
+                v[t] = shift ? v[t - 1] : (here ? s : v[t]);
             }
+            if (better(s, row, v[0], id[0])) { v[0] = s; id[0] = row; }
+        }
+    };
+    if (ccnt <= (unsigned)PF_CAP || in_table) {
+        const unsigned* cr = P.cand_row + (size_t)ccol * PF_CAP;
+        for (unsigned it = tid; it < min(ccnt, (unsigned)PF_CAP); it += 256) consider(cr[it]);
+        if (in_table) {
+            const uint2* ext = P.x_ext + P.x_off[ccol];
+            for (unsigned e = tid; e < ccnt - (unsigned)PF_CAP; e += 256) consider(ext[e].x);
         }
     } else {
+    if (tid == 0) atomicAdd(P.fb_count + 5, 1);   // (statistics: slots that scan their whole bucket)
     for (unsigned row = tid; row < (unsigned)n_b; row += 256) {
         const float s = exact_score(P.rows, (size_t)rb0 * 32 + row, qv, P.d, P.dp);
         if (s > v[KPB - 1]) list_insert(v, id, s, row);  // rows ascend per thread: strict > keeps the earlier

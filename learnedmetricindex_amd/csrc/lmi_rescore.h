@@ -127,7 +127,7 @@ __device__ __forceinline__ void select_tail(const RescoreParams& P, const Select
         P.rank_id[(size_t)p * KPB + lane] = P.raw ? NOROW : P.ids_slab[(size_t)rb0 * 32 + (n_b - 1)];
     }
     if (lane == 0) {
-        if (nk > (unsigned)RC_KEEP) P.fallback[p] = 1;
+        if (nk > (unsigned)RC_KEEP) flag_fallback(P, p);
         else {
             P.nkeep[p] = (int)nk;
             if (nk > 0 && atomicExch(&O.grp_flag[p / O.G], 1) == 0) {
@@ -140,6 +140,7 @@ __device__ __forceinline__ void select_tail(const RescoreParams& P, const Select
 
 // That + survivors of one slot; unvisited slots get their (inf, 0) rank list here.
 __global__ __launch_bounds__(256) void select_kernel(RescoreParams P, SelectOut O) {
+    pf_x_scatter(P, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int p = blockIdx.x * 4 + wv;
     if (p >= P.nslots) return;
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256) void select_kernel(RescoreParams P, SelectOut 
     for (int i = 0; i < SPEC; ++i) { s_spec[i] = cs[lane + 64 * i]; r_spec[i] = cr[lane + 64 * i]; }
     const unsigned cnt = P.cand_cnt[col];
     if (cnt > (unsigned)PF_CAP) {
-        if (lane == 0) P.fallback[p] = 1;
+        if (lane == 0) flag_fallback(P, p);
         return;
     }
     if (cnt <= 64u) select_tail<1, SPEC>(P, O, p, col, lane, cnt, cs, cr, s_spec, r_spec);   // (the columns behind a query's primary one: a handful each)

@@ -156,13 +156,14 @@ def test_query_tile_shapes(capi, oracle, d):
     np.testing.assert_array_equal(d1[qsel], np.float32(1) - D)
 
 
-def test_duplicate_heavy_buckets_recover_without_fallback(capi, oracle):
-    """Every vector copied 100 times (1e-7 apart): far more than PF_CAP rows pass a column's sampled threshold.  The
-    overflowed columns get the 10th best STORED score as their bound and a second run of pass 2 (overflow_rebound_kernel),
-    the ~100 survivors per slot fit the streamed re-rank: (almost) no slot takes the exact fallback, results as always
-    identical to the all-f32 scan."""
+@pytest.mark.parametrize("dup,d", [(100, 64), (1000, 64), (1000, 160)])
+def test_duplicate_heavy_buckets_recover_without_fallback(capi, oracle, dup, d):
+    """Every vector copied 100 / 1 000 times (1e-7 apart): far more than PF_CAP rows pass a column's sampled threshold, and at
+    1 000 copies far more than PF_CAP lie within 2 eps' of a slot's top ten.  What does not fit a column's buffer goes to the
+    shared overflow log, is sorted by column behind pass 2 and re-scored from there (fallback_kernel's candidate path; d = 64:
+    the low-dimensional kernels, d = 160: pass2_kernel): results as always identical to the all-f32 scan."""
     rs = np.random.RandomState(21)
-    d, L, dup, U, nq, nb = 64, 4, 100, 1200, 160, 2
+    L, U, nq, nb = 4, 120_000 // dup, 160, 2
     base = rs.randn(U, d).astype(np.float32)
     base /= np.linalg.norm(base, axis=1, keepdims=True)
     X = np.repeat(base, dup, axis=0) + (1e-7 * rs.randn(U * dup, d)).astype(np.float32)
@@ -173,8 +174,17 @@ def test_duplicate_heavy_buckets_recover_without_fallback(capi, oracle):
     (d1, i1, sv, fb), (d0, i0, _, _) = both_modes(capi, X, labels, L, Q, order, chunk_rows=2048)
     np.testing.assert_array_equal(i1, i0)
     np.testing.assert_array_equal(d1, d0)
-    assert fb <= nq * nb // 20, f"{fb} of {nq * nb} slots fell back"
-    assert sv / (nq * nb) > 50   # the copies of the best vectors are all re-scored
+    # and no slot scanned its whole bucket: the flagged ones were re-scored from their (complete) candidates
+    idx = capi.Index(0, chunk_rows=2048)
+    idx.set_buckets(X, labels, L)
+    d2, i2 = idx.scan_topk(Q, order, 10)
+    st = idx.debug_peek("pf_fallback", 32).view(np.uint32)
+    idx.close()
+    np.testing.assert_array_equal(i2, i0)
+    assert st[1] == 0 and st[2] == 0, "the overflow log ran full"
+    assert st[5] == 0, f"{st[5]} of {nq * nb} slots brute-forced their bucket ({st[0]} flagged, {st[3]} overflow entries)"
+    if dup == 1000:
+        assert st[3] > 0 and st[0] > nq   # thousands of rows within 2 eps' of a slot's top ten: past the column buffers, into the log
 
 
 @pytest.mark.parametrize("d", [5, 29, 45, 64, 77, 96, 109, 128])
