@@ -178,9 +178,12 @@ class Workload:
         lib_comm = None
         if world > 1 and os.environ.get("LMI_BENCH_LIBCOMM"):  # result exchange by lmi_allgather_merge (RCCL inside the library)
             if getattr(self, "_lib_comm", None) is None:
+                wd = Watchdog(rank)
+                wd.arm("lmi_comm_init (RCCL inside the library)")
                 ids = [self.eng.comm_unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(ids, src=0)
                 self._lib_comm = eng.comm_init(rank, world, ids[0])
+                wd.done()
             lib_comm = self._lib_comm
         searcher = ShardedSearcher(eng, rank, world, shard_inference=shard_inference, lib_comm=lib_comm)
 
@@ -501,6 +504,84 @@ def dominant_roofline(args, cfg, res, sizes, owner, rank, capi, exact=None):
     return roof, flops, dom_s
 
 
+class Watchdog:
+    """Multi-rank bring-up must fail FAST and LOUDLY: the first time more than one RCCL rank exists is the driver's SCALE run, and
+    a rank stuck in communicator init or in the first collective would otherwise hang until the lease's own limit.  A daemon
+    thread ends THIS rank with a non-zero code when `phase` is not done within `seconds` (LMI_BENCH_WATCHDOG_S, default 60);
+    torchrun then ends the other ranks and `python bench.py --gpus N` returns that code.  (Exiting is fine for a process that has
+    touched the GPU; it must never be replaced by exec.)"""
+
+    def __init__(self, rank: int):
+        self.rank = rank
+        self.seconds = float(os.environ.get("LMI_BENCH_WATCHDOG_S", "60"))
+        self._timer = None
+
+    def arm(self, phase: str):
+        import threading
+
+        self.done()
+
+        def fire():
+            log(f"[bench] WATCHDOG rank {self.rank}: '{phase}' did not finish within {self.seconds:.0f} s -- exiting 86 "
+                f"(check RCCL / xGMI bring-up: NCCL_DEBUG=INFO, HSA_ENABLE_IPC_MODE_LEGACY=0, one process per GPU)")
+            sys.stderr.flush()
+            os._exit(86)
+
+        self._timer = threading.Timer(self.seconds, fire)
+        self._timer.daemon = True
+        self._timer.start()
+
+    def done(self):
+        if self._timer is not None:
+            self._timer.cancel()
+            self._timer = None
+
+
+def bring_up(rank: int, world: int, backend: str, dev, wd: "Watchdog", lib_engine=None):
+    """init_process_group + the FIRST collective under the watchdog, then who is there: every rank's device / bus id and the
+    RCCL version, logged by rank 0 before any index is built.  Returns {"rccl_ranks_seen", "rccl_version", "devices",
+    "lib_comm"} (lib_comm: the library's own ncclComm_t when LMI_BENCH_LIBCOMM=1 and an engine is given)."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    wd.arm(f"init_process_group({backend})")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(backend)
+    wd.arm("first all-reduce")
+    t = torch.ones(1, dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(t)
+    if backend == "nccl":
+        torch.cuda.synchronize()
+    seen = int(t.item())
+    wd.arm("all_gather_object of the ranks' devices")
+    mine = {"rank": rank, "pid": os.getpid(), "device": None, "pci_bus_id": None}
+    if dev is not None and getattr(dev, "type", "cpu") == "cuda":
+        pr = torch.cuda.get_device_properties(dev)
+        mine.update(device=f"{pr.name} #{dev.index}", pci_bus_id=getattr(pr, "pci_bus_id", None), hbm_gib=round(pr.total_memory / 2 ** 30, 1))
+    devices = [None] * world
+    dist.all_gather_object(devices, mine)
+    try:
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
+    except Exception:  # noqa: BLE001
+        ver = None
+    lib_comm = None
+    if lib_engine is not None and os.environ.get("LMI_BENCH_LIBCOMM"):   # result exchange by lmi_allgather_merge (RCCL inside the library)
+        wd.arm("lmi_comm_init (RCCL inside the library)")
+        ids = [lib_engine.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        lib_comm = lib_engine.comm_init(rank, world, ids[0])
+    wd.done()
+    if rank == 0:
+        log(f"[bench] {world} ranks up over {backend}" + (f" (RCCL {ver})" if ver else "") + f": first all-reduce saw {seen} ranks")
+        for d_ in devices:
+            log(f"[bench]   rank {d_['rank']}: pid {d_['pid']}, {d_['device']}, bus {d_['pci_bus_id']}")
+    assert seen == world, f"the first all-reduce saw {seen} of {world} ranks"
+    return {"rccl_ranks_seen": seen, "rccl_version": ver, "devices": devices, "lib_comm": lib_comm}
+
+
 def launch_ranks(n: int, argv) -> int:
     """`python bench.py --gpus N` outside a launcher: start the N ranks as a CHILD torchrun (one process per GPU) before this
     process has touched the GPU (no torch import, no HIP call so far -- a process that has initialised the GPU must
@@ -532,21 +613,39 @@ def launch_ranks(n: int, argv) -> int:
 
 
 def launch_check() -> None:
-    """LMI_BENCH_LAUNCH_CHECK=1: rendezvous + one all-reduce over gloo and a JSON line from rank 0, nothing else -- lets
-    the CPU test suite (no GPU) drive `python bench.py --gpus N` through launch_ranks end to end."""
-    import torch
+    """LMI_BENCH_LAUNCH_CHECK=1: the bring-up (rendezvous, first all-reduce, device roll call, watchdog) over gloo and a JSON line
+    from rank 0, nothing else -- lets the CPU test suite (no GPU) drive `python bench.py --gpus N` through launch_ranks end to end.
+    LMI_BENCH_LAUNCH_CHECK_FAIL_RANK / _HANG_RANK make one rank exit / never reach the first collective; LMI_BENCH_LIBCOMM=1 runs
+    the library-communicator branch of bring_up on a stand-in engine (the real one needs the GPU)."""
     import torch.distributed as dist
 
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("gloo")
-    rank, world = dist.get_rank(), dist.get_world_size()
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     fail = os.environ.get("LMI_BENCH_LAUNCH_CHECK_FAIL_RANK")
+    hang = os.environ.get("LMI_BENCH_LAUNCH_CHECK_HANG_RANK")
+    wd = Watchdog(rank)
+    if hang is not None and int(hang) == rank:
+        wd.arm("a rank that never reaches the first collective (test)")
+        time.sleep(3600)
     if fail is not None and int(fail) == rank:
         sys.exit(7)
-    t = torch.tensor([rank + 1], dtype=torch.int64)
-    dist.all_reduce(t)
+
+    class _StubEngine:   # the two calls bring_up makes on the library engine
+        inits = 0
+
+        @staticmethod
+        def comm_unique_id():
+            return bytes(range(128))
+
+        def comm_init(self, r, w, uid):
+            assert uid == bytes(range(128)) and 0 <= r < w
+            _StubEngine.inits += 1
+            return ("stub-comm", r, w)
+
+    eng = _StubEngine() if os.environ.get("LMI_BENCH_LIBCOMM") else None
+    up = bring_up(rank, world, "gloo", None, wd, lib_engine=eng)
     if rank == 0:
-        print(json.dumps({"launch_check": True, "world": world, "sum": int(t.item())}), flush=True)
+        print(json.dumps({"launch_check": True, "world": world, "sum": world * (world + 1) // 2, "rccl_ranks_seen": up["rccl_ranks_seen"],
+                          "lib_comm": None if up["lib_comm"] is None else list(up["lib_comm"])}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -619,12 +718,9 @@ def main():
         local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+    up = None
+    if world > 1:   # (the library communicator, when asked for, is set up by Workload.run: it needs the engine)
+        up = bring_up(rank, world, backend, dev, Watchdog(rank))
     if args.emulate_shard:
         assert world == 1, "--emulate-shard is a single-GPU diagnostic"
         args.no_cpu_baseline = args.no_recall = args.no_hard_leg = True
@@ -869,6 +965,9 @@ def main():
             "cpu_baseline": cpu,
             "resident": resident,
             "sharded_alt_mode": alt,
+            "rccl_ranks_seen": None if up is None else up["rccl_ranks_seen"],
+            "rccl_version": None if up is None else up["rccl_version"],
+            "rank_devices": None if up is None else up["devices"],
             "per_rank": per_rank,
             "hard_leg": hard,
             "exact_leg": exact_leg,

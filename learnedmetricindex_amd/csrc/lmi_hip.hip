@@ -173,6 +173,10 @@ struct lmi_index {
     bool stats_pending = false;
 };
 
+// which fp16 fragment shape the index and the queries are packed in: 16 x 32 for pass2_kernel, 32 x 16 for the low-dimensional kernels
+static int frag16x16(const lmi_index* h) { return (h->pf_small && h->KG16 <= PS_MAXKG) ? 0 : 1; }
+
+
 static int set_dev(lmi_index* h) {
     HIPCHK(hipSetDevice(h->device));
     return 0;
@@ -705,7 +709,7 @@ extern "C" LMI_API int lmi_buckets_end(lmi_index* h) {
         HIPCHK(hipGetLastError());
         const long long total = n_rows * h->KG16 * 2;
         convert16_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(h->rowmajor.as<float>(), h->d, h->dp, n_rows, h->KG16,
-                                                                 h->xscale.as<float>(), h->slab16.as<uint4>());
+                                                                 h->xscale.as<float>(), h->slab16.as<uint4>(), frag16x16(h));
         HIPCHK(hipGetLastError());
         dim3 g(64, h->L);
         bucket_norm_kernel<<<g, 256, 0, h->stream>>>(h->rowmajor.as<float>(), h->d, h->dp, h->d_rb_start.as<int>(),
@@ -1149,7 +1153,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         {
             long long total = (long long)ncols * h->KG16 * 2;
             pack_queries16_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(d_qs, h->d, h->colmap.as<int>(), (long long)ncols,
-                                                                          h->KG16, h->qscale.as<float>(), h->qfrag16.as<uint4>());
+                                                                          h->KG16, h->qscale.as<float>(), h->qfrag16.as<uint4>(), frag16x16(h));
             HIPCHK(hipGetLastError());
         }
         slot_bound_kernel<<<cdiv(nslots, 256), 256, 0, h->stream>>>(d_order, h->slot_col.as<int>(), nslots, nb, h->KG16 * 16,

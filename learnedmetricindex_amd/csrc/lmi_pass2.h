@@ -4,6 +4,11 @@
 // the tile's col-blocks (12 x 16 = 192 accumulator registers): a bucket chunk is one tile whenever <= 384 queries are routed to
 // the bucket, every wave does the same work for any number of col-blocks, and a 32-deep stage carries 2 NCB MFMAs per wave.
 //
+// MFMA shape (round 4): v_mfma_f32_16x16x32_f16 -- the 32 x 32 block of a wave and a col-block is four 16 x 16 tiles, a stage (32 k) is
+// one k-step; the index slab and the query fragments are packed as 16-row x 32-k fragments for it (convert16_kernel /
+// pack_queries16_kernel, lmi_prefilter.h).  Same flops, bytes and registers as round 3's 32x32x16 form, half the accumulator
+// read-modify-write per MAC: pass 2 is power-limited and the chip holds a higher clock on this shape (measured: -2 % time at C2).
+//
 // Operand paths (round 4).  A wave's vector fragments are PRIVATE to it (its row-block x the stage's two k-groups = 2 KiB), so
 // they need neither LDS nor a barrier: every wave loads them with two global_load_dwordx4 straight into registers, two stages
 // ahead, into one of three 8-register sets, and waits for them with a counted vmcnt.  hipcc cannot express a load that stays
@@ -45,7 +50,9 @@ constexpr int P2_TILE_RB = 8;                                            // row-
 constexpr int P2_TILE_ROWS = 32 * P2_TILE_RB;
 constexpr int P2_SLOT_BYTES = P2_MAXCB * P2_G * 1024;                    // 24 KiB per ring slot: the stage's query fragments
 constexpr int P2_RING = 3;
-constexpr int P2_NSL = 16;   // pass 1: lists per column (sampled tile j -> list j % P2_NSL), each 16 slot maxima
+constexpr int P2_NSL = 16;   // pass 1, low-dimensional kernels: lists per column (sampled tile j -> list j % P2_NSL), each 16 slot maxima
+constexpr int P2_NSL_BIG = 8;   // pass 1, pass2_kernel: 8 lists of 32 slot maxima (the 16x16 MFMA tile gives a lane 8 rows of a column, not 16)
+static_assert(P2_NSL * 16 == P2_NSL_BIG * 32, "bound_merge2_kernel reads 256 values per column either way");
 constexpr int P2_LIST = 64 + 1;
 // The vector-fragment register sets: v[P2_AREG0 + 8 s + 4 g .. + 3] = k-group g of the stage in ring slot s.  hipcc is kept
 // below P2_AREG0 by the kernels' amdgpu_num_vgpr attribute (= P2_AREG0 / 2: the attribute is per register-file half).
@@ -116,7 +123,10 @@ struct Tile2 {
     int lane, w;
     unsigned lds_lane;   // ring + lane * 16: the lane's LDS read address AND its byte offset in the vector loads (whose SGPR base has
                          // `ring` subtracted): one register for both
-    f32x16 acc[NCB];
+    // acc[n][rh][ch]: the 16 x 16 block (row half rh, column half ch) of col-block n; a lane holds column 16 ch + (lane & 15) and rows
+    // 16 rh + 4 (lane >> 4) + 0..3 of it (the C/D map of v_mfma_f32_16x16x32_f16)
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    f32x4v acc[NCB][2][2];
     half8 b[BR];         // query-fragment ring
     unsigned pend_pos;
 #ifdef LMI_P2_STAMPS
@@ -142,20 +152,27 @@ struct Tile2 {
         asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(y) : "n"(N) : "memory");
     }
 
-    // The MFMAs read their vector fragment from the reserved set by NAME (hipcc knows nothing of v[232:255]); being volatile asm
-    // they keep their program order against the fragment reads, the waits and the loads.  Consecutive MFMAs go to different
-    // accumulators (or chain C -> D on the same one): no wait states needed between them; the tile's epilogue is preceded by
-    // the states an MFMA result needs before a VALU read (end of run()'s K loop).
+    // Shape (round 4): v_mfma_f32_16x16x32_f16 -- a stage (32 k) is ONE k-step; the wave's 32 x 32 block of col-block n is four
+    // 16 x 16 MFMA tiles, its vector fragments are the two row halves (set registers +0: rows 0..15, +4: rows 16..31), a query
+    // fragment is one column half of a col-block (16 columns x 32 k) and feeds two MFMAs.  Same flops, bytes and registers as the
+    // 32x32x16 form of round 3, half the accumulator read-modify-write per MAC: the kernel is POWER-limited
+    // (profiles/r04_pass2_experiments.txt) and the chip holds a ~15 % higher clock on this shape.
+    // The MFMAs read their vector fragments from the reserved set by NAME (hipcc knows nothing of v[232:255]); being volatile asm
+    // they keep their program order against the fragment reads, the waits and the loads.  Neighbouring MFMAs go to different
+    // accumulators: no wait states needed between them; the tile's epilogue is preceded by the states an MFMA result needs
+    // before a VALU read (end of run()'s K loop).
     template <int SLOT, int QI>
-    __device__ __forceinline__ void mfma_q() {
-        constexpr int g = QI / NCB, n = QI % NCB, R = areg(SLOT, g);
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, v[%c2:%c3], %1, %0" : "+v"(acc[n]) : "v"(b[breg(SLOT, QI)]), "n"(R), "n"(R + 3));
+    __device__ __forceinline__ void mfma_q() {   // query fragment QI = (column half QI / NCB, col-block QI % NCB)
+        constexpr int ch = QI / NCB, n = QI % NCB, R = areg(SLOT, 0);
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, v[%c3:%c4], %2, %0\n\tv_mfma_f32_16x16x32_f16 %1, v[%c5:%c6], %2, %1"
+                     : "+v"(acc[n][0][ch]), "+v"(acc[n][1][ch]) : "v"(b[breg(SLOT, QI)]), "n"(R), "n"(R + 3), "n"(R + 4), "n"(R + 7));
     }
-    // the tile's first k-group starts the accumulators at 0 (srcC = the inline constant: no clearing pass, no zero registers)
+    // the tile's first stage starts the accumulators at 0 (srcC = the inline constant: no clearing pass, no zero registers)
     template <int SLOT, int QI>
     __device__ __forceinline__ void mfma_q0() {
-        constexpr int n = QI % NCB, R = areg(SLOT, 0);
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, v[%c2:%c3], %1, 0" : "=&v"(acc[n]) : "v"(b[breg(SLOT, QI)]), "n"(R), "n"(R + 3));
+        constexpr int ch = QI / NCB, n = QI % NCB, R = areg(SLOT, 0);
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, v[%c3:%c4], %2, 0\n\tv_mfma_f32_16x16x32_f16 %1, v[%c5:%c6], %2, 0"
+                     : "=&v"(acc[n][0][ch]), "=&v"(acc[n][1][ch]) : "v"(b[breg(SLOT, QI)]), "n"(R), "n"(R + 3), "n"(R + 4), "n"(R + 7));
     }
     template <int SLOT, int QI>
     __device__ __forceinline__ void read_b() {  // query fragment QI of the stage in ring slot SLOT
@@ -205,20 +222,26 @@ struct Tile2 {
     // stage left its last D MFMAs (they read set DST's k-group 1 and the b[] ring) to be issued here -- the vector loads into
     // DST follow them; `last`: this stage issues all of its own (tile end / dead stage next).
     template <int SLOT, int DST>
-    __device__ __forceinline__ void stage(const Stream& S, bool loader, bool pend, bool last, bool first) {
+    __device__ __forceinline__ void stage(const Stream& S, bool loader, bool pend, bool last, bool first, bool prev_first) {
         constexpr int PS = (SLOT + P2_RING - 1) % P2_RING;   // the previous stage's slot: its fragments' register numbering
         static_assert(PS == DST, "ring of three: the stage two ahead reuses the previous stage's slot");
         if (loader) dma_b<DST>(S);
         static_for<0, D>([&](auto i) {
             constexpr int I = decltype(i)::value;
-            if (pend) mfma_q<PS, Q - D + I>();
+            if (pend) {   // (every accumulator gets ONE MFMA per stage: all of the tile's first stage starts from 0, its deferred ones too)
+                if constexpr (PS == 0) {
+                    if (prev_first) mfma_q0<PS, Q - D + I>(); else mfma_q<PS, Q - D + I>();
+                } else {
+                    mfma_q<PS, Q - D + I>();
+                }
+            }
             read_b<SLOT, I>();
         });
         load_a<DST>(S);
         static_for<0, Q - D>([&](auto qi) {
             constexpr int q = decltype(qi)::value;
             lgkm_wait<younger(q)>(b[breg(SLOT, q)]);
-            if constexpr (SLOT == 0 && q < NCB) {
+            if constexpr (SLOT == 0) {
                 if (first) mfma_q0<SLOT, q>(); else mfma_q<SLOT, q>();
             } else {
                 mfma_q<SLOT, q>();
@@ -229,7 +252,7 @@ struct Tile2 {
             static_for<Q - D, Q>([&](auto qi) {
                 constexpr int q = decltype(qi)::value;
                 lgkm_wait<0>(b[breg(SLOT, q)]);
-                if constexpr (SLOT == 0 && q < NCB) {   // (one-stage tiles of one or two col-blocks)
+                if constexpr (SLOT == 0) {   // (one-stage tiles)
                     if (first) mfma_q0<SLOT, q>(); else mfma_q<SLOT, q>();
                 } else {
                     mfma_q<SLOT, q>();
@@ -265,73 +288,96 @@ struct Tile2 {
     }
 
     // pass 2: rows with shat >= threshold -> the slot's candidate buffer (compaction through a wave-private LDS list, one
-    // position atomic per candidate whose stores go out at the NEXT tile end; > 64 candidates in the tile: direct path)
+    // position atomic per candidate whose stores go out at the NEXT tile end; > 64 candidates in the tile: direct path).
+    // Lane (quad = lane >> 4, c16 = lane & 15) holds, per col-block n and column half ch, column 16 ch + c16 and the 8 rows
+    // 16 rh + 4 quad + r (rh = 0 / 1, r = 0..3).
     __device__ __forceinline__ void epilogue_emit(int rb_tile0, int n_b, size_t col0) {
         const int ln = lane_id();
-        const int hh = ln >> 5, cc = ln & 31;
+        const int quad = ln >> 4, c16 = ln & 15;
 #ifdef LMI_ABL_NOEPI   // timing-only ablation: the tile's scores are never tested (no candidates: wrong results)
 #pragma unroll
-        for (int n = 0; n < NCB; ++n) asm volatile("" :: "v"(acc[n]));
+        for (int n = 0; n < NCB; ++n) asm volatile("" :: "v"(acc[n][0][0]), "v"(acc[n][1][0]), "v"(acc[n][0][1]), "v"(acc[n][1][1]));
         return;
 #endif
         const unsigned row0 = (unsigned)((rb_tile0 + w) * 32);
         if (row0 + 32u > (unsigned)n_b) {  // wave-uniform: the bucket's ragged end (zero-padded / clamped rows never pass)
-            int lim = n_b - (int)row0 - 4 * hh;   // lane's rows (r & 3) + 8 (r >> 2) at or past `lim` are beyond the bucket
+            int lim = n_b - (int)row0 - 4 * quad;   // lane's rows 16 rh + r at or past `lim` are beyond the bucket
 #pragma unroll
             for (int n = 0; n < NCB; ++n) {
-                asm volatile("" : "+v"(lim));    // opaque per col-block: sixteen hoisted lane masks would cost 32 SGPRs in the K loop
+                asm volatile("" : "+v"(lim));    // opaque per col-block: hoisted lane masks would cost SGPRs in the K loop
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if ((r & 3) + 8 * (r >> 2) >= lim) acc[n][r] = __builtin_nanf("");
+                for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (16 * rh + r >= lim) { acc[n][rh][0][r] = __builtin_nanf(""); acc[n][rh][1][r] = __builtin_nanf(""); }
             }
         }
         const unsigned list_addr = (unsigned)reinterpret_cast<uintptr_t>(sList + w * P2_LIST);   // wave-uniform
         int tot = 0;  // wave-uniform
-        unsigned kb = (unsigned)((cc << 8) | (4 * hh));
-        const unsigned thr_addr = (unsigned)reinterpret_cast<uintptr_t>(sThr) + (unsigned)cc * 4u;
-        // all thresholds first (the operand registers of the K loop are free now): one LDS latency instead of NCB
-        float thr[NCB];
+        const unsigned kb = (unsigned)((c16 << 8) | (4 * quad));   // key = column in the tile << 8 | row in the row-block
+        const unsigned thr_addr = (unsigned)reinterpret_cast<uintptr_t>(sThr) + (unsigned)c16 * 4u;
+        // thresholds in batches of TB col-blocks (2 TB registers; all 2 NCB at once do not fit beside 192 accumulators): one LDS round
+        // trip per batch, the next batch requested before the current one is tested
+        constexpr int TB = 2;
+        float thr[2][TB][2];
+        auto thr_load = [&](int nb0, float (&t)[TB][2]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int n = 0; n < NCB; ++n) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(thr[n]) : "v"(thr_addr), "n"(n * 128) : "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int n = 0; n < NCB; ++n) asm volatile("" : "+v"(thr[n]));   // defined from here on
+            for (int i = 0; i < TB; ++i) {
+                const int n = min(nb0 + i, NCB - 1);
+                asm volatile("ds_read_b32 %0, %1" : "=v"(t[i][0]) : "v"(thr_addr + (unsigned)(n * 128)) : "memory");
+                asm volatile("ds_read_b32 %0, %1" : "=v"(t[i][1]) : "v"(thr_addr + (unsigned)(n * 128 + 64)) : "memory");
+            }
+        };
+        thr_load(0, thr[0]);
 #pragma unroll
         for (int n = 0; n < NCB; ++n) {
-            // About one score in a thousand passes (~40 candidates per column and bucket): four col-blocks in ten hold a candidate.
-            // Maxima of the four register groups (rows 8 j + 4 hh + 0..3) first: a col-block without one costs 10 max + 1 compare, one
-            // with a single candidate tests 4 group maxima + 4 registers, not 16.  v_max3 returns the other operands for a NaN.
-            float gm[4], t0, mall;
+            constexpr int dummy = 0; (void)dummy;
+            if (n % TB == 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t0) : "v"(acc[n][4 * j]), "v"(acc[n][4 * j + 1]), "v"(acc[n][4 * j + 2]));
-                asm("v_max_f32 %0, %1, %2" : "=v"(gm[j]) : "v"(t0), "v"(acc[n][4 * j + 3]));
+                for (int i = 0; i < TB; ++i) asm volatile("" : "+v"(thr[(n / TB) & 1][i][0]), "+v"(thr[(n / TB) & 1][i][1]));   // defined from here on
+                if (n + TB < NCB) thr_load(n + TB, thr[((n / TB) + 1) & 1]);
             }
-            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t0) : "v"(gm[0]), "v"(gm[1]), "v"(gm[2]));
-            asm("v_max_f32 %0, %1, %2" : "=v"(mall) : "v"(t0), "v"(gm[3]));
-            bool any = mall >= thr[n];
+            // About one score in a thousand passes (~40 candidates per column and bucket): four col-blocks in ten hold one.  Maxima of the
+            // four (row half, column half) groups of 4 values first, ONE branch per col-block: a col-block without a candidate costs
+            // 11 max + 2 compares.  v_max3 returns the other operands for a NaN.
+            float gm[2][2], t0, mh[2];
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+#pragma unroll
+                for (int rh = 0; rh < 2; ++rh) {
+                    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t0) : "v"(acc[n][rh][ch][0]), "v"(acc[n][rh][ch][1]), "v"(acc[n][rh][ch][2]));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(gm[ch][rh]) : "v"(t0), "v"(acc[n][rh][ch][3]));
+                }
+                asm("v_max_f32 %0, %1, %2" : "=v"(mh[ch]) : "v"(gm[ch][0]), "v"(gm[ch][1]));
+            }
+            const float th0 = thr[(n / TB) & 1][n % TB][0], th1 = thr[(n / TB) & 1][n % TB][1];
+            bool any = (mh[0] >= th0) | (mh[1] >= th1);
 #ifdef LMI_ABL_NOEMIT
-            any = any && thr[n] == 12345.678f;
+            any = any && th0 == 12345.678f;
 #endif
             if (__builtin_expect(__ballot(any) == 0ull, 1)) continue;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (__ballot(gm[j] >= thr[n]) == 0ull) continue;
+            for (int ch = 0; ch < 2; ++ch) {
+                const float th = ch ? th1 : th0;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = 4 * j + i;
-                    const bool pass = acc[n][r] >= thr[n];  // thr = +inf for idle columns, NaN scores never pass
-                    const unsigned long long mask = __ballot(pass);
-                    if (__builtin_expect(mask != 0ull, 0)) {
-                        if (pass) {
-                            const int my = tot + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                            const unsigned key = kb + (unsigned)(((n * 32) << 8) | ((r & 3) + 8 * (r >> 2)));
-                            const unsigned la = list_addr + (unsigned)min(my, 64) * 8u;
-                            const unsigned sb = __float_as_uint(acc[n][r]);
-                            const u32x2 ent = {key, sb};
-                            asm volatile("ds_write_b64 %0, %1" :: "v"(la), "v"(ent) : "memory");
+                for (int rh = 0; rh < 2; ++rh) {
+                    if (__ballot(gm[ch][rh] >= th) == 0ull) continue;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool pass = acc[n][rh][ch][r] >= th;  // thr = +inf for idle columns, NaN scores never pass
+                        const unsigned long long mask = __ballot(pass);
+                        if (__builtin_expect(mask != 0ull, 0)) {
+                            if (pass) {
+                                const int my = tot + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                                const unsigned key = kb + (unsigned)(((n * 32 + 16 * ch) << 8) | (16 * rh + r));
+                                const unsigned la = list_addr + (unsigned)min(my, 64) * 8u;
+                                const unsigned sb = __float_as_uint(acc[n][rh][ch][r]);
+                                const u32x2 ent = {key, sb};
+                                asm volatile("ds_write_b64 %0, %1" :: "v"(la), "v"(ent) : "memory");
+                            }
+                            tot += (int)__popcll(mask);
                         }
-                        tot += (int)__popcll(mask);
                     }
                 }
             }
@@ -359,52 +405,60 @@ struct Tile2 {
         } else if (tot > 64) {
 #pragma unroll
             for (int n = 0; n < NCB; ++n) {
-                const float thr = sThr[n * 32 + cc];
-                unsigned rowh = row0 + 4u * (unsigned)hh;
-                asm volatile("" : "+v"(rowh));   // the 16 row numbers are formed where they are used, not kept across the K loop
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (acc[n][r] >= thr) {
-                        const size_t col = col0 + n * 32 + cc;
-                        const unsigned pos = atomicAdd(P.cand_cnt + col, 1u);
-                        cand_store(P, col, pos, rowh + (unsigned)((r & 3) + 8 * (r >> 2)), acc[n][r]);
-                    }
+                for (int ch = 0; ch < 2; ++ch) {
+                    const float th = sThr[n * 32 + 16 * ch + c16];
+                    unsigned rowq = row0 + 4u * (unsigned)quad;
+                    asm volatile("" : "+v"(rowq));   // the row numbers are formed where they are used, not kept across the K loop
+#pragma unroll
+                    for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (acc[n][rh][ch][r] >= th) {
+                                const size_t col = col0 + n * 32 + 16 * ch + c16;
+                                const unsigned pos = atomicAdd(P.cand_cnt + col, 1u);
+                                cand_store(P, col, pos, rowq + (unsigned)(16 * rh + r), acc[n][rh][ch][r]);
+                            }
+                }
             }
         }
     }
 
-    // pass 1: per lane and col-block the maximum of its 16 scores -> bound[col][list][w * 2 + h]
+    // pass 1: per lane, col-block and column half the maximum of its 8 scores -> bound[list][slot = 4 (row-block in the tile) + quad][column]
+    // (32 slots per sampled tile, each the best of 8 rows; P2_NSL_BIG lists of them = the same 256 values per column that the
+    // low-dimensional kernels' 16 lists x 16 slots give bound_merge2_kernel)
     __device__ __forceinline__ void epilogue_sample(int rb_tile0, int n_b, size_t col0, int m_left, int list_j, bool use_atomic, int rb_in_tile) {
         const int ln = lane_id();
-        const int h = ln >> 5, c = ln & 31;
+        const int quad = ln >> 4, c16 = ln & 15;
         const unsigned row0 = (unsigned)((rb_tile0 + w) * 32);
         const bool ragged = row0 + 32u > (unsigned)n_b;
-        int lim = ragged ? n_b - (int)row0 - 4 * h : 64;
+        int lim = ragged ? n_b - (int)row0 - 4 * quad : 64;
 #pragma unroll
         for (int n = 0; n < NCB; ++n) {
             if (ragged) {
                 asm volatile("" : "+v"(lim));
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if ((r & 3) + 8 * (r >> 2) >= lim) acc[n][r] = -INFINITY;
+                for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (16 * rh + r >= lim) { acc[n][rh][0][r] = -INFINITY; acc[n][rh][1][r] = -INFINITY; }
             }
-            float m0, m1, m2, m3, m4;
-            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m0) : "v"(acc[n][0]), "v"(acc[n][1]), "v"(acc[n][2]));
-            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m1) : "v"(acc[n][3]), "v"(acc[n][4]), "v"(acc[n][5]));
-            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m2) : "v"(acc[n][6]), "v"(acc[n][7]), "v"(acc[n][8]));
-            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m3) : "v"(acc[n][9]), "v"(acc[n][10]), "v"(acc[n][11]));
-            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m4) : "v"(acc[n][12]), "v"(acc[n][13]), "v"(acc[n][14]));
-            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m0) : "v"(m0), "v"(m1), "v"(acc[n][15]));
-            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m2) : "v"(m2), "v"(m3), "v"(m4));
-            asm("v_max_f32 %0, %1, %2" : "=v"(m0) : "v"(m0), "v"(m2));
-            const float mx = m0;
-            if (n * 32 + c < m_left) {
-                // lists are COLUMN-minor: [list][slot = w * 2 + h][column] -- a wave's store is two runs of 32 consecutive floats
-                float* dst = P.bound + ((size_t)(list_j * 16 + (rb_in_tile + w) * 2 + h)) * (size_t)P.ncols + (col0 + n * 32 + c);
-                if (!use_atomic) *dst = mx;
-                else {  // more sampled tiles than lists: monotone float max through the order-preserving integer image
-                    if (mx >= 0.0f) atomicMax(reinterpret_cast<int*>(dst), __float_as_int(mx));
-                    else atomicMin(reinterpret_cast<unsigned*>(dst), __float_as_uint(mx));
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                float m0, m1, m2;
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m0) : "v"(acc[n][0][ch][0]), "v"(acc[n][0][ch][1]), "v"(acc[n][0][ch][2]));
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m1) : "v"(acc[n][1][ch][0]), "v"(acc[n][1][ch][1]), "v"(acc[n][1][ch][2]));
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m2) : "v"(m0), "v"(m1), "v"(acc[n][0][ch][3]));
+                asm("v_max_f32 %0, %1, %2" : "=v"(m2) : "v"(m2), "v"(acc[n][1][ch][3]));
+                const float mx = m2;
+                if (n * 32 + 16 * ch + c16 < m_left) {
+                    // lists are COLUMN-minor: a wave's store is four runs of 16 consecutive floats
+                    float* dst = P.bound + ((size_t)(list_j * 32 + (rb_in_tile + w) * 4 + quad)) * (size_t)P.ncols + (col0 + n * 32 + 16 * ch + c16);
+                    if (!use_atomic) *dst = mx;
+                    else {  // more sampled tiles than lists: monotone float max through the order-preserving integer image
+                        if (mx >= 0.0f) atomicMax(reinterpret_cast<int*>(dst), __float_as_int(mx));
+                        else atomicMin(reinterpret_cast<unsigned*>(dst), __float_as_uint(mx));
+                    }
                 }
             }
         }
@@ -490,7 +544,7 @@ struct Tile2 {
         P2_BARRIER                                                                               \
         P2_STAMP_FINE(1)                                                                         \
         if (LIVE) {                                                                              \
-            stage<SLOT, (SLOT + P2_RING - 1) % P2_RING>(S, loader, pend, (LAST), SLOT == 0 && t == 0); \
+            stage<SLOT, (SLOT + P2_RING - 1) % P2_RING>(S, loader, pend, (LAST), SLOT == 0 && t == 0, SLOT == 1 && t == 0); \
             pend = !(LAST);                                                                      \
         } else {                                                                                 \
             if (loader) dma_b<(SLOT + P2_RING - 1) % P2_RING>(S);                                \
@@ -520,7 +574,7 @@ struct Tile2 {
             // (a bucket with more sampled tiles than lists: EVERY tile that shares a list folds with the monotone atomic -- a plain
             // store from tile j could land behind tile j + 16's atomic and discard it: still a valid bound, but a different one from
             // run to run)
-            if (SAMPLE) epilogue_sample(rb0 + vt * P2_WAVES, n_b, col0, m_left, ch % P2_NSL, p2_sample_tiles(n_b) > P2_NSL, vt * P2_WAVES);
+            if (SAMPLE) epilogue_sample(rb0 + vt * P2_WAVES, n_b, col0, m_left, ch % P2_NSL_BIG, p2_sample_tiles(n_b) > P2_NSL_BIG, vt * P2_WAVES);
             else epilogue_emit(rb0 + vt * P2_WAVES, n_b, col0);
             P2_STAMP(3)
         }

@@ -81,10 +81,15 @@ __global__ void make_scale_kernel(const unsigned* __restrict__ maxbits, float* _
     scale[1] = 1.0f / s;
 }
 
-// row-major f32 -> fp16 fragment-major (x scale): H[rb][k/16][((k>>3)&1)*32 + r][k&7].
+// row-major f32 -> fp16 fragment-major (x scale).  Two fragment shapes (one 1-KiB fragment = one MFMA operand, a lane's 16 bytes = 8
+// consecutive k of one row):
+// (the host picks by the kernel family that will read them: lmi_hip.hip, frag16x16())
+//   K <= 128 (lmi_pass2_small.h, v_mfma_f32_32x32x16_f16):  H[rb][k/16][lane = 32 ((k >> 3) & 1) + r][k & 7]              (32 rows x 16 k)
+//   K  > 128 (lmi_pass2.h, v_mfma_f32_16x16x32_f16):        H[rb][k/32][r >> 4][lane = 16 ((k >> 3) & 3) + (r & 15)][k & 7]  (16 rows x 32 k)
+// (r = row in its 32-row block.)  Either way a row-block's fragments of 32 consecutive k are 2 KiB side by side.
 // One thread per (slab row p, k16-group, half).
 __global__ void convert16_kernel(const float* __restrict__ rows, int d, int pitch, long long n_rows, int KG16,
-                                 const float* __restrict__ scale, uint4* __restrict__ dst) {
+                                 const float* __restrict__ scale, uint4* __restrict__ dst, int f16x16 /* 1: the K > 128 shape */) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_rows * KG16 * 2) return;
     const int hh = (int)(idx & 1);
@@ -98,7 +103,13 @@ __global__ void convert16_kernel(const float* __restrict__ rows, int d, int pitc
         const int k = 16 * g + 8 * hh + j;
         h[j] = (_Float16)(k < d ? x[k] * s : 0.0f);
     }
-    dst[((size_t)(p >> 5) * KG16 + g) * 64 + hh * 32 + (p & 31)] = *reinterpret_cast<uint4*>(&h);
+    const int r = (int)(p & 31);
+    if (f16x16) {
+        const int kq = 2 * (g & 1) + hh;   // which 8 of the 32-k step
+        dst[(((size_t)(p >> 5) * (KG16 / 2) + (g >> 1)) * 2 + (r >> 4)) * 64 + 16 * kq + (r & 15)] = *reinterpret_cast<uint4*>(&h);
+    } else {
+        dst[((size_t)(p >> 5) * KG16 + g) * 64 + hh * 32 + r] = *reinterpret_cast<uint4*>(&h);
+    }
 }
 
 // Rounding-up factor of a binary32 norm: a sum of d non-negative squares accumulated in ANY order errs by at
@@ -232,17 +243,19 @@ __global__ __launch_bounds__(256) void query_norm_kernel(const float* __restrict
 // lane): a wave writes one whole 1-KiB fragment (coalesced); each lane reads 32 contiguous bytes of its row
 __global__ void pack_queries16_kernel(const float* __restrict__ q, int d, const int* __restrict__ colmap,
                                       long long ncols, int KG16, const float* __restrict__ qscale,
-                                      uint4* __restrict__ dst) {
+                                      uint4* __restrict__ dst, int f16x16 /* 1: the K > 128 shape */) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= ncols * KG16 * 2) return;
     const int lane = (int)(idx & 63);
     const int g = (int)((idx >> 6) % KG16);
     const long long cb = (idx >> 6) / KG16;
-    const int hh = lane >> 5;
-    const int qi = colmap[cb * 32 + (lane & 31)];
+    // the fragment shapes of convert16_kernel: 32 columns x 16 k (K <= 128) or 16 columns x 32 k (K > 128: fragment (k/32, column half))
+    const bool f16 = f16x16 != 0;
+    const int colb = f16 ? 16 * (g & 1) + (lane & 15) : (lane & 31);
+    const int k0 = f16 ? 32 * (g >> 1) + 8 * (lane >> 4) : 16 * g + 8 * (lane >> 5);
+    const int qi = colmap[cb * 32 + colb];
     const float s = qi >= 0 ? qscale[qi] : 1.0f;  // the query's power-of-two scale (query_norm_kernel)
     half8 h;
-    const int k0 = 16 * g + 8 * hh;
     if (qi >= 0 && k0 + 8 <= d && (d & 3) == 0) {
         const float4 lo = *reinterpret_cast<const float4*>(q + (size_t)qi * d + k0);
         const float4 hi = *reinterpret_cast<const float4*>(q + (size_t)qi * d + k0 + 4);

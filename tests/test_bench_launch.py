@@ -23,10 +23,31 @@ def test_bench_gpus2_self_launches_and_forwards_json():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
-    assert json.loads(lines[0]) == {"launch_check": True, "world": 2, "sum": 3}
+    assert json.loads(lines[0]) == {"launch_check": True, "world": 2, "sum": 3, "rccl_ranks_seen": 2, "lib_comm": None}
+    assert "2 ranks up over gloo" in r.stderr and "rank 1: pid" in r.stderr   # the roll call, before anything is built
 
 
 def test_bench_child_failure_is_the_exit_code():
     r = _run(2, {"LMI_BENCH_LAUNCH_CHECK_FAIL_RANK": "1"})
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_watchdog_ends_a_rank_that_never_reaches_the_first_collective():
+    """the first real multi-rank RCCL run will be the driver's -- a stuck bring-up must end within the watchdog's
+    limit with a non-zero code and a message, not hang until the lease's."""
+    import time
+
+    t0 = time.time()
+    r = _run(2, {"LMI_BENCH_LAUNCH_CHECK_HANG_RANK": "1", "LMI_BENCH_WATCHDOG_S": "5"})
+    assert r.returncode != 0
+    assert time.time() - t0 < 120
+    assert "WATCHDOG rank" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_library_communicator_branch_runs_once_on_the_cpu():
+    r = _run(2, {"LMI_BENCH_LIBCOMM": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["lib_comm"] == ["stub-comm", 0, 2] and line["rccl_ranks_seen"] == 2
