@@ -186,6 +186,58 @@ struct Tile2 {
         lds_rd<(n * G + g) * 1024>(b[breg(SLOT, QI)], lds_lane + SLOT * P2_SLOT_BYTES);
     }
 
+    // One step of the fragment stream as ONE asm statement: [wait for fragment QI] [request fragment RQ of slot RSLOT] [the two MFMAs
+    // of fragment QI].  The read goes out BEFORE the MFMAs: the second MFMA waits ~16 cycles for the matrix pipe, and an in-order
+    // wave cannot issue the read behind it until then; and hipcc's one-state pad between a wait statement and an MFMA statement
+    // is gone (PMC, round 4: the 16x16x32 stream needed 13 % more cycles than the 32x32x16 one for the same flops).
+    //   WAIT < 0: no wait (the previous stage's deferred fragments: the stage barrier's lgkmcnt(0) covered them)
+    //   RQ < 0: no read (the stage's last D fragments)
+    template <int SLOT, int QI, int WAIT, bool ZERO, int RSLOT, int RQ>
+    __device__ __forceinline__ void step() {
+        constexpr int ch = QI / NCB, n = QI % NCB, R = areg(SLOT, 0);
+#if defined(LMI_ABL_NOLDS) || defined(LMI_ABL_NOLDSB)
+        if constexpr (WAIT >= 0) lgkm_wait<WAIT>(b[breg(SLOT, QI)]);
+        if constexpr (ZERO) mfma_q0<SLOT, QI>(); else mfma_q<SLOT, QI>();
+        if constexpr (RQ >= 0) read_b<RSLOT, RQ>();
+        return;
+#endif
+#define P2_MFMA_ACC "v_mfma_f32_16x16x32_f16 %0, v[%c4:%c5], %3, %0\n\tv_mfma_f32_16x16x32_f16 %1, v[%c6:%c7], %3, %1"
+#define P2_MFMA_ZERO "v_mfma_f32_16x16x32_f16 %0, v[%c4:%c5], %3, 0\n\tv_mfma_f32_16x16x32_f16 %1, v[%c6:%c7], %3, 0"
+        if constexpr (RQ >= 0) {
+            constexpr int rg = RQ / NCB, rn = RQ % NCB;
+            constexpr int OFF = (rn * G + rg) * 1024;
+            const unsigned addr = lds_lane + RSLOT * P2_SLOT_BYTES;
+            half8& bn = b[breg(RSLOT, RQ)];
+            static_assert(breg(RSLOT, RQ) != breg(SLOT, QI), "the read's destination is the MFMAs' operand");
+            if constexpr (WAIT >= 0) {
+                if constexpr (ZERO)
+                    asm volatile("s_waitcnt lgkmcnt(%c10)\n\tds_read_b128 %2, %8 offset:%c9\n\t" P2_MFMA_ZERO
+                                 : "=&v"(acc[n][0][ch]), "=&v"(acc[n][1][ch]), "=&v"(bn) : "v"(b[breg(SLOT, QI)]), "n"(R), "n"(R + 3), "n"(R + 4), "n"(R + 7), "v"(addr), "n"(OFF), "n"(WAIT) : "memory");
+                else
+                    asm volatile("s_waitcnt lgkmcnt(%c10)\n\tds_read_b128 %2, %8 offset:%c9\n\t" P2_MFMA_ACC
+                                 : "+v"(acc[n][0][ch]), "+v"(acc[n][1][ch]), "=&v"(bn) : "v"(b[breg(SLOT, QI)]), "n"(R), "n"(R + 3), "n"(R + 4), "n"(R + 7), "v"(addr), "n"(OFF), "n"(WAIT) : "memory");
+            } else {
+                if constexpr (ZERO)
+                    asm volatile("ds_read_b128 %2, %8 offset:%c9\n\t" P2_MFMA_ZERO
+                                 : "=&v"(acc[n][0][ch]), "=&v"(acc[n][1][ch]), "=&v"(bn) : "v"(b[breg(SLOT, QI)]), "n"(R), "n"(R + 3), "n"(R + 4), "n"(R + 7), "v"(addr), "n"(OFF) : "memory");
+                else
+                    asm volatile("ds_read_b128 %2, %8 offset:%c9\n\t" P2_MFMA_ACC
+                                 : "+v"(acc[n][0][ch]), "+v"(acc[n][1][ch]), "=&v"(bn) : "v"(b[breg(SLOT, QI)]), "n"(R), "n"(R + 3), "n"(R + 4), "n"(R + 7), "v"(addr), "n"(OFF) : "memory");
+            }
+        } else {
+            static_assert(WAIT >= 0, "");
+            half8 dummy;   // (operand numbering shared with the forms above)
+            if constexpr (ZERO)
+                asm volatile("s_waitcnt lgkmcnt(%c8)\n\t" P2_MFMA_ZERO
+                             : "=&v"(acc[n][0][ch]), "=&v"(acc[n][1][ch]), "=&v"(dummy) : "v"(b[breg(SLOT, QI)]), "n"(R), "n"(R + 3), "n"(R + 4), "n"(R + 7), "n"(WAIT) : "memory");
+            else
+                asm volatile("s_waitcnt lgkmcnt(%c8)\n\t" P2_MFMA_ACC
+                             : "+v"(acc[n][0][ch]), "+v"(acc[n][1][ch]), "=&v"(dummy) : "v"(b[breg(SLOT, QI)]), "n"(R), "n"(R + 3), "n"(R + 4), "n"(R + 7), "n"(WAIT) : "memory");
+        }
+#undef P2_MFMA_ACC
+#undef P2_MFMA_ZERO
+    }
+
     __device__ __forceinline__ bool is_loader() const { return P2_WAVES == 4 ? true : w >= 4; }
     struct Stream {        // wave-uniform source pointers of the NEXT stage to load
         const char* a;     // the wave's row-block of the tile, k-group pair t, MINUS `ring` (the lane offset register is lds_lane)
@@ -230,32 +282,30 @@ struct Tile2 {
             constexpr int I = decltype(i)::value;
             if (pend) {   // (every accumulator gets ONE MFMA per stage: all of the tile's first stage starts from 0, its deferred ones too)
                 if constexpr (PS == 0) {
-                    if (prev_first) mfma_q0<PS, Q - D + I>(); else mfma_q<PS, Q - D + I>();
+                    if (prev_first) step<PS, Q - D + I, -1, true, SLOT, I>(); else step<PS, Q - D + I, -1, false, SLOT, I>();
                 } else {
-                    mfma_q<PS, Q - D + I>();
+                    step<PS, Q - D + I, -1, false, SLOT, I>();
                 }
+            } else {
+                read_b<SLOT, I>();
             }
-            read_b<SLOT, I>();
         });
         load_a<DST>(S);
         static_for<0, Q - D>([&](auto qi) {
             constexpr int q = decltype(qi)::value;
-            lgkm_wait<younger(q)>(b[breg(SLOT, q)]);
             if constexpr (SLOT == 0) {
-                if (first) mfma_q0<SLOT, q>(); else mfma_q<SLOT, q>();
+                if (first) step<SLOT, q, younger(q), true, SLOT, q + D>(); else step<SLOT, q, younger(q), false, SLOT, q + D>();
             } else {
-                mfma_q<SLOT, q>();
+                step<SLOT, q, younger(q), false, SLOT, q + D>();
             }
-            read_b<SLOT, q + D>();
         });
         if (last) {
             static_for<Q - D, Q>([&](auto qi) {
                 constexpr int q = decltype(qi)::value;
-                lgkm_wait<0>(b[breg(SLOT, q)]);
                 if constexpr (SLOT == 0) {   // (one-stage tiles)
-                    if (first) mfma_q0<SLOT, q>(); else mfma_q<SLOT, q>();
+                    if (first) step<SLOT, q, 0, true, -1, -1>(); else step<SLOT, q, 0, false, -1, -1>();
                 } else {
-                    mfma_q<SLOT, q>();
+                    step<SLOT, q, 0, false, -1, -1>();
                 }
             });
         }

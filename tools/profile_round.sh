@@ -1,13 +1,13 @@
 #!/usr/bin/env bash
 # GPU box: the rocprofv3 passes behind profiles/<tag>_*: kernel trace + stats of the bench, then separate PMC passes
 # (FETCH_SIZE, WRITE_SIZE, SQ, TCC) restricted to the dominant kernel, condensed by profiles/summarize.py.
-#   bash tools/profile_round.sh r02 [dominant-kernel-regex]
+#   bash tools/profile_round.sh r02 [dominant-kernel-regex] [extra bench flags, e.g. "--config c5"]
 set -uo pipefail
 export TMPDIR=/tmp
-tag="$1"; K="${2:-pass2_kernel<false}"
+tag="$1"; K="${2:-pass2_kernel<false}"; EXTRA="${3:-}"
 root="$PWD"; out="$root/gpurun_out/prof_$tag"
 mkdir -p "$out"
-B="python3 $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-recall --no-hard-leg --no-other-configs"
+B="python3 $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-recall --no-hard-leg --no-other-configs --no-exact-leg $EXTRA"
 cd /tmp
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- $B > "$out/bench_under_rocprof.json" 2> "$out/trace.err" || { echo "trace pass failed"; tail -5 "$out/trace.err"; exit 1; }
 echo "trace done"
