@@ -809,6 +809,16 @@ def main():
         eroof, eflops, _ = dominant_roofline(args, cfg, re_, we.sizes, we.owner, rank, _capi, exact=True)
         same = bool(np.array_equal(re_["out_i"], out_i) and np.array_equal(re_["out_d"], out_d))
         assert same, "the all-f32 leg and the default leg returned different results"
+        etj = os.path.join(ROOT, "profiles", "scan_pmc_c2_exact.json")   # counters of `bench.py --exact`, replayed like the default leg's
+        eroof["traffic"] = eroof["mfma_pipe_busy_frac"] = None
+        if os.path.exists(etj) and not any(getattr(args, key) is not None for key in ("n", "nq", "nb", "leaves")):
+            epj = json.load(open(etj))
+            esame = ((epj.get("lib") or {}).get("built_from_source_sha16") == lib_provenance()["built_from_source_sha16"]
+                     and str(epj.get("kernel", "")).rstrip("(") in eroof["kernel"])
+            if esame:
+                eroof["traffic"], eroof["mfma_pipe_busy_frac"] = epj.get("hbm_bytes_per_launch"), epj.get("mfma_pipe_busy_frac")
+            eroof["traffic_source"] = {"file": os.path.relpath(etj, ROOT), "collected_utc": epj.get("collected_utc"), "commit": epj.get("commit"),
+                                       "matches_loaded_library": bool(esame), "how": "replayed from separate rocprofv3 --pmc passes of bench.py --exact"}
         echeck = None
         if rank == 0 and not args.no_cpu_baseline:
             eq_ = min(args.cpu_queries, nq, 64)

@@ -7,9 +7,10 @@
 // MFMA shape (round 4): v_mfma_f32_16x16x32_f16 -- the 32 x 32 block of a wave and a col-block is four 16 x 16 tiles, a stage (32 k) is
 // one k-step; the index slab and the query fragments are packed as 16-row x 32-k fragments for it (convert16_kernel /
 // pack_queries16_kernel, lmi_prefilter.h).  Same flops, bytes and registers as round 3's 32x32x16 form, half the accumulator
-// read-modify-write per MAC: pass 2 is power-limited and the chip holds a higher clock on this shape (measured: -2 % time at C2).
+// read-modify-write per MAC: pass 2 is power-limited and the chip holds a ~12 % higher clock on this shape; with the fragment
+// stream as one asm statement per query fragment (wait, next read, MFMA pair) the net is -4 % time at C2.
 //
-// Operand paths (round 4).  A wave's vector fragments are PRIVATE to it (its row-block x the stage's two k-groups = 2 KiB), so
+// Operand paths (round 4).  A wave's vector fragments are PRIVATE to it (its row-block x the stage's two row halves = 2 KiB), so
 // they need neither LDS nor a barrier: every wave loads them with two global_load_dwordx4 straight into registers, two stages
 // ahead, into one of three 8-register sets, and waits for them with a counted vmcnt.  hipcc cannot express a load that stays
 // in flight into registers it allocates (round 3, profiles/r03_pass2_experiments.txt section 21: tied waits are preceded by
@@ -26,7 +27,7 @@
 // two streams overlap either way once the query tiles are L2-resident; what the register path removes is 16 of the loader
 // waves' 16 + 2 NCB pieces per stage, the vector fragments' LDS reads, and 48 KiB of ring that a deeper query ring can use.)
 // Pass 1 (SAMPLE) = the same tile on sampled tiles only; one item per (bucket, query tile, sampled tile); per lane and
-// col-block the MAXIMUM of its 16 scores is all it keeps: the slot maxima of a column come from disjoint rows, so the 10th
+// column the MAXIMUM of its 8 scores is all it keeps: the slot maxima of a column come from disjoint rows, so the 10th
 // largest of them is the 10th best of a subset of the bucket = a valid lower bound of That (lmi_prefilter.h, header).
 #pragma once
 #include <type_traits>
@@ -54,7 +55,7 @@ constexpr int P2_NSL = 16;   // pass 1, low-dimensional kernels: lists per colum
 constexpr int P2_NSL_BIG = 8;   // pass 1, pass2_kernel: 8 lists of 32 slot maxima (the 16x16 MFMA tile gives a lane 8 rows of a column, not 16)
 static_assert(P2_NSL * 16 == P2_NSL_BIG * 32, "bound_merge2_kernel reads 256 values per column either way");
 constexpr int P2_LIST = 64 + 1;
-// The vector-fragment register sets: v[P2_AREG0 + 8 s + 4 g .. + 3] = k-group g of the stage in ring slot s.  hipcc is kept
+// The vector-fragment register sets: v[P2_AREG0 + 8 s + 4 h .. + 3] = row half h of the stage in ring slot s.  hipcc is kept
 // below P2_AREG0 by the kernels' amdgpu_num_vgpr attribute (= P2_AREG0 / 2: the attribute is per register-file half).
 constexpr int P2_AREG0 = 232;
 #define LMI_P2_NUM_VGPR_ATTR 116
