@@ -135,6 +135,9 @@ class Workload:
         owner = assign_buckets(sizes, world, weights=work_w)
         owned = (owner == rank).astype(np.uint8) if world > 1 else None
         self.shard_world, self.owner_all = world, owner
+        self.replica = world > 1 and getattr(args, "shard_mode", "bucket") == "replica"
+        if self.replica:   # query-sharded replicas: every rank ingests everything
+            owner, owned, self.shard_world = np.full(L, rank, dtype=np.int32), None, 1
         if args.emulate_shard and tag == "main":
             er, ew = (int(v) for v in args.emulate_shard.split("/"))
             self.shard_world = ew
@@ -185,7 +188,11 @@ class Workload:
                 self._lib_comm = eng.comm_init(rank, world, ids[0])
                 wd.done()
             lib_comm = self._lib_comm
-        searcher = ShardedSearcher(eng, rank, world, shard_inference=shard_inference, lib_comm=lib_comm)
+        if self.replica:
+            from learnedmetricindex_amd.sharded import ReplicaSearcher
+            searcher = ReplicaSearcher(eng, rank, world)
+        else:
+            searcher = ShardedSearcher(eng, rank, world, shard_inference=shard_inference, lib_comm=lib_comm)
 
         def sync_all():
             torch.cuda.synchronize()
@@ -273,7 +280,8 @@ class Workload:
 
         L, k = self.cfg["leaves"], self.args.k
         q = self.queries[:nr].contiguous()
-        _, gt_i, _ = ShardedSearcher(self.eng, self.rank, self.world).search(q, q, L, k)
+        gt_searcher = ShardedSearcher(self.eng, 0, 1) if self.replica else ShardedSearcher(self.eng, self.rank, self.world)
+        _, gt_i, _ = gt_searcher.search(q, q, L, k)
         gt = gt_i.cpu().numpy().astype(np.int64)
         got = out_i[:nr].astype(np.int64)
         return float(np.mean([len(set(a) & set(b)) / float(k) for a, b in zip(got, gt)]))
@@ -685,6 +693,9 @@ def main():
                          "kernel's duration; 0/1 show the step without the events' bubbles (roofline fields then null/0)")
     ap.add_argument("--exact", action="store_true",
                     help="all-f32 scan (lmi_set_prefilter(0)) instead of fp16 prefilter + exact re-rank; same results")
+    ap.add_argument("--shard-mode", choices=("bucket", "replica"), default="bucket",
+                    help="N > 1: `bucket` (default, the headline): bucket b lives on one rank; `replica`: SURVEY 8e's other mode -- "
+                         "the whole index on every rank, a rank answers 1/N of the batch, one all-gather of the rows")
     ap.add_argument("--emulate-shard", default=None, metavar="R/W",
                     help="diagnostic, single GPU: own only the buckets rank R of a W-way sharded run would own "
                          "(no collective); shows the per-rank step time of the N>1 bench on one card")
@@ -743,7 +754,7 @@ def main():
                      m=np.bincount(bo_h, minlength=L))
     # N > 1: the other collective layout (every rank routes the whole batch: ONE all-gather, as north_star words it)
     alt = None
-    if world > 1:
+    if world > 1 and not wl.replica:
         r2 = wl.run(args.steps, args.warmup, shard_inference=False, measure_resident=False)
         assert np.array_equal(r2["out_i"], out_i), "the two sharded modes disagree"
         alt = {"mode": "replicated MLP on every rank, ONE all-gather (per-rank top-k)",
@@ -965,6 +976,8 @@ def main():
                                    f"{cfg['model']} {d}->512->{L} trained {args.epochs} epochs), top-{nb} buckets, "
                                    f"{nq}-query batch, k={k}",
                        "baseline_config": args.config, "parallelism": "single GPU" if world == 1 else
+                                      f"query-sharded replicas x{world}: the whole index on every rank, a rank answers 1/{world} of the "
+                                      f"batch, one all-gather of [dists | ids | bucket order] rows" if wl.replica else
                                       f"bucket-sharded x{world} (owned-only ingest): MLP on 1/{world} of the batch + all-gather of "
                                       f"the bucket order, scan of the owned buckets + all-gather of the per-rank top-k",
                        "scan_pairs": int(pairs), "scan_items": int(items)},

@@ -9,6 +9,11 @@ Two layouts of the routing step (`ShardedSearcher(shard_inference=...)`):
   * False: every rank runs the MLP on the whole batch -- ONE collective per search (the all-gather above);
   * True (default for world > 1): every rank routes its 1/world slice of the batch and the bucket order
     (nq*nb*4 bytes) is all-gathered first -- TWO small collectives, 1/world of the MLP work per rank.
+`ReplicaSearcher` is the other mode SURVEY section 8e names: QUERY-sharded replicas -- every rank holds the whole
+index and answers its 1/world slice of the batch; one all-gather of [dists | ids | bucket order] rows.  A query's
+answer does not depend on the rest of its batch, so the result is again byte-identical for every world size.  It
+pays off when a rank's slice still fills the query tiles (>= ~350 queries per bucket and rank: batches of >= 80 k
+at 8 ranks on the 10M benchmark); at 10 k queries bucket-sharding is 2-3 x faster.
 """
 from __future__ import annotations
 
@@ -193,3 +198,47 @@ class ShardedSearcher:
             return self.search_routed(qs_t, self._bo_loc, nb, k)
         self.index.search_device(qn_t, qs_t, nb, k, blk[0], blk[1], blk[2], bo)
         return self._exchange(blk, out_d, out_i, bo, nq, kout)
+
+
+class ReplicaSearcher:
+    """Query-sharded replicas: the index is whole on every rank (`set_buckets` / `add_rows` without an `owned`
+    mask), rank r answers rows [lo, hi) of the batch (`row_slice`) and ONE all-gather assembles the batch's
+    answer: per query [kout distances | kout ids | nb buckets] as int32 words.  No merge step: the slices are
+    disjoint.  Same call signature and return value as `ShardedSearcher.search`."""
+
+    calls_per_search = 1
+    shard_inference = False   # (HostPipeline: nothing to route ahead of the search call)
+    lib_comm = None
+
+    def __init__(self, index, rank: int, world: int, group=None):
+        self.index, self.rank, self.world, self.group = index, rank, world, group
+        self._buf = None
+
+    def _buffers(self, per: int, nb: int, kout: int, dev):
+        import torch
+
+        if self._buf is None or self._buf[0].shape != (per, 2 * kout + nb):
+            self._buf = (torch.empty((per, 2 * kout + nb), dtype=torch.int32, device=dev),
+                         torch.empty((per, kout), dtype=torch.float32, device=dev),
+                         torch.empty((per, kout), dtype=torch.int32, device=dev),
+                         torch.empty((per, kout), dtype=torch.int32, device=dev),
+                         torch.empty((per, nb), dtype=torch.int32, device=dev))
+        return self._buf
+
+    def search(self, qn_t, qs_t, nb: int, k: int):
+        import torch
+
+        nq = qn_t.shape[0]
+        kout = self.index.kout(nb, k)
+        per, lo, hi = row_slice(nq, self.rank, self.world)
+        row, d, i, keys, bo = self._buffers(per, nb, kout, qn_t.device)
+        if hi > lo:
+            n = hi - lo
+            self.index.search_device(qn_t[lo:hi], qs_t[lo:hi], nb, k, d[:n], i[:n], keys[:n], bo[:n])
+        if self.world == 1:
+            return d[:nq], i[:nq], bo[:nq]
+        row[:, :kout] = d.view(torch.int32)
+        row[:, kout:2 * kout] = i
+        row[:, 2 * kout:] = bo
+        g = all_gather_rows(row, nq, self.world, self.group)   # the one collective
+        return g[:, :kout].contiguous().view(torch.float32), g[:, kout:2 * kout].contiguous(), g[:, 2 * kout:].contiguous()

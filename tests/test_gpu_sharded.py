@@ -91,6 +91,41 @@ def test_sharded_equals_single(oracle, name, nb, k, world):
         h.close()
 
 
+@pytest.mark.parametrize("name,nb,k,world", [("G3", 4, 10, 2), ("G4", 3, 15, 3), ("G5", 4, 10, 8), ("G4", 1, 5, 7)])
+def test_query_sharded_replica_slices_equal_whole_batch(oracle, name, nb, k, world):
+    """ReplicaSearcher's premise on the GPU path: a query's answer (prefilter bounds included) does not depend on the rest
+    of its batch -- the ranks' slices, concatenated as the all-gather does, are the whole batch's answer bit for bit."""
+    from learnedmetricindex_amd import _capi
+    from learnedmetricindex_amd.sharded import ReplicaSearcher, row_slice
+
+    g = load_golden(name)
+    Xn, Qn, Xs, Qs = inputs_for(name, g)
+    layers = layers_from(g)
+    dp = g["data_prediction"]
+    dev = torch.device("cuda", 0)
+    qn, qs = torch.from_numpy(Qn).to(dev), torch.from_numpy(Qs).to(dev)
+    nq = Qn.shape[0]
+    h = _capi.Index(0, chunk_rows=256)
+    h.set_stream(torch.cuda.current_stream().cuda_stream)
+    h.set_mlp(layers)
+    h.set_buckets(Xs, dp[:, 0], layers[-1][0].shape[0])
+    wd, wi, wbo = (t.clone() for t in ReplicaSearcher(h, 0, 1).search(qn, qs, nb, k))
+    torch.cuda.synchronize()
+    do, io, boo = oracle.search(layers, Qn, Xs, Qs, dp, nb, k, nthreads=4)
+    np.testing.assert_array_equal(wi.cpu().numpy().view(np.uint32), io)
+    np.testing.assert_array_equal(wd.cpu().numpy().astype(np.float64), do)
+    np.testing.assert_array_equal(wbo.cpu().numpy(), boo[:, :, 0])
+    parts = []
+    for r in range(world):
+        per, lo, hi = row_slice(nq, r, world)
+        if hi > lo:
+            parts.append(tuple(t.clone() for t in ReplicaSearcher(h, 0, 1).search(qn[lo:hi].contiguous(), qs[lo:hi].contiguous(), nb, k)))
+    torch.cuda.synchronize()
+    for j, whole in enumerate((wd, wi, wbo)):
+        assert torch.equal(torch.cat([p[j] for p in parts]), whole)
+    h.close()
+
+
 def test_library_rccl_exchange_world1(oracle):
     """lmi_comm_* / lmi_allgather_merge: the exchange step through RCCL inside the library, exercised on the one test
     GPU with a single-rank communicator (a real ncclCommInitRank + ncclAllGather on the handle's stream)."""

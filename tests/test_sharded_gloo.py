@@ -97,6 +97,59 @@ def test_multi_rank_result_identical_to_single(oracle, tmp_path, name, nb, k, wo
         np.testing.assert_array_equal(r["d"].astype(np.float64), do)
 
 
+class _OracleIndex:
+    """Stands in for `_capi.Index` under ReplicaSearcher on the CPU: lmi_search played by the oracle on CPU tensors."""
+
+    def __init__(self, oracle, layers, Xs, dp):
+        self.oracle, self.layers, self.Xs, self.dp = oracle, layers, Xs, dp
+
+    @staticmethod
+    def kout(nb, k):
+        return 10 if nb == 1 else k
+
+    def search_device(self, qn_t, qs_t, nb, k, d_t, i_t, keys_t=None, bo_t=None):
+        d, i, bo = self.oracle.search(self.layers, qn_t.numpy(), self.Xs, qs_t.numpy(), self.dp, nb, k)
+        d_t.copy_(torch.from_numpy(d.astype(np.float32)))
+        i_t.copy_(torch.from_numpy(i.view(np.int32)))
+        if bo_t is not None:
+            bo_t.copy_(torch.from_numpy(bo[:, :, 0].astype(np.int32)))
+
+
+def _replica_worker(rank, world, port, name, nb, k, out_dir):
+    sys.path[:0] = [ROOT, HERE, os.path.join(HERE, "golden")]
+    from helpers import inputs_for, layers_from, load_golden
+    from learnedmetricindex_amd import sharded
+    from oracle import lmi_oracle as oracle
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        g = load_golden(name)
+        Xn, Qn, Xs, Qs = inputs_for(name, g)
+        idx = _OracleIndex(oracle, layers_from(g), Xs, g["data_prediction"])
+        d, i, bo = sharded.ReplicaSearcher(idx, rank, world).search(torch.from_numpy(Qn), torch.from_numpy(Qs), nb, k)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), d=d.numpy(), i=i.numpy().view(np.uint32), bo=bo.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,nb,k,world", [("G1", 3, 10, 2), ("G4", 3, 15, 2), ("G4", 1, 5, 2), ("G4", 4, 10, 8)])
+def test_query_sharded_replicas_identical_to_single(oracle, tmp_path, name, nb, k, world):
+    """SURVEY section 8e's other mode: every rank answers its slice of the batch against the whole index; the one
+    all-gather of [dists | ids | bucket order] rows must reproduce the single-process answer (also when the batch does
+    not divide by the world size and when a rank's slice is empty)."""
+    from helpers import inputs_for, layers_from, load_golden
+
+    mp.spawn(_replica_worker, args=(world, _free_port(), name, nb, k, str(tmp_path)), nprocs=world, join=True)
+    g = load_golden(name)
+    Xn, Qn, Xs, Qs = inputs_for(name, g)
+    do, io, boo = oracle.search(layers_from(g), Qn, Xs, Qs, g["data_prediction"], nb, k)
+    for r in range(world):
+        got = np.load(tmp_path / f"rank{r}.npz")
+        np.testing.assert_array_equal(got["i"], io)
+        np.testing.assert_array_equal(got["d"].astype(np.float64), do)
+        np.testing.assert_array_equal(got["bo"], boo[:, :, 0])
+
+
 def test_assign_buckets_balances_and_is_deterministic():
     from learnedmetricindex_amd.sharded import assign_buckets
 
