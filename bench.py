@@ -667,6 +667,7 @@ def main():
     ap.add_argument("--n", type=int)
     ap.add_argument("--nq", type=int)
     ap.add_argument("--nb", type=int)
+    ap.add_argument("--d", type=int, help="diagnostic: another dimensionality on the chosen config's shape (not a bench line)")
     ap.add_argument("--leaves", type=int)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--seed", type=int, default=2023)
@@ -704,7 +705,7 @@ def main():
                          "written by profiles/summarize.py from separate rocprofv3 --pmc passes of this bench)")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
-    for key in ("n", "nq", "nb", "leaves"):
+    for key in ("n", "nq", "nb", "leaves", "d"):
         if getattr(args, key) is not None:
             cfg[key] = getattr(args, key)
     N, d, L, nb, nq, k = cfg["n"], cfg["d"], cfg["leaves"], cfg["nb"], cfg["nq"], args.k
@@ -822,7 +823,7 @@ def main():
         assert same, "the all-f32 leg and the default leg returned different results"
         etj = os.path.join(ROOT, "profiles", "scan_pmc_c2_exact.json")   # counters of `bench.py --exact`, replayed like the default leg's
         eroof["traffic"] = eroof["mfma_pipe_busy_frac"] = None
-        if os.path.exists(etj) and not any(getattr(args, key) is not None for key in ("n", "nq", "nb", "leaves")):
+        if os.path.exists(etj) and not any(getattr(args, key) is not None for key in ("n", "nq", "nb", "leaves", "d")):
             epj = json.load(open(etj))
             esame = ((epj.get("lib") or {}).get("built_from_source_sha16") == lib_provenance()["built_from_source_sha16"]
                      and str(epj.get("kernel", "")).rstrip("(") in eroof["kernel"])
@@ -928,7 +929,7 @@ def main():
         traffic = mfma_busy = None
         prov = lib_provenance()
         tj = args.traffic_json or os.path.join(ROOT, "profiles", f"scan_pmc_{args.config}{'_exact' if args.exact else ''}.json")
-        overridden = any(getattr(args, key) is not None for key in ("n", "nq", "nb", "leaves", "emulate_shard"))
+        overridden = any(getattr(args, key) is not None for key in ("n", "nq", "nb", "leaves", "d", "emulate_shard"))
         traffic_source = None
         if world == 1 and not overridden and os.path.exists(tj):
             pj = json.load(open(tj))

@@ -1048,7 +1048,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     R.grp_base1 = R.grp_total + NGRP;
     R.grp_total1 = R.grp_base1 + (size_t)NGRP * (L + 1);
     const bool v2 = h->prefilter && h->have16;   // the prefilter's kernels: lmi_pass2.h (tiles of up to 12 col-blocks)
-    R.tile_cb = v2 ? P2_MAXCB : 4;
+    R.tile_cb = !v2 ? 4 : (h->pf_small && h->KG16 <= PS_MAXKG) ? ps_tile_cb(h->KG16) : P2_MAXCB;
     R.sample_items = v2 ? 1 : 0;
     // one bound per QUERY is enough when the caller keeps the k <= 10 best over all ranks (query_bound_kernel, lmi_pass2.h): pass 1
     // then samples only each query's primary slot(s) -- a quarter of the columns at n_buckets = 4
@@ -1168,6 +1168,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         F.KG16 = h->KG16;
         F.L = L;
         F.chunk_rb = S.chunk_rb;
+        F.tile_cb = R.tile_cb;
         F.rb_start = S.rb_start;
         F.nb_rows = R.nb_rows;
         F.nch = R.nch;

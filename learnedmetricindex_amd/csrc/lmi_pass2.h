@@ -718,7 +718,7 @@ __global__ void query_bound_kernel(const int* __restrict__ slot_col, int nq, int
 // The XCD-affine queues (route_group_kernel): pass 1 has its own prefixes (items = query tiles x SAMPLED tiles) and heads; a
 // bucket's items go to the same XCD in both passes: its queries' fragments stay in that L2.
 struct P2Item { int b, cbt0, ncb_tile, ch, m_use; };
-// Item `local` of bucket b.  Query tiles of the bucket: its col-blocks split evenly over nqt = ceil(col-blocks / 12) tiles.
+// Item `local` of bucket b.  Query tiles of the bucket: its col-blocks split evenly over nqt = ceil(col-blocks / P.tile_cb) tiles.
 // pass 2: local = chunk * nqt + tile, all columns.  pass 1: pass1_decode -> sampled tile j, query tile; every
 // P1_ALL_EVERY-th sampled tile runs over all the columns, the others over the primary ones (the bucket's first m0).
 template <bool SAMPLE>
@@ -726,12 +726,12 @@ __device__ __forceinline__ void p2_decode_item(const PrefilterParams& P, int b, 
     int qt = 0, ch = 0;
     bool all_cols = true;
     if (SAMPLE) {
-        const int nqa = query_tiles(P.m[b], P2_MAXCB), nqp = query_tiles(P.m0[b], P2_MAXCB);
+        const int nqa = query_tiles(P.m[b], P.tile_cb), nqp = query_tiles(P.m0[b], P.tile_cb);
         all_cols = pass1_decode(local, nqa, nqp, &ch, &qt);
     }
     it.m_use = all_cols ? P.m[b] : P.m0[b];
     const int ncb_b = (it.m_use + 31) >> 5;
-    const int nqt = (ncb_b + P2_MAXCB - 1) / P2_MAXCB;
+    const int nqt = (ncb_b + P.tile_cb - 1) / P.tile_cb;
     const int per = (ncb_b + nqt - 1) / nqt;
     if (!SAMPLE) { qt = local % nqt; ch = local / nqt; }
     it.b = b;

@@ -37,14 +37,17 @@ constexpr int PS_WAVES = LMI_PS_WAVES;   // waves per block (they share the quer
 #define LMI_PS_SPILL 96
 #endif
 #ifndef LMI_PS_SPILL_KG
-#define LMI_PS_SPILL_KG 4
+#define LMI_PS_SPILL_KG 6
 #endif
 constexpr int PS_SPILL = LMI_PS_SPILL;        // entries of a wave's spill ring (pass 2, K <= 64): 64 scores + tag each
 constexpr int PS_SPILL_KG = LMI_PS_SPILL_KG;  // ... used up to this many k16-groups
 constexpr int PS_ROW_BITS = 23;   // list entry = column in the tile (9 bits) << 23 | row in the item's chunk (a chunk is at most 2^31 / 1024 rows)
 
+// col-blocks per query tile: K = 65..96 (5 / 6 k16-groups) takes tiles of 8, so that two blocks per CU hold the tile AND the spill ring
+// (round 4: these two shapes were on the per-register path with 1 270 / 1 436 spilled registers: 0.13 of the HBM roofline at d = 80 / 96)
+__host__ __device__ constexpr int ps_tile_cb(int kg) { return kg == 5 || kg == 6 ? 8 : P2_MAXCB; }
 __host__ __device__ constexpr int ps_spill_bytes(int kg) { return kg <= PS_SPILL_KG ? PS_WAVES * PS_SPILL * (64 + 4) : 0; }
-__host__ __device__ constexpr int ps_lds_bytes(int kg) { return P2_MAXCB * kg * 1024 + P2_MAXCB * 32 * 4 + ps_spill_bytes(kg); }
+__host__ __device__ constexpr int ps_lds_bytes(int kg) { return ps_tile_cb(kg) * kg * 1024 + ps_tile_cb(kg) * 32 * 4 + ps_spill_bytes(kg); }
 constexpr int PS_PREFIX_CAP = 257;   // buckets + 1 of a queue group held in LDS (more: the global prefix is searched)
 #ifndef LMI_PS_BLOCKS4
 #define LMI_PS_BLOCKS4 2   // blocks per CU at KG <= 4 (LDS allows 3, but pass 2 then has 168 registers and spills 175: 0.47 -> 1.06 ms)
@@ -55,10 +58,12 @@ static_assert(PS_SPILL >= 128 - 32 && 2 * (ps_lds_bytes(6) + 4096) <= 160 * 1024
 template <int KG, bool SAMPLE>
 __global__ __launch_bounds__(64 * PS_WAVES, ps_blocks_per_cu(KG) * PS_WAVES / 4) void pass2_small_kernel(PrefilterParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ps_smem[];
+    constexpr int TCB = ps_tile_cb(KG);                                       // col-blocks per query tile
     uint4* sB = reinterpret_cast<uint4*>(ps_smem);                            // [col-blocks of the tile][KG][64 lanes]
-    float* sThr = reinterpret_cast<float*>(ps_smem + P2_MAXCB * KG * 1024);   // [P2_MAXCB * 32] emission thresholds (pass 2)
+    float* sThr = reinterpret_cast<float*>(ps_smem + TCB * KG * 1024);        // [TCB * 32] emission thresholds (pass 2)
     constexpr bool SPILL = !SAMPLE && KG <= PS_SPILL_KG;   // pass 2's lane-granular spill ring (file header)
-    float4* sSpill = reinterpret_cast<float4*>(ps_smem + P2_MAXCB * KG * 1024 + P2_MAXCB * 32 * 4);   // [waves][PS_SPILL][4] the 16 scores of an entry
+    constexpr bool B2 = KG <= 4 || SAMPLE;                 // two query-fragment sets taking turns (K <= 64; beyond, pass 2 has no registers for the second)
+    float4* sSpill = reinterpret_cast<float4*>(ps_smem + TCB * KG * 1024 + TCB * 32 * 4);   // [waves][PS_SPILL][4] the 16 scores of an entry
     unsigned* sTag = reinterpret_cast<unsigned*>(sSpill + PS_WAVES * PS_SPILL * 4);                    // [waves][PS_SPILL] column in the tile | row base << 9
     __shared__ int s_item[2];
     __shared__ int s_prefix[PS_PREFIX_CAP];
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(64 * PS_WAVES, ps_blocks_per_cu(KG) * PS_WAVES / 4)
         {
             // the query tile -> LDS: every load of a thread in flight before its first LDS store (one memory round trip, not one per step)
             const uint4* bsrc = P.qfrag16 + (size_t)cb_tile * KG * 64;   // the tile's col-blocks are consecutive
-            constexpr int NV = (P2_MAXCB * KG * 64 + 64 * PS_WAVES - 1) / (64 * PS_WAVES);
+            constexpr int NV = (TCB * KG * 64 + 64 * PS_WAVES - 1) / (64 * PS_WAVES);
             const int nfrag = ncb * KG * 64;
             if constexpr (NV <= 12) {
                 uint4 tmp[NV];
@@ -352,11 +357,13 @@ __global__ __launch_bounds__(64 * PS_WAVES, ps_blocks_per_cu(KG) * PS_WAVES / 4)
         // A pair of row-blocks against every col-block of the tile.  The fragments of col-block n + 1 are requested before the
         // MFMAs of col-block n (two fragment sets taking turns): the LDS latency is off the MFMA chain.
         auto block = [&](int n, int rbA, bool second, const half8 (&x0)[KG], const half8 (&x1)[KG], const half8 (&bfc)[KG],
-                         half8 (&bfn)[KG]) __attribute__((always_inline)) {
+                         auto& bfn) __attribute__((always_inline)) {
             const int nn = min(n + 1, ncb - 1);
             const float thr_n = SAMPLE ? 0.0f : sThr[n * 32 + c];   // requested ahead of the MFMAs: no LDS round trip in front of the test
+            if constexpr (B2) {
 #pragma unroll
-            for (int g = 0; g < KG; ++g) bfn[g] = sBh[(nn * KG + g) * 64];
+                for (int g = 0; g < KG; ++g) bfn[g] = sBh[(nn * KG + g) * 64];
+            }
             f32x16 c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x0[0], bfc[0], zero, 0, 0, 0);
             f32x16 c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x1[0], bfc[0], zero, 0, 0, 0);
 #pragma unroll
@@ -374,14 +381,24 @@ __global__ __launch_bounds__(64 * PS_WAVES, ps_blocks_per_cu(KG) * PS_WAVES / 4)
             if (!SAMPLE) { asm volatile("s_waitcnt vmcnt(12)" : "+v"(const_cast<half8&>(x0[0])) :: "memory"); st_acc[7] += 1; }
             PS_STAMP(1)
 #endif
-            half8 bfa[KG], bfb[KG];
+            half8 bfa[KG], bfb[B2 ? KG : 1];
+            if constexpr (B2) {
 #pragma unroll
-            for (int g = 0; g < KG; ++g) bfa[g] = sBh[g * 64];
+                for (int g = 0; g < KG; ++g) bfa[g] = sBh[g * 64];
+            }
             // (Tried and dropped, round 4, profiles/r04_pass2_experiments.txt: the col-block loop software-pipelined on top of the spill
             // ring -- MFMAs of col-block n + 1 issued before the test of n, two accumulator pairs: 256 registers + 34 spilled, +10 % time.)
-            for (int n = 0; n < ncb; n += 2) {
-                block(n, rbA, second, x0, x1, bfa, bfb);
-                if (n + 1 < ncb) block(n + 1, rbA, second, x0, x1, bfb, bfa);
+            if constexpr (B2) {
+                for (int n = 0; n < ncb; n += 2) {
+                    block(n, rbA, second, x0, x1, bfa, bfb);
+                    if (n + 1 < ncb) block(n + 1, rbA, second, x0, x1, bfb, bfa);
+                }
+            } else {   // one fragment set, read when the col-block starts (the SIMD's other wave covers the LDS round trip)
+                for (int n = 0; n < ncb; ++n) {
+#pragma unroll
+                    for (int g = 0; g < KG; ++g) bfa[g] = sBh[(n * KG + g) * 64];
+                    block(n, rbA, second, x0, x1, bfa, bfa);
+                }
             }
             PS_STAMP(2)
             pair_done();
