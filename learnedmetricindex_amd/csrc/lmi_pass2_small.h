@@ -11,13 +11,15 @@
 //     are private to the wave: no LDS, no barrier) one pair ahead, and walks the col-blocks: KG MFMAs per (row-block,
 //     col-block) chained on one 16-register accumulator, tested (pass 2) or reduced to its maximum (pass 1) at once;
 //   * no K loop, no ring, no stage barrier; four waves per block, two blocks per CU (three fit the LDS at KG <= 4 but leave pass 2 too few registers);
+//     K > 64: ONE row-block at a time instead of a pair (registers), query tiles of 8 / 7 / 6 col-blocks at 5-6 / 7 / 8 k16-groups (LDS);
 //   * pass 2's candidates (round 4, K <= 64): the kernel is bound by VALU ISSUE, not by bytes or the matrix pipe -- PMC at C5: 16 vector
 //     instructions per MFMA, the matrix pipe 11 % busy -- and two thirds of the 32 x 32 blocks hold a candidate (~42 per column and
 //     39 k-row bucket), so the per-register search for it WAS the kernel.  Now a block's test is one 8-instruction max tree + one
 //     compare; a LANE whose 16 scores hold a candidate spills the 16 scores (4 ds_write_b128) + a tag into a wave-private ring in
 //     LDS, and whenever the ring holds 64 entries the wave drains them in parallel -- lane i takes entry i, finds its hits (almost
 //     always one), issues their position atomics, and stores row / score at the NEXT drain (nobody waits for an atomic's round trip).
-//     K > 64 keeps round 3's per-register path (its query tile leaves no LDS for the ring at two blocks per CU).
+//     Every K <= 128 takes this path since round 4 (until then K > 64 kept round 3's per-register path: 1 270 / 1 436 spilled registers at
+//     5 / 6 k16-groups, one wave per SIMD at 7 / 8: 0.13 / 0.13 / 0.24 / 0.30 of the HBM roofline at d = 80 / 96 / 112 / 128, now 0.43 / 0.43 / 0.41 / 0.46).
 // Work items, queues, bounds, candidate buffers and the accumulation order (k-groups in order from 0, so shat is bit-identical
 // to pass2_kernel's) are those of lmi_pass2.h: the host picks the kernel by KG16 alone.
 #pragma once
@@ -36,24 +38,18 @@ constexpr int PS_WAVES = LMI_PS_WAVES;   // waves per block (they share the quer
 #ifndef LMI_PS_SPILL
 #define LMI_PS_SPILL 96
 #endif
-#ifndef LMI_PS_SPILL_KG
-#define LMI_PS_SPILL_KG 6
-#endif
-constexpr int PS_SPILL = LMI_PS_SPILL;        // entries of a wave's spill ring (pass 2, K <= 64): 64 scores + tag each
-constexpr int PS_SPILL_KG = LMI_PS_SPILL_KG;  // ... used up to this many k16-groups
-constexpr int PS_ROW_BITS = 23;   // list entry = column in the tile (9 bits) << 23 | row in the item's chunk (a chunk is at most 2^31 / 1024 rows)
+constexpr int PS_SPILL = LMI_PS_SPILL;        // entries of a wave's spill ring (pass 2): 64 scores + tag each
 
-// col-blocks per query tile: K = 65..96 (5 / 6 k16-groups) takes tiles of 8, so that two blocks per CU hold the tile AND the spill ring
-// (round 4: these two shapes were on the per-register path with 1 270 / 1 436 spilled registers: 0.13 of the HBM roofline at d = 80 / 96)
-__host__ __device__ constexpr int ps_tile_cb(int kg) { return kg == 5 || kg == 6 ? 8 : P2_MAXCB; }
-__host__ __device__ constexpr int ps_spill_bytes(int kg) { return kg <= PS_SPILL_KG ? PS_WAVES * PS_SPILL * (64 + 4) : 0; }
+// col-blocks per query tile: K > 64 takes smaller tiles, so that two blocks per CU hold the tile AND the spill ring
+__host__ __device__ constexpr int ps_tile_cb(int kg) { return kg <= 4 ? P2_MAXCB : kg <= 6 ? 8 : kg == 7 ? 7 : 6; }
+__host__ __device__ constexpr int ps_spill_bytes(int) { return PS_WAVES * PS_SPILL * (64 + 4); }
 __host__ __device__ constexpr int ps_lds_bytes(int kg) { return ps_tile_cb(kg) * kg * 1024 + ps_tile_cb(kg) * 32 * 4 + ps_spill_bytes(kg); }
 constexpr int PS_PREFIX_CAP = 257;   // buckets + 1 of a queue group held in LDS (more: the global prefix is searched)
 #ifndef LMI_PS_BLOCKS4
 #define LMI_PS_BLOCKS4 2   // blocks per CU at KG <= 4 (LDS allows 3, but pass 2 then has 168 registers and spills 175: 0.47 -> 1.06 ms)
 #endif
-__host__ __device__ constexpr int ps_blocks_per_cu(int kg) { return kg <= 4 ? LMI_PS_BLOCKS4 : kg <= 6 ? 2 : 1; }   // LDS: 160 KiB per CU
-static_assert(PS_SPILL >= 128 - 32 && 2 * (ps_lds_bytes(6) + 4096) <= 160 * 1024 && 2 * (ps_lds_bytes(4) + 4096) <= 160 * 1024 && ps_lds_bytes(PS_MAXKG) + 4096 <= 160 * 1024, "LDS budget (dynamic + ~3 KiB static)");
+__host__ __device__ constexpr int ps_blocks_per_cu(int kg) { return kg <= 4 ? LMI_PS_BLOCKS4 : 2; }   // LDS: 160 KiB per CU
+static_assert(PS_SPILL >= 128 - 32 && 2 * (ps_lds_bytes(6) + 4096) <= 160 * 1024 && 2 * (ps_lds_bytes(4) + 4096) <= 160 * 1024 && 2 * (ps_lds_bytes(7) + 4096) <= 160 * 1024 && 2 * (ps_lds_bytes(8) + 4096) <= 160 * 1024, "LDS budget (dynamic + ~3 KiB static)");
 
 template <int KG, bool SAMPLE>
 __global__ __launch_bounds__(64 * PS_WAVES, ps_blocks_per_cu(KG) * PS_WAVES / 4) void pass2_small_kernel(PrefilterParams P) {
@@ -61,13 +57,20 @@ __global__ __launch_bounds__(64 * PS_WAVES, ps_blocks_per_cu(KG) * PS_WAVES / 4)
     constexpr int TCB = ps_tile_cb(KG);                                       // col-blocks per query tile
     uint4* sB = reinterpret_cast<uint4*>(ps_smem);                            // [col-blocks of the tile][KG][64 lanes]
     float* sThr = reinterpret_cast<float*>(ps_smem + TCB * KG * 1024);        // [TCB * 32] emission thresholds (pass 2)
-    constexpr bool SPILL = !SAMPLE && KG <= PS_SPILL_KG;   // pass 2's lane-granular spill ring (file header)
-    constexpr bool B2 = KG <= 4 || SAMPLE;                 // two query-fragment sets taking turns (K <= 64; beyond, pass 2 has no registers for the second)
+    constexpr bool SPILL = !SAMPLE;   // pass 2's lane-granular spill ring (file header)
+#ifndef LMI_PS_PAIR_KG
+#define LMI_PS_PAIR_KG 4
+#endif
+    // A wave's unit of work: a PAIR of row-blocks at K <= 64 (a query fragment feeds two MFMAs), ONE row-block beyond -- two sets of a pair's
+    // fragments are 16 KG registers (K = 96: with pairs 42 spilled registers and one query-fragment set; single row-blocks: none, two sets;
+    // pass 2 at d = 80 / 96: 0.580 / 0.660 -> 0.472 / 0.562 ms; at d = 45 / 64 pairs stay 1-4 % ahead; profiles/r04_pass2_experiments.txt section 10)
+    constexpr bool PAIR = KG <= LMI_PS_PAIR_KG;
+    constexpr bool B2 = KG <= 4 || SAMPLE || !PAIR;        // two query-fragment sets taking turns
+    constexpr int KG1 = PAIR ? KG : 1;                     // (the second row-block's fragment arrays)
     float4* sSpill = reinterpret_cast<float4*>(ps_smem + TCB * KG * 1024 + TCB * 32 * 4);   // [waves][PS_SPILL][4] the 16 scores of an entry
     unsigned* sTag = reinterpret_cast<unsigned*>(sSpill + PS_WAVES * PS_SPILL * 4);                    // [waves][PS_SPILL] column in the tile | row base << 9
     __shared__ int s_item[2];
     __shared__ int s_prefix[PS_PREFIX_CAP];
-    __shared__ uint2 s_list[(SAMPLE || SPILL) ? 1 : PS_WAVES * 64];   // K > 64: a wave's candidates of one row-block pair (key, score bits)
     if (!SAMPLE && P.redo_count && *P.redo_count == 0u) return;  // the redo launch of a batch without overflowed columns
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -110,20 +113,20 @@ __global__ __launch_bounds__(64 * PS_WAVES, ps_blocks_per_cu(KG) * PS_WAVES / 4)
         const int m_left = item_m_use - item_cbt0 * 32;   // live columns of the tile from its first one
         const size_t col0 = (size_t)cb_tile * 32;
         const uint4* aslab = P.slab16 + (size_t)P.rb_start[b] * KG * 64 + lane;
-        const int npairs = (nrb + 1) >> 1;
+        const int npairs = PAIR ? (nrb + 1) >> 1 : nrb;   // units of the item
         const int list_j = item_ch % P2_NSL;
         const bool use_atomic = SAMPLE && p2_sample_tiles(n_b) > P2_NSL;   // more sampled tiles than lists: every tile folds with the atomic
-        half8 a0[KG], a1[KG];
-        auto load_pair = [&](int pp, half8 (&x0)[KG], half8 (&x1)[KG]) __attribute__((always_inline)) {
-            const uint4* pa = aslab + (size_t)min(rb0 + 2 * pp, rb_last) * (KG * 64);
+        half8 a0[KG], a1[KG1];
+        auto load_pair = [&](int pp, half8 (&x0)[KG], half8 (&x1)[KG1]) __attribute__((always_inline)) {
+            const uint4* pa = aslab + (size_t)min(rb0 + (PAIR ? 2 : 1) * pp, rb_last) * (KG * 64);
             const uint4* pb = aslab + (size_t)min(rb0 + 2 * pp + 1, rb_last) * (KG * 64);
 #pragma unroll
             for (int g = 0; g < KG; ++g) {
                 x0[g] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(pa + g * 64));
-                x1[g] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(pb + g * 64));
+                if constexpr (PAIR) x1[g] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(pb + g * 64));
             }
         };
-        half8 b0[KG], b1[KG];
+        half8 b0[KG], b1[KG1];
         {
             // the query tile -> LDS: every load of a thread in flight before its first LDS store (one memory round trip, not one per step)
             const uint4* bsrc = P.qfrag16 + (size_t)cb_tile * KG * 64;   // the tile's col-blocks are consecutive
@@ -148,72 +151,12 @@ __global__ __launch_bounds__(64 * PS_WAVES, ps_blocks_per_cu(KG) * PS_WAVES / 4)
         }
         __syncthreads();
         PS_STAMP(0)
-        uint2* my_list = s_list + ((SAMPLE || SPILL) ? 0 : w * 64);
         float4* my_spill = sSpill + w * (PS_SPILL * 4);
         unsigned* my_tag = sTag + w * PS_SPILL;
-        int tot = 0;    // wave-uniform.  K > 64: candidates of the current pair in my_list (entries past 63 went out directly);
-                        // K <= 64: entries in the wave's spill ring, the oldest at `head`
+        int tot = 0;    // wave-uniform: entries in the wave's spill ring, the oldest at `head`
         int head = 0;
         // One (row-block, col-block) block of 32 x 32 scores: lane (h, c) holds column c, rows 4 h + (r & 3) + 8 (r >> 2).
-        //   group_max  maximum of register group j (rows 8 j + 4 h + 0..3); v_max3 as asm: fmaxf() costs a canonicalising
-        //              v_max per operand, and v_max3 returns the other operands for a NaN (the masked rows of pass 2)
-        //   settle     pass 1: the lane's maximum -> its slot of the list; pass 2: candidates -> the wave's list
-        auto group_max = [&](const f32x16& acc, int j) __attribute__((always_inline)) -> float {
-            float t, m;
-            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(acc[4 * j]), "v"(acc[4 * j + 1]), "v"(acc[4 * j + 2]));
-            asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(t), "v"(acc[4 * j + 3]));
-            return m;
-        };
-        auto settle = [&](const f32x16& acc, const float (&gm)[4], float thr, int rb, int n) __attribute__((always_inline)) {
-            float t, mx;
-            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(gm[0]), "v"(gm[1]), "v"(gm[2]));
-            asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(t), "v"(gm[3]));
-            if (SAMPLE) {
-                if (n * 32 + c < m_left) {
-                    // lists are COLUMN-minor: [list][slot = 2 (row-block in the tile) + h][column]
-                    float* dst = P.bound + ((size_t)(list_j * 16 + (rb - rb0) * 2 + h)) * (size_t)P.ncols + (col0 + n * 32 + c);
-                    if (!use_atomic) *dst = mx;
-                    else {  // monotone float max through the order-preserving integer image
-                        if (mx >= 0.0f) atomicMax(reinterpret_cast<int*>(dst), __float_as_int(mx));
-                        else atomicMin(reinterpret_cast<unsigned*>(dst), __float_as_uint(mx));
-                    }
-                }
-            } else {
-                bool any = mx >= thr;   // thr = +inf for idle columns
-#ifdef LMI_ABL_NOEMIT   // timing-only ablation: no candidate is ever emitted (wrong results)
-                any = any && thr == 12345.678f;
-#endif
-                // About one score in a thousand passes (~40 candidates per column and bucket), i.e. about every second block
-                // has one: the path below is not rare.  Group maxima first: a block with one candidate tests 4 + 4 values, not 16.
-                if (__builtin_expect(__ballot(any) != 0ull, 0)) {
-                    const unsigned rowh = (unsigned)((rb - rb0) * 32 + 4 * h);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (__ballot(gm[j] >= thr) == 0ull) continue;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const bool pass = acc[4 * j + i] >= thr;
-                            const unsigned long long mask = __ballot(pass);
-                            if (mask == 0ull) continue;
-                            const unsigned row = rowh + (unsigned)(i + 8 * j);   // in the chunk
-                            if (pass) {
-                                const int my = tot + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                                if (my < 64) {
-                                    my_list[my] = make_uint2(((unsigned)(n * 32 + c) << PS_ROW_BITS) | row, __float_as_uint(acc[4 * j + i]));
-                                } else {   // a pair with more than 64 candidates: the rest goes out at once
-                                    const size_t col = col0 + n * 32 + c;
-                                    const unsigned pos = atomicAdd(P.cand_cnt + col, 1u);
-                                    cand_store(P, col, pos, (unsigned)(rb0 * 32) + row, acc[4 * j + i]);
-                                }
-                            }
-                            tot += (int)__popcll(mask);
-                        }
-                    }
-                }
-            }
-        };
-        // the block's maximum by a flat v_max3 tree (8 instructions; the grouped form above costs 10 and is only worth it where the
-        // groups steer the per-register search)
+        // the block's maximum by a flat v_max3 tree (8 instructions)
         auto flat_max = [&](const f32x16& acc) __attribute__((always_inline)) -> float {
             float m0, m1, m2, m3, m4;
             asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m0) : "v"(acc[0]), "v"(acc[1]), "v"(acc[2]));
@@ -313,9 +256,9 @@ __global__ __launch_bounds__(64 * PS_WAVES, ps_blocks_per_cu(KG) * PS_WAVES / 4)
         // the block's test
         auto finish = [&](f32x16& acc, int rb, int n, float thr_n) __attribute__((always_inline)) {
             mask_rows(acc, rb);
-            if constexpr (SPILL) {
+            if constexpr (!SAMPLE) {
                 spill(acc, flat_max(acc), thr_n, rb, n);
-            } else if constexpr (SAMPLE) {   // pass 1: the lane's maximum -> its slot of the list
+            } else {   // pass 1: the lane's maximum -> its slot of the list
                 const float mx = flat_max(acc);
                 if (n * 32 + c < m_left) {
                     // lists are COLUMN-minor: [list][slot = 2 (row-block in the tile) + h][column]
@@ -326,37 +269,18 @@ __global__ __launch_bounds__(64 * PS_WAVES, ps_blocks_per_cu(KG) * PS_WAVES / 4)
                         else atomicMin(reinterpret_cast<unsigned*>(dst), __float_as_uint(mx));
                     }
                 }
-            } else {
-                float gm[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) gm[j] = group_max(acc, j);
-                settle(acc, gm, thr_n, rb, n);
             }
         };
-        // the pair's candidates: lane i takes list entry i -- its position atomic goes out now, its two stores when the NEXT
-        // pair is done (the atomic's round trip is about one pair's time: nobody waits for it)
+        // a unit's end: full batches of the ring go out (the rest waits for company)
         auto pair_done = [&]() __attribute__((always_inline)) {
-            if (SAMPLE) return;
-            if constexpr (SPILL) {
+            if constexpr (!SAMPLE) {
                 while (tot >= 64) drain();
-                return;
-            }
-            flush_pending();
-            if (tot > 0) {
-                if (lane < min(tot, 64)) {
-                    const uint2 e = my_list[lane];
-                    pend_col = col0 + (e.x >> PS_ROW_BITS);
-                    pend_row = (unsigned)(rb0 * 32) + (e.x & ((1u << PS_ROW_BITS) - 1u));
-                    pend_s = __uint_as_float(e.y);
-                    pend_pos = atomicAdd(P.cand_cnt + pend_col, 1u);
-                }
-                tot = 0;
             }
         };
         const half8* sBh = reinterpret_cast<const half8*>(sB) + lane;
         // A pair of row-blocks against every col-block of the tile.  The fragments of col-block n + 1 are requested before the
         // MFMAs of col-block n (two fragment sets taking turns): the LDS latency is off the MFMA chain.
-        auto block = [&](int n, int rbA, bool second, const half8 (&x0)[KG], const half8 (&x1)[KG], const half8 (&bfc)[KG],
+        auto block = [&](int n, int rbA, bool second, const half8 (&x0)[KG], const half8 (&x1)[KG1], const half8 (&bfc)[KG],
                          auto& bfn) __attribute__((always_inline)) {
             const int nn = min(n + 1, ncb - 1);
             const float thr_n = SAMPLE ? 0.0f : sThr[n * 32 + c];   // requested ahead of the MFMAs: no LDS round trip in front of the test
@@ -364,19 +288,26 @@ __global__ __launch_bounds__(64 * PS_WAVES, ps_blocks_per_cu(KG) * PS_WAVES / 4)
 #pragma unroll
                 for (int g = 0; g < KG; ++g) bfn[g] = sBh[(nn * KG + g) * 64];
             }
-            f32x16 c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x0[0], bfc[0], zero, 0, 0, 0);
-            f32x16 c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x1[0], bfc[0], zero, 0, 0, 0);
+            if constexpr (PAIR) {
+                f32x16 c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x0[0], bfc[0], zero, 0, 0, 0);
+                f32x16 c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x1[0], bfc[0], zero, 0, 0, 0);
 #pragma unroll
-            for (int g = 1; g < KG; ++g) {
-                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x0[g], bfc[g], c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x1[g], bfc[g], c1, 0, 0, 0);
+                for (int g = 1; g < KG; ++g) {
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x0[g], bfc[g], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x1[g], bfc[g], c1, 0, 0, 0);
+                }
+                finish(c0, rbA, n, thr_n);
+                if (second) finish(c1, rbA + 1, n, thr_n);   // (the chunk's odd last row-block has no partner: a clamped re-read)
+            } else {
+                f32x16 c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x0[0], bfc[0], zero, 0, 0, 0);
+#pragma unroll
+                for (int g = 1; g < KG; ++g) c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x0[g], bfc[g], c0, 0, 0, 0);
+                finish(c0, rbA, n, thr_n);
             }
-            finish(c0, rbA, n, thr_n);
-            if (second) finish(c1, rbA + 1, n, thr_n);   // (the chunk's odd last row-block has no partner: a clamped re-read)
         };
-        auto do_pair = [&](int p, const half8 (&x0)[KG], const half8 (&x1)[KG]) __attribute__((always_inline)) {
-            const int rbA = rb0 + 2 * p;
-            const bool second = 2 * p + 1 < nrb;   // wave-uniform
+        auto do_pair = [&](int p, const half8 (&x0)[KG], const half8 (&x1)[KG1]) __attribute__((always_inline)) {
+            const int rbA = rb0 + (PAIR ? 2 : 1) * p;
+            const bool second = PAIR && 2 * p + 1 < nrb;   // wave-uniform
 #ifdef LMI_P2_STAMPS
             if (!SAMPLE) { asm volatile("s_waitcnt vmcnt(12)" : "+v"(const_cast<half8&>(x0[0])) :: "memory"); st_acc[7] += 1; }
             PS_STAMP(1)
