@@ -969,7 +969,7 @@ extern "C" LMI_API int lmi_mlp_proba(lmi_index* h, const float* queries_nav, int
 
 // the exact re-rank runs in its streamed form (select_kernel + rescore_kernel, lmi_rescore.h) for these shapes
 static bool rescore_is_streamed(const lmi_index* h) {
-    return h->rescore_streamed && h->dp <= RS_MAXD && RC_WAVES * rc_wave_lds(h->dp, 4) <= 160 * 1024;
+    return h->rescore_streamed && rc_waves_for(h->dp, 4) > 0 && rc_wave_lds(h->dp, 4, true) <= 64 * 1024;
 }
 static int rescore_group_size(int nb) { return nb % 4 == 0 ? 4 : nb % 3 == 0 ? 3 : nb % 2 == 0 ? 2 : 1; }
 
@@ -1287,11 +1287,14 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
             O.big = O.active + RC_SUB + RC_SUB * sub_cap;
             select_kernel<<<cdiv(nslots, 4), 256, 0, h->stream>>>(Q, O);
             HIPCHK(hipGetLastError());
-            const int blocks = cdiv(groups, RC_WAVES);
-            const int lds = RC_WAVES * rc_wave_lds(h->dp, G), lds_s = RC_WAVES * rc_wave_lds(h->dp, G, true);
+            // (wide rows: fewer waves per block in the big form, whose per-wave buffers hold the query and 256 survivors per slot; the small
+            // form keeps four waves as long as a block stays under 64 KiB)
+            const int wb = rc_waves_for(h->dp, G), ws = RC_WAVES * rc_wave_lds(h->dp, G, true) <= 64 * 1024 ? RC_WAVES : 1;
+            const int blocks = cdiv(groups, ws);
+            const int lds = wb * rc_wave_lds(h->dp, G), lds_s = ws * rc_wave_lds(h->dp, G, true);
             // first every group in the small-LDS form (three blocks per CU), then the groups it passed on (more survivors than it holds)
-#define LMI_RC_LAUNCH(GV) { rescore_kernel<GV, true><<<blocks, 64 * RC_WAVES, lds_s, h->stream>>>(Q, O); \
-                            rescore_kernel<GV, false><<<std::min(blocks, h->num_cus), 64 * RC_WAVES, lds, h->stream>>>(Q, O); }
+#define LMI_RC_LAUNCH(GV) { rescore_kernel<GV, true><<<blocks, 64 * ws, lds_s, h->stream>>>(Q, O); \
+                            rescore_kernel<GV, false><<<std::min(cdiv(groups, wb), h->num_cus), 64 * wb, lds, h->stream>>>(Q, O); }
             if (G == 4) LMI_RC_LAUNCH(4) else if (G == 3) LMI_RC_LAUNCH(3) else if (G == 2) LMI_RC_LAUNCH(2) else LMI_RC_LAUNCH(1)
 #undef LMI_RC_LAUNCH
             HIPCHK(hipGetLastError());

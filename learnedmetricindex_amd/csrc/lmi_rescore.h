@@ -15,7 +15,9 @@
 //                    over chunk c of row r (q broadcast from LDS).  The wave owns its buffers: no barriers, the
 //                    ring is ordered by the wave's own counted `s_waitcnt vmcnt`.  Then, per slot, the 10 best by
 //                    (score desc, row asc) become the slot's rank list exactly as before.
-// Used when the row pitch (d rounded up to 4: the f32 rows are zero-padded to 16-byte multiples) is <= RS_MAXD; wider shapes keep select_rescore_kernel.  Results are bit-identical
+// Used for every row pitch (d rounded up to 4: the f32 rows are zero-padded to 16-byte multiples) whose per-wave buffers fit the LDS (the
+// host launches 4, 2 or 1 waves per block, rc_waves_for: d <= 1 126 / 8 700 / 28 000; round 4 -- until then d > 1 024 kept select_rescore_kernel,
+// 2.2 x slower at d = 1 536 / 2 048).  Results are bit-identical
 // (same chain, same selection rule); tests/test_gpu_prefilter.py runs both.
 #pragma once
 #include <type_traits>
@@ -182,6 +184,12 @@ constexpr int RC_SMALL_RING = 8 * 1024;           // chunk buffers of the small 
 // dynamic LDS per wave: chunk buffers | q [d] | rows [KEEPW] | scores [KEEPW]
 __host__ __device__ inline int rc_wave_lds(int d, int G, bool small_form = false) {
     return small_form ? RC_SMALL_RING + d * 4 + 32 * 8 : RC_DEPTH * RC_BUF + d * 4 + G * RC_KEEP * 8;
+}
+// waves per block for rows of pitch d: as many of RC_WAVES as the big form's per-wave LDS allows (0: the shape does not fit at all)
+__host__ inline int rc_waves_for(int d, int G) {
+    for (int w = RC_WAVES; w >= 1; w >>= 1)
+        if (w * rc_wave_lds(d, G) <= 160 * 1024 - 512) return w;
+    return 0;
 }
 static_assert(RC_CHUNK % 32 == 0 && (RC_ROWS == 32 || RC_ROWS == 64) && RC_DEPTH >= 2 && RC_DEPTH <= 4, "rescore_kernel shapes");
 
@@ -361,7 +369,8 @@ template <int G, bool SMALL>
 __global__ __launch_bounds__(64 * RC_WAVES, SMALL ? 3 : 1) void rescore_kernel(RescoreParams P, SelectOut O) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rc_smem[];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int wid = blockIdx.x * RC_WAVES + wv;
+    const int nwv = (int)(blockDim.x >> 6);   // waves of the block: RC_WAVES, fewer for rows so wide that four waves' buffers pass 160 KiB
+    const int wid = blockIdx.x * nwv + wv;
     if (SMALL) {
         // wave wid -> the wid-th entry of the concatenated sub-lists (inclusive prefix of the 64 counts across the lanes)
         int incl = O.active[lane];
@@ -378,7 +387,7 @@ __global__ __launch_bounds__(64 * RC_WAVES, SMALL ? 3 : 1) void rescore_kernel(R
         // the passed-on groups are few (none on most batches): a grid of one block per CU walks the list, so that an empty list
         // costs one launch of 256 blocks and not one block (148 KiB of LDS each, one per CU at a time) per four groups
         const int nbig = __builtin_amdgcn_readfirstlane(O.big[0]);
-        for (int i = wid; i < nbig; i += (int)gridDim.x * RC_WAVES) {
+        for (int i = wid; i < nbig; i += (int)gridDim.x * nwv) {
             rescore_group<G, false>(P, O, rc_smem, wv, lane, O.big[1 + i] * G);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the wave's LDS lists are rewritten by its next group
             __builtin_amdgcn_wave_barrier();

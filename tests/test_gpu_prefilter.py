@@ -273,3 +273,35 @@ def test_narrow_query_tiles_in_long_chunks(capi, oracle, d):
         D, I = oracle.knn_ip(Q[qsel], X[rows], 10)
         np.testing.assert_array_equal(ii, (rows[I] + 1).astype(np.uint32))
         np.testing.assert_array_equal(dd, np.float32(1) - D)
+
+
+@pytest.mark.parametrize("d", [1100, 1536, 3000, 9000])
+def test_wide_rows_take_the_streamed_rerank(capi, oracle, d):
+    """Rows wider than four waves' re-rank buffers (d > 1 126: two waves per block up to ~8 700, one beyond; the small form one wave
+    per block from ~2 000) keep select_kernel + rescore_kernel (round 4; before: select_rescore_kernel).  A cluster of 120 near-copies
+    puts groups on the `big` list (more survivors than the small form holds).  Prefilter, exact mode and the oracle agree bit for bit."""
+    rs = np.random.RandomState(d)
+    L, nq, nb = 5, 160, 2
+    sizes = [900, 33, 1500, 700, 1200]
+    labels = np.concatenate([np.full(n, b) for b, n in enumerate(sizes)]).astype(np.int64)
+    rs.shuffle(labels)
+    centres = rs.randn(L, d).astype(np.float32)
+    X = centres[labels] + rs.randn(labels.size, d).astype(np.float32)
+    dup = np.flatnonzero(labels == 2)[:120]
+    X[dup] = X[dup[0]] + 1e-4 * rs.randn(120, d).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    qc = rs.randint(0, L, nq)
+    Q = centres[qc] + rs.randn(nq, d).astype(np.float32)
+    Q[:20] = X[dup[0]] + 0.05 * rs.randn(20, d).astype(np.float32)   # queries next to the cluster of copies
+    qc[:20] = 2
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    order = np.stack([np.concatenate([[qc[i]], rs.permutation(np.delete(np.arange(L), qc[i]))[: nb - 1]]) for i in range(nq)]).astype(np.int32)
+    (d1, i1, sv, fb), (d0, i0, _, _) = both_modes(capi, X, labels, L, Q, order)
+    assert fb == 0
+    np.testing.assert_array_equal(i1, i0)
+    np.testing.assert_array_equal(d1, d0)
+    for q in (0, 5, 40, nq - 1):
+        rows = np.flatnonzero(np.isin(labels, order[q]))
+        D, I = oracle.knn_ip(Q[q:q + 1], X[rows], 10)
+        np.testing.assert_array_equal(i1[q:q + 1], (rows[I] + 1).astype(np.uint32))
+        np.testing.assert_array_equal(d1[q:q + 1], np.float32(1) - D)
