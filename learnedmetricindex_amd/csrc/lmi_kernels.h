@@ -318,7 +318,10 @@ struct RouteArrays {
 
 // ---- prefilter pass 1: which tiles of a bucket are sampled (shared by the routing kernels and lmi_prefilter.h / lmi_pass2.h) ----
 #ifndef LMI_PF_SAMPLE_ROWS
-#define LMI_PF_SAMPLE_ROWS 2000  // a bucket is sampled at stride s only if it has >= this many rows per unit of s (1300..3500: within 1 %)
+#define LMI_PF_SAMPLE_ROWS 512   // a bucket is sampled at stride s only if it has >= this many rows per unit of s.  Round 4: 2 000 -> 512 -- with 2 000 a
+                                 // bucket under 4 000 rows was "sampled" whole (pass 1 = a second pass 2: at 2 000 leaves over 4M rows pass 1 1.32 ms
+                                 // against pass 2's 1.22); 512: +7..22 % queries/s on 500-2 000-leaf shapes, C2 / hard / C1 / C5 unchanged (their
+                                 // buckets sit at stride 16 either way; 256 loses at d <= 128: profiles/r04_pass2_experiments.txt section 12)
 #endif
 #ifndef LMI_PF_SAMPLE
 #define LMI_PF_SAMPLE 16
