@@ -699,7 +699,9 @@ extern "C" LMI_API int lmi_buckets_end(lmi_index* h) {
         CHK(h->xscale.reserve(16));
         CHK(h->bnorm.reserve((size_t)h->L * 4));
         CHK(h->bdelta.reserve((size_t)h->L * 4));
-        CHK(h->slab16.reserve((size_t)h->n_rb_total * h->KG16 * 1024));
+        // (+ 8 KiB: pass2_kernel's look-ahead requests up to two stages = 4 KiB past the last row-block's fragments before it learns that
+        // the item is over; the data is never used, the addresses must be the allocation's)
+        CHK(h->slab16.reserve((size_t)h->n_rb_total * h->KG16 * 1024 + 8192));
         HIPCHK(hipMemsetAsync(h->xmaxbits.p, 0, 16, h->stream));
         HIPCHK(hipMemsetAsync(h->bnorm.p, 0, (size_t)h->L * 4, h->stream));
         HIPCHK(hipMemsetAsync(h->bdelta.p, 0, (size_t)h->L * 4, h->stream));
@@ -1068,7 +1070,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         CHK(h->qnorm.reserve((size_t)nq * 4));
         CHK(h->qdelta.reserve((size_t)nq * 4));
         CHK(h->qscale.reserve((size_t)nq * 4));
-        CHK(h->qfrag16.reserve((size_t)ncb_bound * h->KG16 * 1024));
+        CHK(h->qfrag16.reserve((size_t)ncb_bound * h->KG16 * 1024 + 8192));   // (+ 8 KiB: the same look-ahead on the query fragments)
         CHK(h->eps2.reserve(ncols * 4));
         CHK(h->cand_cnt.reserve(ncols * 4));
         CHK(h->cand_row.reserve(ncols * PF_CAP * 4));

@@ -338,18 +338,34 @@ __device__ __forceinline__ int sample_stride(int n_b) {
 // at the full rate, the others at 1 / P1_ALL_EVERY of it -- enough of an own bound that their candidate buffers cannot overflow
 // when the query's bound (query_bound_kernel) turns out loose for their bucket (10 x the stride x P1_ALL_EVERY rows pass).
 constexpr int P1_ALL_EVERY = 2;
+// An item takes up to P1_TPI sampled tiles of ONE class (the even ones: all columns; the odd ones: primary columns), two sampled tiles apart:
+// the item's fixed costs (queue ticket, cold ring / query tile staged in LDS, barriers) are paid once for them (round 4; 1 = round 3's items).
+#ifndef LMI_P1_TPI
+#define LMI_P1_TPI 2
+#endif
+constexpr int P1_TPI = LMI_P1_TPI;
+static_assert(P1_ALL_EVERY == 2 && P1_TPI >= 1, "the two classes are the even and the odd sampled tiles");
 __device__ __forceinline__ int pass1_items(int nst, int nqt_all, int nqt_primary) {
-    const int n_all = (nst + P1_ALL_EVERY - 1) / P1_ALL_EVERY;
-    return n_all * nqt_all + (nst - n_all) * nqt_primary;
+    const int n_all = (nst + 1) / 2, n_pri = nst / 2;
+    return ((n_all + P1_TPI - 1) / P1_TPI) * nqt_all + ((n_pri + P1_TPI - 1) / P1_TPI) * nqt_primary;
 }
-// item `local` of the bucket -> sampled tile j and query tile qt; returns whether the tile runs over all columns
-__device__ __forceinline__ bool pass1_decode(int local, int nqt_all, int nqt_primary, int* j, int* qt) {
-    const int per = nqt_all + (P1_ALL_EVERY - 1) * nqt_primary;   // items of one group of P1_ALL_EVERY sampled tiles
-    const int grp = local / per, rem = local - grp * per;
-    if (rem < nqt_all) { *j = grp * P1_ALL_EVERY; *qt = rem; return true; }
-    const int r2 = rem - nqt_all;
-    *j = grp * P1_ALL_EVERY + 1 + r2 / nqt_primary;
-    *qt = r2 % nqt_primary;
+// item `local` of a bucket with nst sampled tiles -> its first sampled tile j0, the number of tiles nt (j0, j0 + 2, ..) and the query tile
+// qt; returns whether the item runs over all columns
+__device__ __forceinline__ bool pass1_decode(int local, int nst, int nqt_all, int nqt_primary, int* j0, int* nt, int* qt) {
+    const int n_all = (nst + 1) / 2, n_pri = nst / 2;
+    const int g_all = (n_all + P1_TPI - 1) / P1_TPI;
+    if (local < g_all * nqt_all) {
+        const int g = local / nqt_all;
+        *qt = local - g * nqt_all;
+        *j0 = g * P1_TPI * 2;
+        *nt = min(P1_TPI, n_all - g * P1_TPI);
+        return true;
+    }
+    local -= g_all * nqt_all;
+    const int g = local / nqt_primary;
+    *qt = local - g * nqt_primary;
+    *j0 = g * P1_TPI * 2 + 1;
+    *nt = min(P1_TPI, n_pri - g * P1_TPI);
     return false;
 }
 __device__ __forceinline__ int sample_tiles256(int n_b) {  // sampled 256-row tiles of a bucket

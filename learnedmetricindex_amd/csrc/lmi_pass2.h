@@ -517,11 +517,12 @@ struct Tile2 {
 
     // The tile = col-blocks [cbt0, cbt0 + NCB) of bucket b.  !SAMPLE: `ch` = chunk of the bucket, every tile of it;
     // SAMPLE: `ch` = sampled tile j of the bucket (tile j * stride), one tile.
-    __device__ __forceinline__ void run(int b_, int cbt0_, int ch_, int m_use_) {
+    __device__ __forceinline__ void run(int b_, int cbt0_, int ch_, int m_use_, int nt_) {
         // the item came through LDS (s_item): tell the compiler it is wave-uniform, so that every address derived from it is
         // scalar (the vector loads take their base as an "s" operand)
         const int b = __builtin_amdgcn_readfirstlane(b_), cbt0 = __builtin_amdgcn_readfirstlane(cbt0_);
         const int ch = __builtin_amdgcn_readfirstlane(ch_), m_use = __builtin_amdgcn_readfirstlane(m_use_);
+        const int nt = __builtin_amdgcn_readfirstlane(nt_);
 #ifdef LMI_P2_STAMPS
         for (int i = 0; i < 12; ++i) st_acc[i] = 0;
         st_last = __builtin_readcyclecounter();
@@ -535,8 +536,13 @@ struct Tile2 {
         const int nrb_b = (n_b + 31) >> 5;
         const int stride = SAMPLE ? sample_stride(n_b) : 1;
         const int rb0 = SAMPLE ? ch * stride * P2_TILE_RB : ch * P.chunk_rb;
-        const int nrb_all = SAMPLE ? min(P2_TILE_RB, nrb_b - rb0) : min(P.chunk_rb, nrb_b - rb0);
-        const int nvt = (nrb_all + P2_WAVES - 1) / P2_WAVES;   // block tiles of P2_WAVES row-blocks
+        const int nrb_all = SAMPLE ? P2_TILE_RB : min(P.chunk_rb, nrb_b - rb0);
+        // block tiles of P2_WAVES row-blocks.  pass 1: the item's nt sampled tiles, each VPT block tiles, 2 stride tiles apart (row-blocks
+        // past the bucket's end are clamped re-reads, masked in the epilogue)
+        constexpr int VPT = P2_TILE_RB / P2_WAVES;
+        const int nvt = SAMPLE ? nt * VPT : (nrb_all + P2_WAVES - 1) / P2_WAVES;
+        const int tile_step = 2 * stride * P2_TILE_RB;
+        auto vt_rb = [&](int v) __attribute__((always_inline)) { return SAMPLE ? rb0 + (v / VPT) * tile_step + (v % VPT) * P2_WAVES : rb0 + v * P2_WAVES; };
         const int cb_tile = P.cb_start[b] + cbt0;
         const int m_left = m_use - cbt0 * 32;   // live columns of the tile from its first one (pass 1: m or m0, see the kernel)
         const size_t col0 = (size_t)cb_tile * 32;
@@ -569,7 +575,7 @@ struct Tile2 {
             t_n = 0;                                                                             \
             if (vt_n + 1 < nvt) {                                                                \
                 ++vt_n; S.b0 = bbase0;                                                           \
-                S.a = abase + ((size_t)min(rb0 + vt_n * P2_WAVES + w, rb_last) * rb_stride) * 16;   \
+                S.a = abase + ((size_t)min(vt_rb(vt_n) + w, rb_last) * rb_stride) * 16;          \
             }                                                                                    \
         }
         // stage u's requests are older than stage u + 1's PA (+ PBL) requests: all but those have landed
@@ -625,7 +631,7 @@ struct Tile2 {
             // (a bucket with more sampled tiles than lists: EVERY tile that shares a list folds with the monotone atomic -- a plain
             // store from tile j could land behind tile j + 16's atomic and discard it: still a valid bound, but a different one from
             // run to run)
-            if (SAMPLE) epilogue_sample(rb0 + vt * P2_WAVES, n_b, col0, m_left, ch % P2_NSL_BIG, p2_sample_tiles(n_b) > P2_NSL_BIG, vt * P2_WAVES);
+            if (SAMPLE) epilogue_sample(vt_rb(vt), n_b, col0, m_left, (ch + 2 * (vt / VPT)) % P2_NSL_BIG, p2_sample_tiles(n_b) > P2_NSL_BIG, (vt % VPT) * P2_WAVES);
             else epilogue_emit(rb0 + vt * P2_WAVES, n_b, col0);
             P2_STAMP(3)
         }
@@ -717,18 +723,19 @@ __global__ void query_bound_kernel(const int* __restrict__ slot_col, int nq, int
 // [cbt0, cbt0 + ncb_tile), chunk / sampled tile `ch`, and the live columns m_use.  Returns false when the queues are empty.
 // The XCD-affine queues (route_group_kernel): pass 1 has its own prefixes (items = query tiles x SAMPLED tiles) and heads; a
 // bucket's items go to the same XCD in both passes: its queries' fragments stay in that L2.
-struct P2Item { int b, cbt0, ncb_tile, ch, m_use; };
+struct P2Item { int b, cbt0, ncb_tile, ch, m_use, nt; };   // (nt: pass 1 -- sampled tiles of the item: ch, ch + 2, ..)
 // Item `local` of bucket b.  Query tiles of the bucket: its col-blocks split evenly over nqt = ceil(col-blocks / P.tile_cb) tiles.
-// pass 2: local = chunk * nqt + tile, all columns.  pass 1: pass1_decode -> sampled tile j, query tile; every
-// P1_ALL_EVERY-th sampled tile runs over all the columns, the others over the primary ones (the bucket's first m0).
+// pass 2: local = chunk * nqt + tile, all columns.  pass 1: pass1_decode -> sampled tiles j0, j0 + 2, .. (up to P1_TPI), query tile; the even
+// sampled tiles run over all the columns, the odd ones over the primary ones (the bucket's first m0).
 template <bool SAMPLE>
 __device__ __forceinline__ void p2_decode_item(const PrefilterParams& P, int b, int local, P2Item& it) {
-    int qt = 0, ch = 0;
+    int qt = 0, ch = 0, nt = 1;
     bool all_cols = true;
     if (SAMPLE) {
         const int nqa = query_tiles(P.m[b], P.tile_cb), nqp = query_tiles(P.m0[b], P.tile_cb);
-        all_cols = pass1_decode(local, nqa, nqp, &ch, &qt);
+        all_cols = pass1_decode(local, p2_sample_tiles(P.nb_rows[b]), nqa, nqp, &ch, &nt, &qt);
     }
+    it.nt = nt;
     it.m_use = all_cols ? P.m[b] : P.m0[b];
     const int ncb_b = (it.m_use + 31) >> 5;
     const int nqt = (ncb_b + P.tile_cb - 1) / P.tile_cb;
@@ -858,12 +865,12 @@ __global__ __launch_bounds__(64 * P2_WAVES, 2) __attribute__((amdgpu_num_vgpr(LM
     queue.init();
     P2Item item;
     while (queue.next(item)) {
-        const int b = item.b, cbt0 = item.cbt0, ch = item.ch, m_use = item.m_use;
-#define P2_CASE(N) case N: { Tile2<N, SAMPLE> it{P, (unsigned)reinterpret_cast<uintptr_t>(ring), ring, sList, sThr, sPend}; it.run(b, cbt0, ch, m_use); break; }
+        const int b = item.b, cbt0 = item.cbt0, ch = item.ch, m_use = item.m_use, nt = item.nt;
+#define P2_CASE(N) case N: { Tile2<N, SAMPLE> it{P, (unsigned)reinterpret_cast<uintptr_t>(ring), ring, sList, sThr, sPend}; it.run(b, cbt0, ch, m_use, nt); break; }
         switch (item.ncb_tile) {
             P2_CASE(1) P2_CASE(2) P2_CASE(3) P2_CASE(4) P2_CASE(5) P2_CASE(6)
             P2_CASE(7) P2_CASE(8) P2_CASE(9) P2_CASE(10) P2_CASE(11)
-            default: { Tile2<12, SAMPLE> it{P, (unsigned)reinterpret_cast<uintptr_t>(ring), ring, sList, sThr, sPend}; it.run(b, cbt0, ch, m_use); break; }
+            default: { Tile2<12, SAMPLE> it{P, (unsigned)reinterpret_cast<uintptr_t>(ring), ring, sList, sThr, sPend}; it.run(b, cbt0, ch, m_use, nt); break; }
         }
 #undef P2_CASE
     }

@@ -103,23 +103,31 @@ __global__ __launch_bounds__(64 * PS_WAVES, ps_blocks_per_cu(KG) * PS_WAVES / 4)
         // the item came through LDS: tell the compiler it is wave-uniform (loop control and addresses become scalar)
         const int b = __builtin_amdgcn_readfirstlane(item.b), ncb = __builtin_amdgcn_readfirstlane(item.ncb_tile);
         const int item_ch = __builtin_amdgcn_readfirstlane(item.ch), item_cbt0 = __builtin_amdgcn_readfirstlane(item.cbt0);
-        const int item_m_use = __builtin_amdgcn_readfirstlane(item.m_use);
+        const int item_m_use = __builtin_amdgcn_readfirstlane(item.m_use), item_nt = __builtin_amdgcn_readfirstlane(item.nt);
         const int n_b = P.nb_rows[b];
         const int nrb_b = (n_b + 31) >> 5, rb_last = nrb_b - 1;
         const int stride = SAMPLE ? sample_stride(n_b) : 1;
         const int rb0 = SAMPLE ? item_ch * stride * P2_TILE_RB : item_ch * P.chunk_rb;
-        const int nrb = SAMPLE ? min(P2_TILE_RB, nrb_b - rb0) : min(P.chunk_rb, nrb_b - rb0);
+        const int nrb = SAMPLE ? P2_TILE_RB : min(P.chunk_rb, nrb_b - rb0);
+        // pass 1: the item's units run through its item_nt sampled tiles (UPT units each, tiles 2 stride apart; units past the bucket's end are skipped)
+        constexpr int UPT = P2_TILE_RB / (PAIR ? 2 : 1);
+        const int tile_step = 2 * stride * P2_TILE_RB;
+        const int rb_end = SAMPLE ? rb_last : rb0 + nrb - 1;   // the last row-block a unit may touch
+        auto unit_rb = [&](int pp) __attribute__((always_inline)) {
+            return SAMPLE ? rb0 + (pp / UPT) * tile_step + (PAIR ? 2 : 1) * (pp % UPT) : rb0 + (PAIR ? 2 : 1) * pp;
+        };
+        int cur_rb0 = rb0, cur_list = item_ch % P2_NSL;       // pass 1: first row-block and list of the tile the current unit belongs to
         const int cb_tile = P.cb_start[b] + item_cbt0;
         const int m_left = item_m_use - item_cbt0 * 32;   // live columns of the tile from its first one
         const size_t col0 = (size_t)cb_tile * 32;
         const uint4* aslab = P.slab16 + (size_t)P.rb_start[b] * KG * 64 + lane;
-        const int npairs = PAIR ? (nrb + 1) >> 1 : nrb;   // units of the item
-        const int list_j = item_ch % P2_NSL;
+        const int npairs = SAMPLE ? item_nt * UPT : PAIR ? (nrb + 1) >> 1 : nrb;   // units of the item
         const bool use_atomic = SAMPLE && p2_sample_tiles(n_b) > P2_NSL;   // more sampled tiles than lists: every tile folds with the atomic
         half8 a0[KG], a1[KG1];
         auto load_pair = [&](int pp, half8 (&x0)[KG], half8 (&x1)[KG1]) __attribute__((always_inline)) {
-            const uint4* pa = aslab + (size_t)min(rb0 + (PAIR ? 2 : 1) * pp, rb_last) * (KG * 64);
-            const uint4* pb = aslab + (size_t)min(rb0 + 2 * pp + 1, rb_last) * (KG * 64);
+            const int rbu = unit_rb(pp);
+            const uint4* pa = aslab + (size_t)min(rbu, rb_last) * (KG * 64);
+            const uint4* pb = aslab + (size_t)min(rbu + 1, rb_last) * (KG * 64);
 #pragma unroll
             for (int g = 0; g < KG; ++g) {
                 x0[g] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(pa + g * 64));
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(64 * PS_WAVES, ps_blocks_per_cu(KG) * PS_WAVES / 4)
                 const float mx = flat_max(acc);
                 if (n * 32 + c < m_left) {
                     // lists are COLUMN-minor: [list][slot = 2 (row-block in the tile) + h][column]
-                    float* dst = P.bound + ((size_t)(list_j * 16 + (rb - rb0) * 2 + h)) * (size_t)P.ncols + (col0 + n * 32 + c);
+                    float* dst = P.bound + ((size_t)(cur_list * 16 + (rb - cur_rb0) * 2 + h)) * (size_t)P.ncols + (col0 + n * 32 + c);
                     if (!use_atomic) *dst = mx;
                     else {  // monotone float max through the order-preserving integer image
                         if (mx >= 0.0f) atomicMax(reinterpret_cast<int*>(dst), __float_as_int(mx));
@@ -306,8 +314,13 @@ __global__ __launch_bounds__(64 * PS_WAVES, ps_blocks_per_cu(KG) * PS_WAVES / 4)
             }
         };
         auto do_pair = [&](int p, const half8 (&x0)[KG], const half8 (&x1)[KG1]) __attribute__((always_inline)) {
-            const int rbA = rb0 + (PAIR ? 2 : 1) * p;
-            const bool second = PAIR && 2 * p + 1 < nrb;   // wave-uniform
+            const int rbA = unit_rb(p);
+            if (SAMPLE) {
+                if (rbA > rb_last) return;   // (wave-uniform: the bucket's last sampled tile is short)
+                cur_rb0 = rb0 + (p / UPT) * tile_step;
+                cur_list = (item_ch + 2 * (p / UPT)) % P2_NSL;
+            }
+            const bool second = PAIR && rbA + 1 <= rb_end;   // wave-uniform
 #ifdef LMI_P2_STAMPS
             if (!SAMPLE) { asm volatile("s_waitcnt vmcnt(12)" : "+v"(const_cast<half8&>(x0[0])) :: "memory"); st_acc[7] += 1; }
             PS_STAMP(1)
