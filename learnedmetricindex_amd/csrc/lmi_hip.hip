@@ -206,7 +206,7 @@ extern "C" LMI_API int lmi_create(int device, lmi_index** out) {
     lmi_index* h = new lmi_index();
     h->device = device;
     h->num_cus = prop.multiProcessorCount;
-    // route_group_kernel stages 20 bytes per bucket in dynamic LDS (fan-outs up to 8 000 buckets)
+    // route_group_kernel sorts the buckets in dynamic LDS (route_group_lds: fan-outs up to ROUTE_MAX_BUCKETS)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&route_group_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));  // its static LDS: 36 bytes
     int occ = 0;
@@ -529,7 +529,7 @@ extern "C" LMI_API int lmi_buckets_begin(lmi_index* h, int64_t N, int d, int L, 
     if (!h) return fail("lmi_buckets_begin: NULL handle");
     if (N < 0 || d < 1 || L < 1 || (N > 0 && !labels)) return fail("lmi_buckets_begin: bad arguments");
     if (N >= (1ll << 31) - 64ll * L) return fail("lmi_buckets_begin: N too large for 32-bit positions");
-    if (L > 8000) return fail("lmi_buckets_begin: %d buckets exceed the 8000 the routing kernels stage in LDS", L);
+    if (L > ROUTE_MAX_BUCKETS) return fail("lmi_buckets_begin: %d buckets exceed the %d the routing kernels stage in LDS", L, ROUTE_MAX_BUCKETS);
     CHK(set_dev(h));
     h->N = N;
     h->d_user = d;
@@ -1112,7 +1112,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     // the work queues (one 1 024-thread block, ~20 us) are only read by the scan kernels: built on the side stream while
     // this one packs the queries
     CHK(side_fork(h));
-    route_group_kernel<<<1, 1024, (size_t)L * 24, h->side>>>(L, R);
+    route_group_kernel<<<1, 1024, route_group_lds(L), h->side>>>(L, R);
     HIPCHK(hipGetLastError());
     route_fill_kernel<<<cdiv(nslots, 256), 256, 0, h->stream>>>(d_order, h->slot_local.as<int>(), nslots, nb,
                                                                R.cb_start, R.m0, h->colmap.as<int>(), h->slot_col.as<int>());

@@ -470,52 +470,80 @@ __global__ __launch_bounds__(256) void route_scan_kernel(int L, RouteArrays R) {
 // on the same few buckets: their query tiles (384 KiB each) then stay L2-resident and a chunk's
 // vectors are fetched once for all of its query tiles.  Heaviest buckets first (LPT) balances the
 // queues; blocks of a drained queue steal from the others, so placement only affects speed.
+// dynamic LDS of route_group_kernel: the sort keys (8 bytes per bucket, padded to a power of two) + two item counts per bucket
+__host__ __device__ inline int route_group_pow2(int L) { int p = 64; while (p < L) p <<= 1; return p; }
+__host__ __device__ inline size_t route_group_lds(int L) { return (size_t)route_group_pow2(L) * 8 + (size_t)L * 8; }
+constexpr int ROUTE_MAX_BUCKETS = 8000;   // (lmi_buckets_begin refuses more: 8 x 8 192 + 8 x 8 000 bytes of LDS)
 __global__ __launch_bounds__(1024) void route_group_kernel(int L, RouteArrays R) {
-    // dynamic LDS: m[L], items[L], order[L] ints + work[L] long long (the serial LPT below then
-    // never waits on global memory: 100 us -> a few us at L = 120)
+    // Everything in LDS: the ranking is a bitonic sort of one 64-bit key per bucket (work descending, id ascending), O(L log^2 L / 1024)
+    // per thread.  (Until round 4 every thread counted the buckets ahead of its own: O(L^2 / 1024) -- a few us at L = 120, 196 us
+    // at L = 2 000, on the critical path in front of pass 1.)
     extern __shared__ __attribute__((aligned(16))) char grp_smem[];
-    long long* work_s = reinterpret_cast<long long*>(grp_smem);
-    int* m_s = reinterpret_cast<int*>(work_s + L);
-    int* items_s = m_s + L;
-    int* order_s = items_s + L;
-    int* items1_s = order_s + L;
+    const int P = route_group_pow2(L);
+    unsigned long long* key_s = reinterpret_cast<unsigned long long*>(grp_smem);
+    int* order_s = reinterpret_cast<int*>(grp_smem);     // the sorted bucket ids, written over the keys once they are read
+    int* items_s = reinterpret_cast<int*>(key_s + P);
+    int* items1_s = items_s + L;
     const int t = threadIdx.x;
-    for (int b = t; b < L; b += 1024) {
-        const int m = R.m[b];
-        m_s[b] = m;
-        work_s[b] = (long long)m * R.nb_rows[b];
-        items_s[b] = query_tiles(m, R.tile_cb) * R.nch[b];
-        const int mp = R.sample_items ? R.m0[b] : 0;   // pass 1 runs over the primary columns only
-        items1_s[b] = (R.sample_items && m > 0) ? pass1_items(sample_tiles256(R.nb_rows[b]), query_tiles(m, R.tile_cb), query_tiles(mp, R.tile_cb)) : 0;
+    __shared__ int active_s, total_s[NGRP], total1_s[NGRP];
+    if (t == 0) active_s = 0;
+    __syncthreads();
+    {
+        int mine = 0;
+        for (int b = t; b < P; b += 1024) {
+            unsigned long long key = ~0ull;   // padding sorts last
+            if (b < L) {
+                const int m = R.m[b];
+                long long work = (long long)m * R.nb_rows[b];   // queries x rows: a fine proxy of the bucket's scan time
+                mine += work > 0;
+                items_s[b] = query_tiles(m, R.tile_cb) * R.nch[b];
+                const int mp = R.sample_items ? R.m0[b] : 0;   // pass 1 runs over the primary columns only
+                items1_s[b] = (R.sample_items && m > 0) ? pass1_items(sample_tiles256(R.nb_rows[b]), query_tiles(m, R.tile_cb), query_tiles(mp, R.tile_cb)) : 0;
+                if (work > (1ll << 43) - 1) work = (1ll << 43) - 1;   // (the heaviest of the heavy then rank by id: placement only affects speed)
+                key = ((unsigned long long)((1ll << 43) - 1 - work) << 20) | (unsigned long long)b;
+            }
+            key_s[b] = key;
+        }
+        if (mine) atomicAdd(&active_s, mine);
     }
     __syncthreads();
-    // rank of every bucket by (work desc, id asc); work = queries x rows is a fine proxy
-    for (int b = t; b < L; b += 1024) {
-        const long long wb = work_s[b];
-        int rank = 0;
-        for (int o = 0; o < L; ++o) {
-            const long long wo = work_s[o];
-            rank += (wo > wb) || (wo == wb && o < b);
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = t; i < P; i += 1024) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = key_s[i], c = key_s[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > c) == up) { key_s[i] = c; key_s[ixj] = a; }
+                }
+            }
+            __syncthreads();
         }
-        order_s[rank] = b;
     }
+    {
+        // rank -> bucket id, in place: every thread reads its keys before anyone writes an id over a key
+        constexpr int PER = (8192 + 1023) / 1024;
+        int ids[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int i = t + u * 1024;
+            ids[u] = i < P ? (int)(key_s[i] & 0xFFFFFull) : 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int i = t + u * 1024;
+            if (i < L) order_s[i] = ids[u];
+        }
+    }
+    if (t < NGRP) { total_s[t] = 0; total1_s[t] = 0; R.grp_base[t * (L + 1)] = 0; if (R.sample_items) R.grp_base1[t * (L + 1)] = 0; }
     __syncthreads();
     // Buckets -> queues in "snake" order over the work-sorted list (ranks 0..7 -> queues 0..7, ranks 8..15 ->
     // queues 7..0, ..): every thread places its own bucket, the prefix of a queue's item counts is a loop
     // over its <= L/8 earlier members.  (Exact LPT is serial: 54-73 us at L = 120 whichever way it was
     // written -- scratch arrays, a wave butterfly, select chains; the snake's queue loads differ by a few
     // per cent and draining queues steal anyway.)
-    __shared__ int active_s, total_s[NGRP], total1_s[NGRP];
-    if (t == 0) active_s = 0;
-    if (t < NGRP) { total_s[t] = 0; total1_s[t] = 0; R.grp_base[t * (L + 1)] = 0; if (R.sample_items) R.grp_base1[t * (L + 1)] = 0; }
-    __syncthreads();
-    {
-        int mine = 0;
-        for (int b = t; b < L; b += 1024) mine += m_s[b] > 0;
-        if (mine) atomicAdd(&active_s, mine);
-    }
-    __syncthreads();
-    const int A = active_s;  // buckets with queries: ranks 0 .. A-1 (idle buckets have zero work and sort last)
+    const int A = active_s;  // buckets with work: ranks 0 .. A-1 (the others have zero work and sort last)
     for (int i = t; i < A; i += 1024) {
         const int b = order_s[i];
         const int r = i / NGRP, ph = i % NGRP;

@@ -305,3 +305,32 @@ def test_wide_rows_take_the_streamed_rerank(capi, oracle, d):
         D, I = oracle.knn_ip(Q[q:q + 1], X[rows], 10)
         np.testing.assert_array_equal(i1[q:q + 1], (rows[I] + 1).astype(np.uint32))
         np.testing.assert_array_equal(d1[q:q + 1], np.float32(1) - D)
+
+
+@pytest.mark.parametrize("L", [1500, 7000])
+def test_many_buckets_route_and_scan(capi, oracle, L):
+    """Thousands of leaf buckets (the routing kernels sort the buckets by work in LDS: a bitonic sort padded to 2 048 / 8 192 keys;
+    round 3's form needed 24 bytes of LDS per bucket and could not be launched past ~6 800 buckets although 8 000 were accepted):
+    many empty buckets, many with fewer than ten rows, queries spread over all of them.  Prefilter == exact == oracle."""
+    rs = np.random.RandomState(L)
+    d, nq, nb = 24, 600, 3
+    N = 6 * L
+    labels = rs.randint(0, L, N).astype(np.int64)
+    labels[: N // 10] = rs.randint(0, 8, N // 10)          # a few heavy buckets
+    centres = rs.randn(L, d).astype(np.float32)
+    X = centres[labels] + 0.3 * rs.randn(N, d).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    qc = rs.randint(0, L, nq)
+    Q = centres[qc] + 0.3 * rs.randn(nq, d).astype(np.float32)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    order = np.stack([np.concatenate([[qc[i]], rs.choice(np.delete(np.arange(16), qc[i]) if qc[i] < 16 else np.arange(16), nb - 1, replace=False)])
+                      for i in range(nq)]).astype(np.int32)
+    (d1, i1, sv, fb), (d0, i0, _, _) = both_modes(capi, X, labels, L, Q, order)
+    np.testing.assert_array_equal(i1, i0)
+    np.testing.assert_array_equal(d1, d0)
+    for q in (0, 17, nq - 1):
+        rows = np.flatnonzero(np.isin(labels, order[q]))
+        if rows.size >= 10:
+            D, I = oracle.knn_ip(Q[q:q + 1], X[rows], 10)
+            np.testing.assert_array_equal(i1[q:q + 1], (rows[I] + 1).astype(np.uint32))
+            np.testing.assert_array_equal(d1[q:q + 1], np.float32(1) - D)
