@@ -485,7 +485,7 @@ __global__ __launch_bounds__(1024) void route_group_kernel(int L, RouteArrays R)
     int* items_s = reinterpret_cast<int*>(key_s + P);
     int* items1_s = items_s + L;
     const int t = threadIdx.x;
-    __shared__ int active_s, total_s[NGRP], total1_s[NGRP];
+    __shared__ int active_s;
     if (t == 0) active_s = 0;
     __syncthreads();
     {
@@ -536,39 +536,51 @@ __global__ __launch_bounds__(1024) void route_group_kernel(int L, RouteArrays R)
             if (i < L) order_s[i] = ids[u];
         }
     }
-    if (t < NGRP) { total_s[t] = 0; total1_s[t] = 0; R.grp_base[t * (L + 1)] = 0; if (R.sample_items) R.grp_base1[t * (L + 1)] = 0; }
+    if (t < NGRP) { R.grp_base[t * (L + 1)] = 0; if (R.sample_items) R.grp_base1[t * (L + 1)] = 0; }
     __syncthreads();
-    // Buckets -> queues in "snake" order over the work-sorted list (ranks 0..7 -> queues 0..7, ranks 8..15 ->
-    // queues 7..0, ..): every thread places its own bucket, the prefix of a queue's item counts is a loop
-    // over its <= L/8 earlier members.  (Exact LPT is serial: 54-73 us at L = 120 whichever way it was
-    // written -- scratch arrays, a wave butterfly, select chains; the snake's queue loads differ by a few
-    // per cent and draining queues steal anyway.)
+    // Buckets -> queues in "snake" order over the work-sorted list (ranks 0..7 -> queues 0..7, ranks 8..15 -> queues 7..0, ..).  (Exact
+    // LPT is serial: 54-73 us at L = 120 whichever way it was written; the snake's queue loads differ by a few per cent and draining
+    // queues steal anyway.)  Wave g scans queue g's item counts (its members are rank 8 r + (r odd ? 7 - g : g), r = 0, 1, ..), wave
+    // NGRP + g its pass-1 item counts: 64 members per step, a shuffle scan + a carry.
+    static_assert(2 * NGRP <= 1024 / 64, "one wave per queue and kind of item");
     const int A = active_s;  // buckets with work: ranks 0 .. A-1 (the others have zero work and sort last)
-    for (int i = t; i < A; i += 1024) {
-        const int b = order_s[i];
-        const int r = i / NGRP, ph = i % NGRP;
-        const int g = (r & 1) ? NGRP - 1 - ph : ph;
-        int prefix = 0, prefix1 = 0;
-        for (int rr = 0; rr < r; ++rr) {
-            const int ob = order_s[rr * NGRP + ((rr & 1) ? NGRP - 1 - g : g)];
-            prefix += items_s[ob];
-            prefix1 += items1_s[ob];
-        }
-        R.grp_bucket[g * L + r] = b;
-        R.grp_base[g * (L + 1) + r + 1] = prefix + items_s[b];
-        atomicAdd(&total_s[g], items_s[b]);
-        if (R.sample_items) {
-            R.grp_base1[g * (L + 1) + r + 1] = prefix1 + items1_s[b];
-            atomicAdd(&total1_s[g], items1_s[b]);
-        }
-    }
-    __syncthreads();
-    if (t < NGRP) {
+    const int wv = t >> 6, ln = t & 63;
+    if (wv < 2 * NGRP) {
+        const int g = wv % NGRP;
+        const bool second = wv >= NGRP;   // the pass-1 items
         const int rows = A / NGRP, rem = A % NGRP;
-        const int ph = (rows & 1) ? NGRP - 1 - t : t;  // this queue's position in the partial last row
-        R.grp_n[t] = rows + (ph < rem ? 1 : 0);
-        R.grp_total[t] = total_s[t];
-        if (R.sample_items) R.grp_total1[t] = total1_s[t];
+        const int ph_last = (rows & 1) ? NGRP - 1 - g : g;          // this queue's position in the partial last row
+        const int n_g = rows + (ph_last < rem ? 1 : 0);
+        if (!second || R.sample_items) {
+            const int* cnt = second ? items1_s : items_s;
+            int carry = 0;
+            for (int r0 = 0; r0 < n_g; r0 += 64) {
+                const int r = r0 + ln;
+                int b = -1, x = 0;
+                if (r < n_g) {
+                    b = order_s[r * NGRP + ((r & 1) ? NGRP - 1 - g : g)];
+                    x = cnt[b];
+                }
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int up = __shfl_up(x, o, 64);
+                    if (ln >= o) x += up;
+                }
+                if (r < n_g) {
+                    if (!second) {
+                        R.grp_bucket[g * L + r] = b;
+                        R.grp_base[g * (L + 1) + r + 1] = carry + x;
+                    } else {
+                        R.grp_base1[g * (L + 1) + r + 1] = carry + x;
+                    }
+                }
+                carry += __shfl(x, 63, 64);
+            }
+            if (ln == 0) {
+                if (!second) { R.grp_n[g] = n_g; R.grp_total[g] = carry; }
+                else R.grp_total1[g] = carry;
+            }
+        }
     }
 }
 
