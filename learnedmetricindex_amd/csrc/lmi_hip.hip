@@ -140,6 +140,7 @@ struct lmi_index {
     int dp = 0;   // row pitch (floats) of `rowmajor`
     DevBuf slab16, rowmajor, xscale, xmaxbits, bnorm, bdelta, qdelta;
     DevBuf qnorm, qscale, qfrag16, eps2, cand_cnt, cand_row, cand_s, fallback, pf_bound, nkeep, surv_row, rs_flag, rs_active;
+    DevBuf grp_scratch;      // route_group_kernel<true>: the bucket sort of fan-outs past ROUTE_MAX_BUCKETS
     DevBuf x_log, x_ext, x_off, fb_list;  // the candidates' overflow log, its by-column sorted form and offsets (lmi_prefilter.h, OverflowLog);
                                           // the fallback list: [count, fail0, fail1, log head, sorted total, pad x 3 | nslots slots]
     unsigned x_cap = 0;                   // entries of the log (0: not allocated yet)
@@ -207,8 +208,8 @@ extern "C" LMI_API int lmi_create(int device, lmi_index** out) {
     h->device = device;
     h->num_cus = prop.multiProcessorCount;
     // route_group_kernel sorts the buckets in dynamic LDS (route_group_lds: fan-outs up to ROUTE_MAX_BUCKETS)
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&route_group_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));  // its static LDS: 36 bytes
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&route_group_kernel<false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));  // its static LDS: 4 bytes
     int occ = 0;
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_kernel, 256, SCAN_LDS));
     h->scan_blocks_per_cu = std::max(1, std::min(occ, RB == 1 ? 2 : 1));
@@ -272,7 +273,7 @@ extern "C" LMI_API int lmi_destroy(lmi_index* h) {
                       &h->act[0], &h->act[1], &h->xfrag, &h->logits, &h->order, &h->q_nav, &h->q_srch, &h->m,
                       &h->cb_start, &h->item_base, &h->part_base, &h->stats, &h->head, &h->slot_local,
                       &h->slot_col, &h->colmap, &h->qfrag, &h->grp, &h->col_thr, &h->slab16, &h->rowmajor, &h->xscale, &h->xmaxbits, &h->bnorm, &h->bdelta, &h->qdelta, &h->qnorm, &h->qscale, &h->qfrag16, &h->eps2, &h->cand_cnt, &h->cand_row, &h->cand_s, &h->fallback, &h->pf_bound, &h->nkeep, &h->redo, &h->part_score, &h->part_row, &h->rank_d,
-                      &h->rank_id, &h->out_d, &h->out_id, &h->out_key, &h->x_log, &h->x_ext, &h->x_off, &h->fb_list};
+                      &h->rank_id, &h->out_d, &h->out_id, &h->out_key, &h->x_log, &h->x_ext, &h->x_off, &h->fb_list, &h->grp_scratch};
     for (DevBuf* b : bufs) b->release();
     for (auto& m : h->node_models) { for (auto& b : m.Wf) b.release(); for (auto& b : m.bias) b.release(); }
     DevBuf* nav[] = {&h->d_models, &h->d_child_offset, &h->d_child_model, &h->d_child_bucket, &h->pq_prob, &h->pq_ent, &h->pq_len, &h->surv_row, &h->rs_flag, &h->rs_active, &h->gather_send, &h->gather_recv, &h->aug_rows, &h->q_aug, &h->qn2,
@@ -312,7 +313,7 @@ extern "C" LMI_API int lmi_clone_view(lmi_index* h, lmi_index** out) {
                      &c->surv_row, &c->rs_flag, &c->rs_active, &c->act[0], &c->act[1], &c->xfrag, &c->logits, &c->order, &c->q_nav,
                      &c->q_srch, &c->m, &c->cb_start, &c->item_base, &c->part_base, &c->stats, &c->head, &c->slot_local, &c->slot_col,
                      &c->colmap, &c->qfrag, &c->grp, &c->col_thr, &c->part_score, &c->part_row, &c->rank_d, &c->rank_id, &c->out_d,
-                     &c->out_id, &c->out_key, &c->x_log, &c->x_ext, &c->x_off, &c->fb_list};
+                     &c->out_id, &c->out_key, &c->x_log, &c->x_ext, &c->x_off, &c->fb_list, &c->grp_scratch};
     for (DevBuf* b : own) b->forget();
     c->x_cap = 0;
     memset(c->ev_ring, 0, sizeof(c->ev_ring));
@@ -529,7 +530,7 @@ extern "C" LMI_API int lmi_buckets_begin(lmi_index* h, int64_t N, int d, int L, 
     if (!h) return fail("lmi_buckets_begin: NULL handle");
     if (N < 0 || d < 1 || L < 1 || (N > 0 && !labels)) return fail("lmi_buckets_begin: bad arguments");
     if (N >= (1ll << 31) - 64ll * L) return fail("lmi_buckets_begin: N too large for 32-bit positions");
-    if (L > ROUTE_MAX_BUCKETS) return fail("lmi_buckets_begin: %d buckets exceed the %d the routing kernels stage in LDS", L, ROUTE_MAX_BUCKETS);
+    if (L >= (1 << ROUTE_ID_BITS)) return fail("lmi_buckets_begin: %d buckets, the routing kernels take fewer than %d", L, 1 << ROUTE_ID_BITS);
     CHK(set_dev(h));
     h->N = N;
     h->d_user = d;
@@ -1112,7 +1113,12 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     // the work queues (one 1 024-thread block, ~20 us) are only read by the scan kernels: built on the side stream while
     // this one packs the queries
     CHK(side_fork(h));
-    route_group_kernel<<<1, 1024, route_group_lds(L), h->side>>>(L, R);
+    if (L <= ROUTE_MAX_BUCKETS) {
+        route_group_kernel<false><<<1, 1024, route_group_lds(L), h->side>>>(L, R, nullptr);
+    } else {   // huge fan-outs: the same sort in a global scratch buffer
+        CHK(h->grp_scratch.reserve(route_group_lds(L) + (size_t)L * 4));
+        route_group_kernel<true><<<1, 1024, 0, h->side>>>(L, R, h->grp_scratch.as<char>());
+    }
     HIPCHK(hipGetLastError());
     route_fill_kernel<<<cdiv(nslots, 256), 256, 0, h->stream>>>(d_order, h->slot_local.as<int>(), nslots, nb,
                                                                R.cb_start, R.m0, h->colmap.as<int>(), h->slot_col.as<int>());

@@ -473,17 +473,22 @@ __global__ __launch_bounds__(256) void route_scan_kernel(int L, RouteArrays R) {
 // dynamic LDS of route_group_kernel: the sort keys (8 bytes per bucket, padded to a power of two) + two item counts per bucket
 __host__ __device__ inline int route_group_pow2(int L) { int p = 64; while (p < L) p <<= 1; return p; }
 __host__ __device__ inline size_t route_group_lds(int L) { return (size_t)route_group_pow2(L) * 8 + (size_t)L * 8; }
-constexpr int ROUTE_MAX_BUCKETS = 8000;   // (lmi_buckets_begin refuses more: 8 x 8 192 + 8 x 8 000 bytes of LDS)
-__global__ __launch_bounds__(1024) void route_group_kernel(int L, RouteArrays R) {
+constexpr int ROUTE_MAX_BUCKETS = 8000;   // up to here the sort runs in LDS (8 x 8 192 + 8 x 8 000 bytes); beyond (GLOBAL: fan-outs like
+                                          // [100, 100]) in a global scratch buffer of route_group_lds(L) + 4 L bytes: slower, rare
+constexpr int ROUTE_ID_BITS = 20;         // bucket ids in the sort key: lmi_buckets_begin refuses 2^20 buckets or more
+template <bool GLOBAL>
+__global__ __launch_bounds__(1024) void route_group_kernel(int L, RouteArrays R, char* scratch) {
     // Everything in LDS: the ranking is a bitonic sort of one 64-bit key per bucket (work descending, id ascending), O(L log^2 L / 1024)
     // per thread.  (Until round 4 every thread counted the buckets ahead of its own: O(L^2 / 1024) -- a few us at L = 120, 196 us
     // at L = 2 000, on the critical path in front of pass 1.)
     extern __shared__ __attribute__((aligned(16))) char grp_smem[];
     const int P = route_group_pow2(L);
-    unsigned long long* key_s = reinterpret_cast<unsigned long long*>(grp_smem);
-    int* order_s = reinterpret_cast<int*>(grp_smem);     // the sorted bucket ids, written over the keys once they are read
+    char* base = GLOBAL ? scratch : grp_smem;
+    unsigned long long* key_s = reinterpret_cast<unsigned long long*>(base);
     int* items_s = reinterpret_cast<int*>(key_s + P);
     int* items1_s = items_s + L;
+    // the sorted bucket ids: written over the keys once they are read (LDS), or behind the item counts (GLOBAL)
+    int* order_s = GLOBAL ? items1_s + L : reinterpret_cast<int*>(base);
     const int t = threadIdx.x;
     __shared__ int active_s;
     if (t == 0) active_s = 0;
@@ -500,7 +505,7 @@ __global__ __launch_bounds__(1024) void route_group_kernel(int L, RouteArrays R)
                 const int mp = R.sample_items ? R.m0[b] : 0;   // pass 1 runs over the primary columns only
                 items1_s[b] = (R.sample_items && m > 0) ? pass1_items(sample_tiles256(R.nb_rows[b]), query_tiles(m, R.tile_cb), query_tiles(mp, R.tile_cb)) : 0;
                 if (work > (1ll << 43) - 1) work = (1ll << 43) - 1;   // (the heaviest of the heavy then rank by id: placement only affects speed)
-                key = ((unsigned long long)((1ll << 43) - 1 - work) << 20) | (unsigned long long)b;
+                key = ((unsigned long long)((1ll << 43) - 1 - work) << ROUTE_ID_BITS) | (unsigned long long)b;
             }
             key_s[b] = key;
         }
@@ -520,14 +525,16 @@ __global__ __launch_bounds__(1024) void route_group_kernel(int L, RouteArrays R)
             __syncthreads();
         }
     }
-    {
+    if constexpr (GLOBAL) {
+        for (int i = t; i < L; i += 1024) order_s[i] = (int)(key_s[i] & ((1ull << ROUTE_ID_BITS) - 1));
+    } else {
         // rank -> bucket id, in place: every thread reads its keys before anyone writes an id over a key
         constexpr int PER = (8192 + 1023) / 1024;
         int ids[PER];
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int i = t + u * 1024;
-            ids[u] = i < P ? (int)(key_s[i] & 0xFFFFFull) : 0;
+            ids[u] = i < P ? (int)(key_s[i] & ((1ull << ROUTE_ID_BITS) - 1)) : 0;
         }
         __syncthreads();
 #pragma unroll

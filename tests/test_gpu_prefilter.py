@@ -307,10 +307,11 @@ def test_wide_rows_take_the_streamed_rerank(capi, oracle, d):
         np.testing.assert_array_equal(d1[q:q + 1], np.float32(1) - D)
 
 
-@pytest.mark.parametrize("L", [1500, 7000])
+@pytest.mark.parametrize("L", [1500, 7000, 10000, 20011])
 def test_many_buckets_route_and_scan(capi, oracle, L):
     """Thousands of leaf buckets (the routing kernels sort the buckets by work in LDS: a bitonic sort padded to 2 048 / 8 192 keys;
-    round 3's form needed 24 bytes of LDS per bucket and could not be launched past ~6 800 buckets although 8 000 were accepted):
+    round 3's form needed 24 bytes of LDS per bucket and could not be launched past ~6 800 buckets although 8 000 were accepted;
+    past 8 000 -- fan-outs like [100, 100] -- the same sort runs in a global scratch buffer):
     many empty buckets, many with fewer than ten rows, queries spread over all of them.  Prefilter == exact == oracle."""
     rs = np.random.RandomState(L)
     d, nq, nb = 24, 600, 3
