@@ -275,13 +275,13 @@ def test_narrow_query_tiles_in_long_chunks(capi, oracle, d):
         np.testing.assert_array_equal(dd, np.float32(1) - D)
 
 
-@pytest.mark.parametrize("d", [1100, 1536, 3000, 9000])
-def test_wide_rows_take_the_streamed_rerank(capi, oracle, d):
+@pytest.mark.parametrize("d,nb", [(1100, 2), (1536, 1), (3000, 3), (9000, 2), (2048, 4)])
+def test_wide_rows_take_the_streamed_rerank(capi, oracle, d, nb):
     """Rows wider than four waves' re-rank buffers (d > 1 126: two waves per block up to ~8 700, one beyond; the small form one wave
     per block from ~2 000) keep select_kernel + rescore_kernel (round 4; before: select_rescore_kernel).  A cluster of 120 near-copies
     puts groups on the `big` list (more survivors than the small form holds).  Prefilter, exact mode and the oracle agree bit for bit."""
     rs = np.random.RandomState(d)
-    L, nq, nb = 5, 160, 2
+    L, nq = 5, 160
     sizes = [900, 33, 1500, 700, 1200]
     labels = np.concatenate([np.full(n, b) for b, n in enumerate(sizes)]).astype(np.int64)
     rs.shuffle(labels)
