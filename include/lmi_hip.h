@@ -122,6 +122,7 @@ LMI_API int lmi_set_metric(lmi_index *h, int metric);
  * begin: labels[N] = data_prediction[:,0] (bucket of every object, 0 <= label < L), ids[N] = the
  *        DataFrame index labels (NULL -> 1..N, search.py:190-191), owned[L] = which buckets this
  *        handle keeps (NULL -> all; used by the bucket-sharded multi-GPU mode).  Host pointers.
+ *        L < 2^20 (any fan-out the reference's n_categories can name in practice, e.g. [100, 100]).
  * add_rows: rows [nrows][d] are the original objects row0 .. row0+nrows-1 (any order of calls, each
  *        object exactly once); they are scattered to their bucket-contiguous position on device.
  * end:   finishes the build; the index is immutable afterwards. */

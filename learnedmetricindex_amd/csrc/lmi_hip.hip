@@ -141,6 +141,9 @@ struct lmi_index {
     DevBuf slab16, rowmajor, xscale, xmaxbits, bnorm, bdelta, qdelta;
     DevBuf qnorm, qscale, qfrag16, eps2, cand_cnt, cand_row, cand_s, fallback, pf_bound, nkeep, surv_row, rs_flag, rs_active;
     DevBuf grp_scratch;      // route_group_kernel<true>: the bucket sort of fan-outs past ROUTE_MAX_BUCKETS
+    bool ps_wide = false;    // this call's form of the low-dimensional kernels (lmi_pass2_small.h)
+    int ps_force_wide = -1;  // LMI_PS_WIDE=0/1 pins it (developer aid)
+    int n_nonempty = 1;      // buckets with rows, on any rank (lmi_buckets_begin)
     DevBuf x_log, x_ext, x_off, fb_list;  // the candidates' overflow log, its by-column sorted form and offsets (lmi_prefilter.h, OverflowLog);
                                           // the fallback list: [count, fail0, fail1, log head, sorted total, pad x 3 | nslots slots]
     unsigned x_cap = 0;                   // entries of the log (0: not allocated yet)
@@ -237,10 +240,15 @@ extern "C" LMI_API int lmi_create(int device, lmi_index** out) {
     if (const char* e = getenv("LMI_PF_SMALL")) h->pf_small = !(e[0] == '0');
     if (const char* e = getenv("LMI_PF_QBOUND")) h->pf_qbound = e[0] && e[0] != '0';
     if (const char* e = getenv("LMI_PF_PRIMARY")) h->pf_primary = e[0] && e[0] != '0';
+    if (const char* e = getenv("LMI_PS_WIDE")) h->ps_force_wide = e[0] == '1' ? 1 : e[0] == '0' ? 0 : -1;
     // per handle = per device (a process may hold handles on several devices; the attribute is per device)
 #define LMI_PS_ATTR(K) \
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pass2_small_kernel<K, false>), hipFuncAttributeMaxDynamicSharedMemorySize, ps_lds_bytes(K))); \
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pass2_small_kernel<K, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ps_lds_bytes(K)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pass2_small_kernel<K, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, ps_lds_bytes(K, false))); \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pass2_small_kernel<K, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, ps_lds_bytes(K, false))); \
+    if constexpr (ps_has_wide(K)) { \
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pass2_small_kernel<K, false, ps_has_wide(K)>), hipFuncAttributeMaxDynamicSharedMemorySize, ps_lds_bytes(K, true))); \
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pass2_small_kernel<K, true, ps_has_wide(K)>), hipFuncAttributeMaxDynamicSharedMemorySize, ps_lds_bytes(K, true))); \
+    }
     // every K: the dynamic part alone stays under 64 KiB up to K = 5, but the static arrays beside it (queue prefix, candidate
     // list, item) put the block's total above it from K = 5 on
     LMI_PS_ATTR(1) LMI_PS_ATTR(2) LMI_PS_ATTR(3) LMI_PS_ATTR(4) LMI_PS_ATTR(5) LMI_PS_ATTR(6) LMI_PS_ATTR(7) LMI_PS_ATTR(8)
@@ -541,10 +549,12 @@ extern "C" LMI_API int lmi_buckets_begin(lmi_index* h, int64_t N, int d, int L, 
     h->KGs = (int)rup(cdiv(d, 8), STAGE_G);
     h->built = false;
     h->h_nb_rows.assign(L, 0);
+    std::vector<unsigned char> seen(owned ? L : 0, 0);   // (a sharded rank: which buckets hold rows on ANY rank)
     for (int64_t i = 0; i < N; ++i) {
         int64_t b = labels[i];
         if (b < 0 || b >= L) return fail("lmi_buckets_begin: labels[%lld] = %lld outside [0,%d)", (long long)i, (long long)b, L);
         if (!owned || owned[b]) h->h_nb_rows[b]++;
+        if (owned) seen[b] = 1;
     }
     h->h_rb_start.assign(L + 1, 0);
     h->h_nch.assign(L, 0);
@@ -556,7 +566,10 @@ extern "C" LMI_API int lmi_buckets_begin(lmi_index* h, int64_t N, int d, int L, 
     {
         int max_rows = 0;
         long long owned_rows = 0;
-        for (int b = 0; b < L; ++b) { max_rows = std::max(max_rows, h->h_nb_rows[b]); owned_rows += h->h_nb_rows[b]; }
+        // buckets with rows on any rank: the queries of a batch spread over all of them, whoever owns them
+        int nonempty = 0;
+        for (int b = 0; b < L; ++b) { max_rows = std::max(max_rows, h->h_nb_rows[b]); owned_rows += h->h_nb_rows[b]; nonempty += owned ? seen[b] : h->h_nb_rows[b] > 0; }
+        h->n_nonempty = std::max(1, nonempty);
         if (h->chunk_rows_auto) {
             h->chunk_rows = (int)std::min<long long>(2048, std::max<long long>(P2_TILE_ROWS, rup(owned_rows / 4096, P2_TILE_ROWS)));
             // d <= 128 (lmi_pass2_small.h): a 2048-row item is ~5 us of work there, about what taking it from the queue and
@@ -980,8 +993,12 @@ static int rescore_group_size(int nb) { return nb % 4 == 0 ? 4 : nb % 3 == 0 ? 3
 template <bool SAMPLE>
 static int launch_pass2(lmi_index* h, const PrefilterParams& F) {
     if (h->pf_small && F.KG16 <= PS_MAXKG) {
-        const int grid = h->num_cus * ps_blocks_per_cu(F.KG16), lds = ps_lds_bytes(F.KG16) - (SAMPLE ? ps_spill_bytes(F.KG16) : 0);
-#define LMI_PS_CASE(K) case K: pass2_small_kernel<K, SAMPLE><<<grid, 64 * PS_WAVES, lds, h->stream>>>(F); break;
+        const bool wide = h->ps_wide;   // (chosen per call with the routing's tile size, scan_enqueue)
+        const int grid = h->num_cus * ps_blocks_per_cu(F.KG16, wide), lds = ps_lds_bytes(F.KG16, wide) - (SAMPLE ? ps_spill_bytes(F.KG16, wide) : 0);
+#define LMI_PS_CASE(K) case K: \
+            if (wide && ps_has_wide(K)) pass2_small_kernel<K, SAMPLE, ps_has_wide(K)><<<grid, 64 * ps_waves(K, true), lds, h->stream>>>(F); \
+            else pass2_small_kernel<K, SAMPLE, false><<<grid, 64 * ps_waves(K, false), lds, h->stream>>>(F); \
+            break;
         switch (F.KG16) {
             LMI_PS_CASE(1) LMI_PS_CASE(2) LMI_PS_CASE(3) LMI_PS_CASE(4) LMI_PS_CASE(5) LMI_PS_CASE(6) LMI_PS_CASE(7) LMI_PS_CASE(8)
             default: return fail("internal: KG16 = %d outside the low-dimensional form (%s:%d)", F.KG16, __FILE__, __LINE__);
@@ -1051,7 +1068,14 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     R.grp_base1 = R.grp_total + NGRP;
     R.grp_total1 = R.grp_base1 + (size_t)NGRP * (L + 1);
     const bool v2 = h->prefilter && h->have16;   // the prefilter's kernels: lmi_pass2.h (tiles of up to 12 col-blocks)
-    R.tile_cb = !v2 ? 4 : (h->pf_small && h->KG16 <= PS_MAXKG) ? ps_tile_cb(h->KG16) : P2_MAXCB;
+    // low-dimensional kernels: the wide form (one 8-wave block per CU, 12-col-block tiles) when the visited buckets receive more
+    // queries than the narrow form's tile holds -- decided from the call's shape alone (no device round trip)
+    h->ps_wide = false;
+    if (v2 && h->pf_small && h->KG16 <= PS_MAXKG) {
+        const double per_bucket = (double)nq * nb / std::max(1, std::min(h->n_nonempty, (int)std::min<long long>((long long)nq * nb, 1 << 30)));
+        h->ps_wide = h->ps_force_wide >= 0 ? h->ps_force_wide != 0 : ps_use_wide(h->KG16, per_bucket);
+    }
+    R.tile_cb = !v2 ? 4 : (h->pf_small && h->KG16 <= PS_MAXKG) ? ps_tile_cb(h->KG16, h->ps_wide) : P2_MAXCB;
     R.sample_items = v2 ? 1 : 0;
     // one bound per QUERY is enough when the caller keeps the k <= 10 best over all ranks (query_bound_kernel, lmi_pass2.h): pass 1
     // then samples only each query's primary slot(s) -- a quarter of the columns at n_buckets = 4

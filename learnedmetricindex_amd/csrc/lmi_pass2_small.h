@@ -34,27 +34,46 @@ constexpr int PS_MAXKG = 8;
 #ifndef LMI_PS_WAVES
 #define LMI_PS_WAVES 4
 #endif
-constexpr int PS_WAVES = LMI_PS_WAVES;   // waves per block (they share the query tile in LDS)
+constexpr int PS_WAVES = LMI_PS_WAVES;   // waves per block (they share the query tile in LDS) ...
+// ... and twice as many in the WIDE form (K > 64 only): ONE block of eight waves per CU, whose LDS then holds a 12-col-block query tile.  The
+// host takes it when the buckets receive more queries than the narrow form's tile holds (ps_use_wide): the rows are then streamed once
+// instead of twice (345 queries per bucket, 4M rows: pass 2 at d = 80 / 96 / 112 / 128 0.377 / 0.445 / 0.494 / 0.552 -> 0.345 / 0.415 /
+// 0.467 / 0.488 ms); with few queries per bucket (C5's 156) two independent 4-wave blocks are 1-7 % ahead and stay.
+#ifndef LMI_PS_WIDE_KG
+#define LMI_PS_WIDE_KG 5
+#endif
+__host__ __device__ constexpr bool ps_has_wide(int kg) { return kg >= LMI_PS_WIDE_KG; }
+__host__ __device__ constexpr int ps_waves(int kg, bool wide) { return wide && ps_has_wide(kg) ? 2 * PS_WAVES : PS_WAVES; }
 #ifndef LMI_PS_SPILL
 #define LMI_PS_SPILL 96
 #endif
 constexpr int PS_SPILL = LMI_PS_SPILL;        // entries of a wave's spill ring (pass 2): 64 scores + tag each
 
 // col-blocks per query tile: K > 64 takes smaller tiles, so that two blocks per CU hold the tile AND the spill ring
-__host__ __device__ constexpr int ps_tile_cb(int kg) { return kg <= 4 ? P2_MAXCB : kg <= 6 ? 8 : kg == 7 ? 7 : 6; }
-__host__ __device__ constexpr int ps_spill_bytes(int) { return PS_WAVES * PS_SPILL * (64 + 4); }
-__host__ __device__ constexpr int ps_lds_bytes(int kg) { return ps_tile_cb(kg) * kg * 1024 + ps_tile_cb(kg) * 32 * 4 + ps_spill_bytes(kg); }
+__host__ __device__ constexpr int ps_tile_cb(int kg, bool wide) { return kg <= 4 || (wide && ps_has_wide(kg)) ? P2_MAXCB : kg <= 6 ? 8 : kg == 7 ? 7 : 6; }
+__host__ __device__ constexpr int ps_spill_bytes(int kg, bool wide) { return ps_waves(kg, wide) * PS_SPILL * (64 + 4); }
+__host__ __device__ constexpr int ps_lds_bytes(int kg, bool wide) { return ps_tile_cb(kg, wide) * kg * 1024 + ps_tile_cb(kg, wide) * 32 * 4 + ps_spill_bytes(kg, wide); }
+// the wide form pays when the mean number of queries per visited bucket exceeds what the narrow form's tile holds
+__host__ inline bool ps_use_wide(int kg, double queries_per_bucket) { return ps_has_wide(kg) && queries_per_bucket > 0.8 * 32.0 * ps_tile_cb(kg, false); }
 constexpr int PS_PREFIX_CAP = 257;   // buckets + 1 of a queue group held in LDS (more: the global prefix is searched)
 #ifndef LMI_PS_BLOCKS4
 #define LMI_PS_BLOCKS4 2   // blocks per CU at KG <= 4 (LDS allows 3, but pass 2 then has 168 registers and spills 175: 0.47 -> 1.06 ms)
 #endif
-__host__ __device__ constexpr int ps_blocks_per_cu(int kg) { return kg <= 4 ? LMI_PS_BLOCKS4 : 2; }   // LDS: 160 KiB per CU
-static_assert(PS_SPILL >= 128 - 32 && 2 * (ps_lds_bytes(6) + 4096) <= 160 * 1024 && 2 * (ps_lds_bytes(4) + 4096) <= 160 * 1024 && 2 * (ps_lds_bytes(7) + 4096) <= 160 * 1024 && 2 * (ps_lds_bytes(8) + 4096) <= 160 * 1024, "LDS budget (dynamic + ~3 KiB static)");
+__host__ __device__ constexpr int ps_blocks_per_cu(int kg, bool wide) { return wide && ps_has_wide(kg) ? 1 : kg <= 4 ? LMI_PS_BLOCKS4 : 2; }   // LDS: 160 KiB per CU
+constexpr bool ps_lds_fits() {
+    for (int kg = 1; kg <= PS_MAXKG; ++kg)
+        for (int wide = 0; wide < 2; ++wide)
+            if (ps_blocks_per_cu(kg, wide) * (ps_lds_bytes(kg, wide) + 4096) > 160 * 1024) return false;
+    return true;
+}
+static_assert(PS_SPILL >= 128 - 32 && ps_lds_fits(), "LDS budget (dynamic + ~3 KiB static) for every k16-group count");
 
-template <int KG, bool SAMPLE>
-__global__ __launch_bounds__(64 * PS_WAVES, ps_blocks_per_cu(KG) * PS_WAVES / 4) void pass2_small_kernel(PrefilterParams P) {
+template <int KG, bool SAMPLE, bool WIDE = false>
+__global__ __launch_bounds__(64 * ps_waves(KG, WIDE), ps_blocks_per_cu(KG, WIDE) * ps_waves(KG, WIDE) / 4) void pass2_small_kernel(PrefilterParams P) {
+    static_assert(!WIDE || ps_has_wide(KG), "the wide form exists for K > 64 only");
+    constexpr int WV = ps_waves(KG, WIDE);   // waves of the block
     extern __shared__ __attribute__((aligned(16))) unsigned char ps_smem[];
-    constexpr int TCB = ps_tile_cb(KG);                                       // col-blocks per query tile
+    constexpr int TCB = ps_tile_cb(KG, WIDE);                                 // col-blocks per query tile
     uint4* sB = reinterpret_cast<uint4*>(ps_smem);                            // [col-blocks of the tile][KG][64 lanes]
     float* sThr = reinterpret_cast<float*>(ps_smem + TCB * KG * 1024);        // [TCB * 32] emission thresholds (pass 2)
     constexpr bool SPILL = !SAMPLE;   // pass 2's lane-granular spill ring (file header)
@@ -68,7 +87,7 @@ __global__ __launch_bounds__(64 * PS_WAVES, ps_blocks_per_cu(KG) * PS_WAVES / 4)
     constexpr bool B2 = KG <= 4 || SAMPLE || !PAIR;        // two query-fragment sets taking turns
     constexpr int KG1 = PAIR ? KG : 1;                     // (the second row-block's fragment arrays)
     float4* sSpill = reinterpret_cast<float4*>(ps_smem + TCB * KG * 1024 + TCB * 32 * 4);   // [waves][PS_SPILL][4] the 16 scores of an entry
-    unsigned* sTag = reinterpret_cast<unsigned*>(sSpill + PS_WAVES * PS_SPILL * 4);                    // [waves][PS_SPILL] column in the tile | row base << 9
+    unsigned* sTag = reinterpret_cast<unsigned*>(sSpill + WV * PS_SPILL * 4);                    // [waves][PS_SPILL] column in the tile | row base << 9
     __shared__ int s_item[2];
     __shared__ int s_prefix[PS_PREFIX_CAP];
     if (!SAMPLE && P.redo_count && *P.redo_count == 0u) return;  // the redo launch of a batch without overflowed columns
@@ -96,7 +115,7 @@ __global__ __launch_bounds__(64 * PS_WAVES, ps_blocks_per_cu(KG) * PS_WAVES / 4)
 #define PS_STAMP(PH)
 #endif
     // an item is a few microseconds of work: the queue takes the next ticket ahead (P2Queue, lmi_pass2.h)
-    P2Queue<SAMPLE, true, 64 * PS_WAVES, PS_PREFIX_CAP> queue{P, s_item, s_prefix};
+    P2Queue<SAMPLE, true, 64 * WV, PS_PREFIX_CAP> queue{P, s_item, s_prefix};
     queue.init();
     P2Item item;
     while (queue.next(item)) {
@@ -138,20 +157,20 @@ __global__ __launch_bounds__(64 * PS_WAVES, ps_blocks_per_cu(KG) * PS_WAVES / 4)
         {
             // the query tile -> LDS: every load of a thread in flight before its first LDS store (one memory round trip, not one per step)
             const uint4* bsrc = P.qfrag16 + (size_t)cb_tile * KG * 64;   // the tile's col-blocks are consecutive
-            constexpr int NV = (TCB * KG * 64 + 64 * PS_WAVES - 1) / (64 * PS_WAVES);
+            constexpr int NV = (TCB * KG * 64 + 64 * WV - 1) / (64 * WV);
             const int nfrag = ncb * KG * 64;
             if constexpr (NV <= 12) {
                 uint4 tmp[NV];
 #pragma unroll
-                for (int j = 0; j < NV; ++j) tmp[j] = bsrc[min(tid + j * 64 * PS_WAVES, nfrag - 1)];   // (clamped: the tail re-reads the last fragment)
+                for (int j = 0; j < NV; ++j) tmp[j] = bsrc[min(tid + j * 64 * WV, nfrag - 1)];   // (clamped: the tail re-reads the last fragment)
 #pragma unroll
                 for (int j = 0; j < NV; ++j)
-                    if (tid + j * 64 * PS_WAVES < nfrag) sB[tid + j * 64 * PS_WAVES] = tmp[j];
+                    if (tid + j * 64 * WV < nfrag) sB[tid + j * 64 * WV] = tmp[j];
             } else {
-                for (int i = tid; i < nfrag; i += 64 * PS_WAVES) sB[i] = bsrc[i];
+                for (int i = tid; i < nfrag; i += 64 * WV) sB[i] = bsrc[i];
             }
             if (!SAMPLE) {
-                for (int i = tid; i < ncb * 32; i += 64 * PS_WAVES) {
+                for (int i = tid; i < ncb * 32; i += 64 * WV) {
                     const bool wanted = i < m_left && (!P.redo_col || P.redo_col[col0 + i]);
                     sThr[i] = wanted ? P.bound1[col0 + i] - P.eps2[col0 + i] : INFINITY;
                 }
@@ -358,17 +377,17 @@ __global__ __launch_bounds__(64 * PS_WAVES, ps_blocks_per_cu(KG) * PS_WAVES / 4)
             int p = w;
 #ifdef LMI_ABL_NOLOAD   // timing-only ablation: the row-blocks are not streamed (wrong results)
             load_pair(min(p, last), a0, a1);
-            for (; p < npairs; p += PS_WAVES) do_pair(p, a0, a1);
+            for (; p < npairs; p += WV) do_pair(p, a0, a1);
 #else
             if (p < npairs) load_pair(p, a0, a1);
             while (p < npairs) {
-                load_pair(min(p + PS_WAVES, last), b0, b1);
+                load_pair(min(p + WV, last), b0, b1);
                 do_pair(p, a0, a1);
-                p += PS_WAVES;
+                p += WV;
                 if (p >= npairs) break;
-                load_pair(min(p + PS_WAVES, last), a0, a1);
+                load_pair(min(p + WV, last), a0, a1);
                 do_pair(p, b0, b1);
-                p += PS_WAVES;
+                p += WV;
             }
 #endif
         }
