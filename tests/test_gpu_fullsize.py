@@ -155,6 +155,20 @@ def test_k15_top8_per_bucket_bounds_at_scale(oracle):
     assert d.shape[1] == 15
 
 
+@pytest.mark.parametrize("tag,d,L,NB,n,nq", [
+    ("d96-wide", 96, 64, 4, 3_000_000, 10_000),       # 625 queries per bucket: the low-dimensional kernels' WIDE form (8-wave blocks, 12-col-block tiles)
+    ("d96-narrow", 96, 512, 4, 3_000_000, 10_000),    # 78 per bucket: two 4-wave blocks per CU, 8-col-block tiles, single row-blocks
+    ("d128", 128, 256, 8, 3_000_000, 8_000),          # 8 k16-groups, top-8
+    ("d1536", 1536, 64, 4, 1_000_000, 4_000),         # rows wider than four waves' re-rank buffers: two waves per block
+    ("leaves2000", 768, 2000, 4, 2_000_000, 10_000),  # small buckets (sampling stride < 16), the routing kernels' sort at 2 000 buckets
+])
+def test_other_shapes_at_scale(oracle, tag, d, L, NB, n, nq):
+    """The code paths round 4 added late, at sizes where they carry real work (MLP-routed end to end like C2's test): whole batch
+    prefilter == all-f32 (ids and distance bits) + 128 oracle-checked queries each."""
+    _need_hbm(40)
+    _mlp_routed_case(oracle, d=d, L=L, NB=NB, n=n, nq=nq, seed=900 + d + L, n_oracle=128, tag=tag)
+
+
 def test_c4_one_eighth_shard(oracle):
     from learnedmetricindex_amd import _capi
     from learnedmetricindex_amd.sharded import assign_buckets
