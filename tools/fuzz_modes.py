@@ -63,17 +63,21 @@ def one_case(capi, rs, case):
     Q /= np.maximum(np.linalg.norm(Q, axis=1, keepdims=True), 1e-20)
     chunk = rs.choice([None, 256, 512, 2048])
     wide = ("", "0", "1")[case % 3]
+    metric = "l2" if rs.rand() < 0.25 else "ip"           # L2: vectors of any norm, one stored column more
+    if metric == "l2":
+        X *= rs.uniform(0.2, 3.0, (N, 1)).astype(np.float32)
+        Q *= np.float32(rs.uniform(0.5, 2.0))
     res = []
     for pf in (True, False):
         if wide:
             os.environ["LMI_PS_WIDE"] = wide
         else:
             os.environ.pop("LMI_PS_WIDE", None)
-        idx = capi.Index(0, chunk_rows=None if chunk is None else int(chunk), prefilter=pf)
+        idx = capi.Index(0, chunk_rows=None if chunk is None else int(chunk), prefilter=pf, metric=metric)
         idx.set_buckets(X, labels, L)
         res.append(idx.scan_topk(Q, order, k))
         idx.close()
-    desc = dict(case=case, d=d, L=L, nb=nb, k=k, N=N, kind=int(kind), nq=nq, hot=bool(hot), chunk=chunk, wide=wide)
+    desc = dict(case=case, d=d, L=L, nb=nb, k=k, N=N, kind=int(kind), nq=nq, hot=bool(hot), chunk=chunk, wide=wide, metric=metric)
     (d1, i1), (d0, i0) = res
     if not (np.array_equal(i1, i0) and np.array_equal(d1.view(np.uint64) if d1.dtype == np.float64 else d1, d0.view(np.uint64) if d0.dtype == np.float64 else d0)):
         bad = np.flatnonzero((i1 != i0).any(axis=1) | (d1 != d0).any(axis=1))
