@@ -6,7 +6,9 @@
 Every case draws d (1..2100, weighted towards the kernels' boundaries), the number of buckets, their sizes (empty, tiny, ragged,
 one heavy), top-n, k and a batch routed at random (so that buckets receive 0 .. thousands of queries), builds two indexes and
 compares ids and distances of the whole batch.  The low-dimensional kernels' wide form is forced on / off / left automatic in turn
-(LMI_PS_WIDE, read when a handle is created).  Prints the failing case's parameters and exits 1 on the first mismatch."""
+(LMI_PS_WIDE, read when a handle is created).  Prints the failing case's parameters and exits 1 on the first mismatch.
+tests/test_gpu_fuzz.py runs the same cases with five queries of each also re-computed by the CPU oracle (LMI_FUZZ_CASES / LMI_FUZZ_SEED
+lengthen it)."""
 import argparse
 import os
 import sys
@@ -21,7 +23,7 @@ D_CHOICES = [1, 3, 8, 15, 16, 17, 31, 32, 33, 45, 48, 63, 64, 65, 77, 80, 81, 95
              161, 191, 192, 200, 255, 256, 257, 300, 384, 500, 512, 640, 767, 768, 769, 1000, 1024, 1025, 1100, 1127, 1300, 1536, 2048, 2100]
 
 
-def one_case(capi, rs, case):
+def one_case(capi, rs, case, oracle=None):
     d = int(rs.choice(D_CHOICES)) if rs.rand() < 0.8 else int(rs.randint(1, 700))
     L = int(rs.choice([1, 2, 3, 7, 16, 40, 120, 300, 1000, 2500]))
     nb = int(min(L, rs.choice([1, 2, 3, 4, 5, 8])))
@@ -79,6 +81,12 @@ def one_case(capi, rs, case):
         idx.close()
     desc = dict(case=case, d=d, L=L, nb=nb, k=k, N=N, kind=int(kind), nq=nq, hot=bool(hot), chunk=chunk, wide=wide, metric=metric)
     (d1, i1), (d0, i0) = res
+    if oracle is not None:   # a few queries against the CPU oracle as well (the routing kernels serve both GPU modes)
+        sub = np.sort(rs.choice(nq, min(nq, 5), replace=False))
+        do, io, _ = oracle.search(None, Q[sub], X, Q[sub], labels, nb, k, bucket_order=order[sub][:, :, None], metric=metric)
+        if not (np.array_equal(i1[sub].view(np.uint32), io) and np.array_equal(d1[sub].astype(np.float64), do)):
+            print("ORACLE MISMATCH", desc, "queries", sub, flush=True)
+            return False, desc
     if not (np.array_equal(i1, i0) and np.array_equal(d1.view(np.uint64) if d1.dtype == np.float64 else d1, d0.view(np.uint64) if d0.dtype == np.float64 else d0)):
         bad = np.flatnonzero((i1 != i0).any(axis=1) | (d1 != d0).any(axis=1))
         print("MISMATCH", desc, "queries", bad[:10], flush=True)
@@ -95,7 +103,7 @@ def main():
     t0 = time.time()
     for case in range(a.cases):
         rs = np.random.RandomState(a.seed * 100003 + case)
-        ok, desc = one_case(_capi, rs, case)
+        ok, desc = one_case(_capi, rs, case)   # (GPU modes only; tests/test_gpu_fuzz.py passes the CPU oracle in as well)
         if not ok:
             sys.exit(1)
         if case % 20 == 0:
