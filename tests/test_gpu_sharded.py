@@ -176,3 +176,51 @@ def test_bench_self_launch_two_ranks_gloo():
     assert j["sharded_alt_mode"]["value"] > 0 and len(j["per_rank"]) == 2
     assert {p["rank"] for p in j["per_rank"]} == {0, 1}
     assert j["recall_at_10"] is not None and j["recall_at_10"] > 0.9
+
+
+def test_random_shardings_equal_single():
+    """A fuzz of the bucket-sharded identity: random shapes (d 8..800, 3..300 buckets with empty / tiny / heavy ones, top-1..6,
+    k 1..20), random world sizes 2..9 and the deterministic bucket assignment; every rank scans the whole batch on the buckets it owns
+    (host-pointer C ABI with keys), the blocks are stacked as the all-gather delivers them and lmi_merge_gathered must reproduce the
+    single-handle answer bit for bit.  40 cases."""
+    from learnedmetricindex_amd import _capi
+    from learnedmetricindex_amd.sharded import assign_buckets
+
+    for case in range(40):
+        rs = np.random.RandomState(5000 + case)
+        d = int(rs.choice([8, 45, 64, 96, 130, 256, 768, 800]))
+        L = int(rs.choice([3, 12, 60, 300]))
+        nb = int(min(L, rs.choice([1, 2, 3, 4, 6])))
+        k = int(min(10 * nb, rs.choice([1, 5, 10, 10, 15, 20]))) if nb > 1 else 10
+        N = int(rs.choice([500, 5000, 30000]))
+        w = 1.0 / (1.0 + np.arange(L) / 4.0)
+        labels = rs.choice(L, N, p=w / w.sum()).astype(np.int64)
+        labels[labels == 1] = 0                                   # an empty bucket
+        X = rs.randn(L, d).astype(np.float32)[labels] * 0.7 + rs.randn(N, d).astype(np.float32)
+        X /= np.linalg.norm(X, axis=1, keepdims=True)
+        nq = int(rs.choice([1, 33, 700]))
+        order = np.stack([rs.permutation(L)[:nb] for _ in range(nq)]).astype(np.int32)
+        Q = rs.randn(nq, d).astype(np.float32)
+        Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+        world = int(rs.randint(2, 10))
+        sizes = np.bincount(labels, minlength=L)
+        owner = assign_buckets(sizes, world, weights=sizes.astype(np.float64) * (1 + rs.rand(L)))
+        single = _capi.Index(0, chunk_rows=256)
+        single.set_buckets(X, labels, L)
+        sd, si = single.scan_topk(Q, order, k)
+        kout = si.shape[1]
+        gd = np.empty((world, nq, kout), np.float32)
+        gi = np.empty((world, nq, kout), np.uint32)
+        gk = np.empty((world, nq, kout), np.uint32)
+        for r in range(world):
+            h = _capi.Index(0, chunk_rows=256)
+            h.set_buckets(X, labels, L, owned=(owner == r).astype(np.uint8))
+            gd[r], gi[r], gk[r] = h.scan_topk(Q, order, k, want_keys=True)
+            h.close()
+        md = np.empty((nq, kout), np.float32)
+        mi = np.empty((nq, kout), np.uint32)
+        single.merge_gathered(gd, gi, gk, world, nq, kout, md, mi)
+        desc = dict(case=case, d=d, L=L, nb=nb, k=k, N=N, nq=nq, world=world)
+        np.testing.assert_array_equal(mi, si, err_msg=str(desc))
+        np.testing.assert_array_equal(md, sd, err_msg=str(desc))
+        single.close()
