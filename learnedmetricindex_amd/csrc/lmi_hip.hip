@@ -1076,6 +1076,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         h->ps_wide = h->ps_force_wide >= 0 ? h->ps_force_wide != 0 : ps_use_wide(h->KG16, per_bucket);
     }
     R.tile_cb = !v2 ? 4 : (h->pf_small && h->KG16 <= PS_MAXKG) ? ps_tile_cb(h->KG16, h->ps_wide) : P2_MAXCB;
+    R.sample_max = (v2 && h->pf_small && h->KG16 <= PF_SAMPLE_LOWD_KG) ? PF_SAMPLE_LOWD : PF_SAMPLE;
     R.sample_items = v2 ? 1 : 0;
     // one bound per QUERY is enough when the caller keeps the k <= 10 best over all ranks (query_bound_kernel, lmi_pass2.h): pass 1
     // then samples only each query's primary slot(s) -- a quarter of the columns at n_buckets = 4
@@ -1201,6 +1202,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         F.L = L;
         F.chunk_rb = S.chunk_rb;
         F.tile_cb = R.tile_cb;
+        F.sample_max = R.sample_max;
         F.rb_start = S.rb_start;
         F.nb_rows = R.nb_rows;
         F.nch = R.nch;

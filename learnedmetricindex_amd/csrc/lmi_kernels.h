@@ -314,6 +314,7 @@ struct RouteArrays {
     int tile_cb;          // col-blocks per query tile: 4 (exact scan), 12 (prefilter: lmi_pass2.h), 8 (the round-2 prefilter kernel)
     int primary_nb;       // > 0 (= n_buckets): a slot is primary iff no lower rank of its query holds a bucket of >= 64 rows here
     int sample_items;     // 1: also build the pass-1 queues of lmi_pass2.h (grp_base1 / grp_total1: query tiles x SAMPLED tiles)
+    int sample_max;       // pass 1's largest sampling stride (PF_SAMPLE; PF_SAMPLE_LOWD at K <= 64)
 };
 
 // ---- prefilter pass 1: which tiles of a bucket are sampled (shared by the routing kernels and lmi_prefilter.h / lmi_pass2.h) ----
@@ -327,9 +328,16 @@ struct RouteArrays {
 #define LMI_PF_SAMPLE 16
 #endif
 constexpr int PF_SAMPLE = LMI_PF_SAMPLE;  // pass 1 looks at every PF_SAMPLE-th tile of a large bucket ...
+// ... every PF_SAMPLE_LOWD-th at K <= 64 (RouteArrays / PrefilterParams::sample_max carry the call's value: there a candidate costs as much
+// as the rows that would rule it out -- C5: stride 16 / 8 / 4: pass 1 0.100 / 0.120 / 0.167, pass 2 0.315 / 0.267 / 0.250 ms, 15.0 / 15.75 /
+// 15.1 M q/s; at d = 768 stride 8 loses 3 %, 32 loses 6 %) ...
+#ifndef LMI_PF_SAMPLE_LOWD
+#define LMI_PF_SAMPLE_LOWD 8
+#endif
+constexpr int PF_SAMPLE_LOWD = LMI_PF_SAMPLE_LOWD, PF_SAMPLE_LOWD_KG = 4;
 // ... and at every 8th, 4th, 2nd or every tile of buckets below LMI_PF_SAMPLE_ROWS x the stride
-__device__ __forceinline__ int sample_stride(int n_b) {
-    int s = PF_SAMPLE;
+__device__ __forceinline__ int sample_stride(int n_b, int smax) {
+    int s = smax;
     while (s > 1 && n_b < LMI_PF_SAMPLE_ROWS * s) s >>= 1;
     return s;
 }
@@ -368,9 +376,9 @@ __device__ __forceinline__ bool pass1_decode(int local, int nst, int nqt_all, in
     *nt = min(P1_TPI, n_pri - g * P1_TPI);
     return false;
 }
-__device__ __forceinline__ int sample_tiles256(int n_b) {  // sampled 256-row tiles of a bucket
+__device__ __forceinline__ int sample_tiles256(int n_b, int smax) {  // sampled 256-row tiles of a bucket
     const int nt = (((n_b + 31) >> 5) + 7) / 8;
-    const int s = sample_stride(n_b);
+    const int s = sample_stride(n_b, smax);
     return (nt + s - 1) / s;
 }
 
@@ -503,7 +511,7 @@ __global__ __launch_bounds__(1024) void route_group_kernel(int L, RouteArrays R,
                 mine += work > 0;
                 items_s[b] = query_tiles(m, R.tile_cb) * R.nch[b];
                 const int mp = R.sample_items ? R.m0[b] : 0;   // pass 1 runs over the primary columns only
-                items1_s[b] = (R.sample_items && m > 0) ? pass1_items(sample_tiles256(R.nb_rows[b]), query_tiles(m, R.tile_cb), query_tiles(mp, R.tile_cb)) : 0;
+                items1_s[b] = (R.sample_items && m > 0) ? pass1_items(sample_tiles256(R.nb_rows[b], R.sample_max), query_tiles(m, R.tile_cb), query_tiles(mp, R.tile_cb)) : 0;
                 if (work > (1ll << 43) - 1) work = (1ll << 43) - 1;   // (the heaviest of the heavy then rank by id: placement only affects speed)
                 key = ((unsigned long long)((1ll << 43) - 1 - work) << ROUTE_ID_BITS) | (unsigned long long)b;
             }

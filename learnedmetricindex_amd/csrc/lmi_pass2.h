@@ -72,7 +72,7 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-__device__ __forceinline__ int p2_sample_tiles(int n_b) { return sample_tiles256(n_b); }
+__device__ __forceinline__ int p2_sample_tiles(int n_b, int smax) { return sample_tiles256(n_b, smax); }
 static_assert(P2_TILE_RB == 8, "sample_tiles256 counts 256-row tiles");
 
 // In-kernel phase timing (developer builds, -DLMI_P2_STAMPS; tools/p2_stamps.py): shader-clock cycles per wave and phase,
@@ -534,7 +534,7 @@ struct Tile2 {
         const int KG = P.KG16, NS = KG / G;
         const int n_b = P.nb_rows[b];
         const int nrb_b = (n_b + 31) >> 5;
-        const int stride = SAMPLE ? sample_stride(n_b) : 1;
+        const int stride = SAMPLE ? sample_stride(n_b, P.sample_max) : 1;
         const int rb0 = SAMPLE ? ch * stride * P2_TILE_RB : ch * P.chunk_rb;
         const int nrb_all = SAMPLE ? P2_TILE_RB : min(P.chunk_rb, nrb_b - rb0);
         // block tiles of P2_WAVES row-blocks.  pass 1: the item's nt sampled tiles, each VPT block tiles, 2 stride tiles apart (row-blocks
@@ -631,7 +631,7 @@ struct Tile2 {
             // (a bucket with more sampled tiles than lists: EVERY tile that shares a list folds with the monotone atomic -- a plain
             // store from tile j could land behind tile j + 16's atomic and discard it: still a valid bound, but a different one from
             // run to run)
-            if (SAMPLE) epilogue_sample(vt_rb(vt), n_b, col0, m_left, (ch + 2 * (vt / VPT)) % P2_NSL_BIG, p2_sample_tiles(n_b) > P2_NSL_BIG, (vt % VPT) * P2_WAVES);
+            if (SAMPLE) epilogue_sample(vt_rb(vt), n_b, col0, m_left, (ch + 2 * (vt / VPT)) % P2_NSL_BIG, p2_sample_tiles(n_b, P.sample_max) > P2_NSL_BIG, (vt % VPT) * P2_WAVES);
             else epilogue_emit(rb0 + vt * P2_WAVES, n_b, col0);
             P2_STAMP(3)
         }
@@ -733,7 +733,7 @@ __device__ __forceinline__ void p2_decode_item(const PrefilterParams& P, int b, 
     bool all_cols = true;
     if (SAMPLE) {
         const int nqa = query_tiles(P.m[b], P.tile_cb), nqp = query_tiles(P.m0[b], P.tile_cb);
-        all_cols = pass1_decode(local, p2_sample_tiles(P.nb_rows[b]), nqa, nqp, &ch, &nt, &qt);
+        all_cols = pass1_decode(local, p2_sample_tiles(P.nb_rows[b], P.sample_max), nqa, nqp, &ch, &nt, &qt);
     }
     it.nt = nt;
     it.m_use = all_cols ? P.m[b] : P.m0[b];

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(64 * ps_waves(KG, WIDE), ps_blocks_per_cu(KG, WIDE)
         const int item_m_use = __builtin_amdgcn_readfirstlane(item.m_use), item_nt = __builtin_amdgcn_readfirstlane(item.nt);
         const int n_b = P.nb_rows[b];
         const int nrb_b = (n_b + 31) >> 5, rb_last = nrb_b - 1;
-        const int stride = SAMPLE ? sample_stride(n_b) : 1;
+        const int stride = SAMPLE ? sample_stride(n_b, P.sample_max) : 1;
         const int rb0 = SAMPLE ? item_ch * stride * P2_TILE_RB : item_ch * P.chunk_rb;
         const int nrb = SAMPLE ? P2_TILE_RB : min(P.chunk_rb, nrb_b - rb0);
         // pass 1: the item's units run through its item_nt sampled tiles (UPT units each, tiles 2 stride apart; units past the bucket's end are skipped)
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64 * ps_waves(KG, WIDE), ps_blocks_per_cu(KG, WIDE)
         const size_t col0 = (size_t)cb_tile * 32;
         const uint4* aslab = P.slab16 + (size_t)P.rb_start[b] * KG * 64 + lane;
         const int npairs = SAMPLE ? item_nt * UPT : PAIR ? (nrb + 1) >> 1 : nrb;   // units of the item
-        const bool use_atomic = SAMPLE && p2_sample_tiles(n_b) > P2_NSL;   // more sampled tiles than lists: every tile folds with the atomic
+        const bool use_atomic = SAMPLE && p2_sample_tiles(n_b, P.sample_max) > P2_NSL;   // more sampled tiles than lists: every tile folds with the atomic
         half8 a0[KG], a1[KG1];
         auto load_pair = [&](int pp, half8 (&x0)[KG], half8 (&x1)[KG1]) __attribute__((always_inline)) {
             const int rbu = unit_rb(pp);
