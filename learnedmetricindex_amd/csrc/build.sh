@@ -13,3 +13,9 @@ SRC_SHA16="$(python3 "${here}/../_srchash.py")"
   -o "${out}" "${here}/lmi_hip.hip" \
   -Wl,-rpath,/opt/rocm/lib -Wl,-Bsymbolic
 echo "built ${out}"
+# pass2_kernel names v[232:255] in inline asm and keeps hipcc out of them with an undocumented attribute: check the binary
+# (LMI_SKIP_ISA_GUARD=1: variant builds that change the kernel's register plan on purpose)
+if [ -z "${LMI_SKIP_ISA_GUARD:-}" ]; then
+  python3 "${here}/../../tools/isa_guard.py" "${out}" > /dev/null || { python3 "${here}/../../tools/isa_guard.py" "${out}"; echo "isa_guard FAILED for ${out}" >&2; exit 1; }
+  echo "isa_guard ok"
+fi
