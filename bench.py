@@ -689,7 +689,7 @@ def main():
     ap.add_argument("--hard-centre-scale", type=float, default=0.26)
     ap.add_argument("--hard-zipf", type=float, default=20.0)
     ap.add_argument("--chunk-rows", type=int, default=None)
-    ap.add_argument("--timing-level", type=int, default=2, choices=(0, 1, 2),
+    ap.add_argument("--timing-level", type=int, default=2, choices=(0, 1, 2, 3),
                     help="lmi_set_timing: 2 (default) times every phase with hipEvents -- the roofline needs the dominant "
                          "kernel's duration; 0/1 show the step without the events' bubbles (roofline fields then null/0)")
     ap.add_argument("--exact", action="store_true",

@@ -53,7 +53,8 @@ extern "C" {
 
 typedef struct lmi_index lmi_index;
 
-/* Timing slots filled by lmi_timings (milliseconds, hipEvent-measured on the handle's stream). */
+/* Timing slots filled by lmi_timings (milliseconds; measured on the handle's stream by device-side clock stamps the kernels
+ * write themselves -- lmi_set_timing 2, the default -- or by hipEvents between them -- levels 1 and 3). */
 enum {
     LMI_T_INFERENCE = 0, /* MLP forward + class ranking   -> measured_time["inference"]            */
     LMI_T_ROUTE = 1,     /* routing (CSR of queries per bucket) + query packing                     */
@@ -206,8 +207,10 @@ LMI_API int lmi_timings(lmi_index *h, float *ms /* [LMI_T_COUNT] */);
 /* Mean of the timing slots over the calls made since lmi_timings_reset (the newest 128 at most), read
  * with ONE stream synchronisation, so a timed loop needs no per-call sync; *n_calls = calls averaged. */
 LMI_API int lmi_timings_reset(lmi_index *h);
-/* How much is timed: 2 (default) every phase, 1 only LMI_T_TOTAL (and LMI_T_INFERENCE), 0 nothing -- every
- * event recorded between two kernels is a bubble of a few microseconds (7 of them: 9 % of a 1 000-query search). */
+/* How much is timed, and how.  2 (default): every phase, from stamps of the chip's constant 100 MHz clock that the first / last
+ * workgroups of the search's kernels write into a per-handle ring -- no event, no bubble, nothing to wait for.  3: every phase
+ * from hipEvents recorded between the kernels (each one is a ~5 us bubble on the stream: 8 of them are 6 % of a 10M x 45 search);
+ * 1: hipEvents for LMI_T_TOTAL (and LMI_T_INFERENCE) only; 0: nothing. */
 LMI_API int lmi_set_timing(lmi_index *h, int level);
 LMI_API int lmi_timings_mean(lmi_index *h, float *ms /* [LMI_T_COUNT] */, int *n_calls /* nullable */);
 /* Work done by the last scan: flops = 2 * d * sum over (query, rank) of the bucket size;

@@ -420,7 +420,8 @@ class Index:
         return ms
 
     def set_timing(self, level: int) -> None:
-        """2: every phase (default), 1: total only, 0: no events (each one is a few-microsecond bubble)."""
+        """2 (default): every phase from device-side clock stamps (no bubbles); 3: every phase from hipEvents (each a ~5 us bubble);
+        1: hipEvents around the whole call only; 0: nothing."""
         _check(lib().lmi_set_timing(self._h, int(level)))
 
     def timings_reset(self) -> None:

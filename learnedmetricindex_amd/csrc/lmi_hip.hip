@@ -7,6 +7,7 @@
 #include "lmi_pass2_small.h"
 #include "lmi_mlp_fused.h"
 #include "lmi_rescore.h"
+#include "lmi_front.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -175,6 +176,15 @@ struct lmi_index {
     bool* ev_valid = valid_ring[0];
     long long h_stats[4] = {0, 0, 0, 0};
     bool stats_pending = false;
+    // device-side phase stamps (timing level 2; lmi_kernels.h): a ring of EV_RING sets of ST_COUNT words, the set of the current
+    // call, which of its stamps a kernel of the call was given (host-side mask), the chip's constant clock in kHz
+    DevBuf ts_ring;
+    unsigned ts_mask[EV_RING] = {};
+    unsigned long long* ts_set = nullptr;
+    double wall_khz = 100000.0;
+    DevBuf fr_dbg;                // LMI_FR_DEBUG=1: front_kernel's phase stamps (lmi_debug_peek "fr_dbg")
+    int fr_parts = 0;             // LMI_FR_PARTS=n pins front_kernel's parts per bucket (developer aid)
+    bool use_front = false;       // front_kernel (lmi_front.h) instead of the eight preparation launches (LMI_FRONT=0 in the environment: off)
 };
 
 // which fp16 fragment shape the index and the queries are packed in: 16 x 32 for pass2_kernel, 32 x 16 for the low-dimensional kernels
@@ -241,6 +251,16 @@ extern "C" LMI_API int lmi_create(int device, lmi_index** out) {
     if (const char* e = getenv("LMI_PF_QBOUND")) h->pf_qbound = e[0] && e[0] != '0';
     if (const char* e = getenv("LMI_PF_PRIMARY")) h->pf_primary = e[0] && e[0] != '0';
     if (const char* e = getenv("LMI_PS_WIDE")) h->ps_force_wide = e[0] == '1' ? 1 : e[0] == '0' ? 0 : -1;
+    if (const char* e = getenv("LMI_FRONT")) h->use_front = !(e[0] == '0');
+    if (const char* e = getenv("LMI_FR_PARTS")) h->fr_parts = atoi(e);
+    if (const char* e = getenv("LMI_FR_DEBUG")) { if (e[0] == '1') { CHK(h->fr_dbg.reserve(256)); HIPCHK(hipMemset(h->fr_dbg.p, 0, 256)); } }
+    {
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) h->wall_khz = (double)khz;
+    }
+#define LMI_FR_ATTR(NBV) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&front_kernel<NBV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fr_lds_bytes(FR_MAX_L, 4 * FR_SLICE_G)));
+    LMI_FR_ATTR(0) LMI_FR_ATTR(1) LMI_FR_ATTR(2) LMI_FR_ATTR(3) LMI_FR_ATTR(4) LMI_FR_ATTR(5) LMI_FR_ATTR(6) LMI_FR_ATTR(8) LMI_FR_ATTR(10) LMI_FR_ATTR(16)
+#undef LMI_FR_ATTR
     // per handle = per device (a process may hold handles on several devices; the attribute is per device)
 #define LMI_PS_ATTR(K) \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pass2_small_kernel<K, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, ps_lds_bytes(K, false))); \
@@ -281,7 +301,7 @@ extern "C" LMI_API int lmi_destroy(lmi_index* h) {
                       &h->act[0], &h->act[1], &h->xfrag, &h->logits, &h->order, &h->q_nav, &h->q_srch, &h->m,
                       &h->cb_start, &h->item_base, &h->part_base, &h->stats, &h->head, &h->slot_local,
                       &h->slot_col, &h->colmap, &h->qfrag, &h->grp, &h->col_thr, &h->slab16, &h->rowmajor, &h->xscale, &h->xmaxbits, &h->bnorm, &h->bdelta, &h->qdelta, &h->qnorm, &h->qscale, &h->qfrag16, &h->eps2, &h->cand_cnt, &h->cand_row, &h->cand_s, &h->fallback, &h->pf_bound, &h->nkeep, &h->redo, &h->part_score, &h->part_row, &h->rank_d,
-                      &h->rank_id, &h->out_d, &h->out_id, &h->out_key, &h->x_log, &h->x_ext, &h->x_off, &h->fb_list, &h->grp_scratch};
+                      &h->rank_id, &h->out_d, &h->out_id, &h->out_key, &h->x_log, &h->x_ext, &h->x_off, &h->fb_list, &h->grp_scratch, &h->ts_ring, &h->fr_dbg};
     for (DevBuf* b : bufs) b->release();
     for (auto& m : h->node_models) { for (auto& b : m.Wf) b.release(); for (auto& b : m.bias) b.release(); }
     DevBuf* nav[] = {&h->d_models, &h->d_child_offset, &h->d_child_model, &h->d_child_bucket, &h->pq_prob, &h->pq_ent, &h->pq_len, &h->surv_row, &h->rs_flag, &h->rs_active, &h->gather_send, &h->gather_recv, &h->aug_rows, &h->q_aug, &h->qn2,
@@ -321,8 +341,10 @@ extern "C" LMI_API int lmi_clone_view(lmi_index* h, lmi_index** out) {
                      &c->surv_row, &c->rs_flag, &c->rs_active, &c->act[0], &c->act[1], &c->xfrag, &c->logits, &c->order, &c->q_nav,
                      &c->q_srch, &c->m, &c->cb_start, &c->item_base, &c->part_base, &c->stats, &c->head, &c->slot_local, &c->slot_col,
                      &c->colmap, &c->qfrag, &c->grp, &c->col_thr, &c->part_score, &c->part_row, &c->rank_d, &c->rank_id, &c->out_d,
-                     &c->out_id, &c->out_key, &c->x_log, &c->x_ext, &c->x_off, &c->fb_list, &c->grp_scratch};
+                     &c->out_id, &c->out_key, &c->x_log, &c->x_ext, &c->x_off, &c->fb_list, &c->grp_scratch, &c->ts_ring, &c->fr_dbg};
     for (DevBuf* b : own) b->forget();
+    c->ts_set = nullptr;
+    memset(c->ts_mask, 0, sizeof(c->ts_mask));
     c->x_cap = 0;
     memset(c->ev_ring, 0, sizeof(c->ev_ring));
     memset(c->valid_ring, 0, sizeof(c->valid_ring));
@@ -776,12 +798,32 @@ static void begin_call(lmi_index* h) {
     h->ev_valid = h->valid_ring[h->ev_cur];
     for (int i = 0; i < 10; ++i) h->ev_valid[i] = false;
     ++h->ev_calls;
+    h->ts_mask[h->ev_cur] = 0u;
+    h->ts_set = nullptr;
+    if (h->timing_level == 2) {   // device stamps: the call's set of the ring (allocated with the first timed call; a failed allocation: no stamps)
+        if (!h->ts_ring.p && h->ts_ring.reserve((size_t)lmi_index::EV_RING * ST_COUNT * 8) != 0) return;
+        h->ts_set = h->ts_ring.as<unsigned long long>() + (size_t)h->ev_cur * ST_COUNT;
+    }
+}
+// the device word a kernel of this call writes stamp `idx` to (nullptr: stamps are off)
+static unsigned long long* tsp(lmi_index* h, int idx) {
+    if (!h->ts_set) return nullptr;
+    h->ts_mask[h->ev_cur] |= 1u << idx;
+    return h->ts_set + idx;
+}
+// the end of a call whose last kernel carries no stamp (lmi_mlp_topk, lmi_nav_order ..): one single-thread launch behind it
+static int stamp_end(lmi_index* h, int idx) {
+    if (unsigned long long* p = tsp(h, idx)) {
+        stamp_kernel<<<1, 1, 0, h->stream>>>(p);
+        HIPCHK(hipGetLastError());
+    }
+    return 0;
 }
 
 static int record(lmi_index* h, int i) {
-    // every recorded event is a ~6 us bubble between two kernels: level 1 keeps the call's first and last
-    // event (LMI_T_TOTAL), level 0 none
-    if (h->timing_level == 0 || (h->timing_level == 1 && i != 0 && i != 1 && i != 4)) return 0;
+    // every recorded event is a ~5 us bubble between two kernels: level 3 records every phase boundary, level 1 the call's first
+    // and last event (LMI_T_TOTAL), levels 0 and 2 none (2: the kernels stamp the chip's clock themselves, tsp)
+    if (h->timing_level == 0 || h->timing_level == 2 || (h->timing_level == 1 && i != 0 && i != 1 && i != 4)) return 0;
     if (!h->ev[i]) HIPCHK(hipEventCreateWithFlags(&h->ev[i], hipEventDisableSystemFence));   // timing only: no system-scope release at the record
     HIPCHK(hipEventRecord(h->ev[i], h->stream));
     h->ev_valid[i] = true;
@@ -825,7 +867,7 @@ static int mlp_layers_enqueue(lmi_index* h, hipStream_t st, const float* d_q, in
     {
         long long total = (long long)ncb * 32 * h->KG[0];
         pack_gather_kernel<<<cdiv(total, 256), 256, 0, st>>>(d_q, h->dims[0], nullptr, nq, (long long)ncb * 32,
-                                                            h->KG[0], h->xfrag.as<float4>());
+                                                            h->KG[0], h->xfrag.as<float4>(), st == h->stream ? tsp(h, ST_MLP0) : nullptr);
         HIPCHK(hipGetLastError());
     }
     int maxrb = 0;
@@ -903,6 +945,7 @@ static int mlp_enqueue(lmi_index* h, const float* d_q, int nq, int nb, int* d_or
         P.order = d_order;
         P.probs = d_probs;
         P.classes = d_order;
+        P.ts = tsp(h, ST_MLP0);
         if (nq_head < nq) CHK(side_fork(h));
         if (d_probs) mlp_fused_kernel<FM_PROBA><<<grid, 256, h->fm_lds, h->stream>>>(P);
         else mlp_fused_kernel<FM_TOPK><<<grid, 256, h->fm_lds, h->stream>>>(P);
@@ -945,6 +988,7 @@ extern "C" LMI_API int lmi_mlp_topk(lmi_index* h, const float* queries_nav, int 
     CHK(record(h, 0));
     CHK(mlp_enqueue(h, static_cast<const float*>(d_q), nq, nb, d_order, d_logits));
     CHK(record(h, 1));
+    CHK(stamp_end(h, ST_MLP1));
     if (!on_device) {
         HIPCHK(hipMemcpyAsync(bucket_order, d_order, (size_t)nq * nb * 4, hipMemcpyDeviceToHost, h->stream));
         if (logits) HIPCHK(hipMemcpyAsync(logits, d_logits, (size_t)nq * L * 4, hipMemcpyDeviceToHost, h->stream));
@@ -975,6 +1019,7 @@ extern "C" LMI_API int lmi_mlp_proba(lmi_index* h, const float* queries_nav, int
     CHK(record(h, 0));
     CHK(mlp_enqueue(h, static_cast<const float*>(d_q), nq, L, d_order, nullptr, d_probs));
     CHK(record(h, 1));
+    CHK(stamp_end(h, ST_MLP1));
     if (!on_device) {
         HIPCHK(hipMemcpyAsync(classes, d_order, (size_t)nq * L * 4, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(probs, d_probs, (size_t)nq * L * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1039,7 +1084,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     CHK(h->item_base.reserve((L + 1) * 4));
     CHK(h->part_base.reserve((L + 1) * 8));
     CHK(h->stats.reserve(32));
-    CHK(h->head.reserve(128));
+    CHK(h->head.reserve(256));   // [0, 32): queue heads | [32, 36): the end-of-launch cells of the device stamps (pass 2, scan_kernel)
     const size_t grp_ints = (size_t)NGRP * L + 2 * (size_t)NGRP * (L + 1) + 3 * NGRP;
     CHK(h->grp.reserve(grp_ints * 4));
     CHK(h->slot_local.reserve((size_t)nslots * 4));
@@ -1088,9 +1133,12 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     Z.count = 0;
     bool fill_ok = true;
     auto fill = [&](void* ptr, long long words, unsigned value) { fill_ok = Z.add(ptr, words, value) && fill_ok; };
-    fill(h->m.p, 3ll * L, 0u);
-    fill(h->head.p, 32, 0u);   // [0..8] pass-2 queue heads + the pass-1 head, [16..24) the heads of pass 2's redo launch
-    fill(h->colmap.p, (long long)ncols, 0xFFFFFFFFu);
+    // front_kernel (lmi_front.h): routing, query norms / packing / bounds and these fills in ONE launch -- for moderate fan-outs and
+    // batches; its blocks compute m / m0 and set their own columns' pass-1 lists, so those fills are not queued
+    const bool use_front = fast && h->use_front && L <= FR_MAX_L && nslots <= FR_MAX_SLOTS && h->d <= FR_MAX_D;
+    if (!use_front) fill(h->m.p, 3ll * L, 0u);
+    fill(h->head.p, 64, 0u);   // [0..8] pass-2 queue heads + the pass-1 head, [16..24) the heads of pass 2's redo launch, [32..36) stamp cells
+    if (!use_front) fill(h->colmap.p, (long long)ncols, 0xFFFFFFFFu);
     fill(h->col_thr.p, (long long)ncols, 0xFF800000u /* -inf */);
     if (fast) {
         CHK(h->qnorm.reserve((size_t)nq * 4));
@@ -1105,7 +1153,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         CHK(h->nkeep.reserve((size_t)nslots * 4));
         const size_t bound_words = ncols * P2_NSL * 16;   // pass 1: [P2_NSL lists][16 slots][columns]
         CHK(h->pf_bound.reserve(bound_words * 4 + 4096));  // + room for the developer builds' phase stamps
-        fill(h->pf_bound.p, (long long)bound_words, 0xFF800000u /* -inf */);
+        if (!use_front) fill(h->pf_bound.p, (long long)bound_words, 0xFF800000u /* -inf */);
         fill(h->cand_cnt.p, (long long)ncols, 0u);
         fill(h->stats.as<long long>() + 2, 4, 0u);
         CHK(h->redo.reserve((size_t)(1 + L) * 4 + ncols));
@@ -1129,6 +1177,9 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         }
     }
     if (!fill_ok) return fail("internal: more than %d fill ranges queued (%s:%d)", FillRanges::MAXR, __FILE__, __LINE__);
+    Z.ts = nullptr;
+    if (!use_front) {
+    Z.ts = tsp(h, ST_FRONT);
     fill_ranges_kernel<<<h->num_cus * 4, 256, 0, h->stream>>>(Z);
     HIPCHK(hipGetLastError());
     route_count_kernel<<<cdiv(nslots, 256), 256, 0, h->stream>>>(d_order, nslots, L, R, h->slot_local.as<int>());
@@ -1148,6 +1199,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     route_fill_kernel<<<cdiv(nslots, 256), 256, 0, h->stream>>>(d_order, h->slot_local.as<int>(), nslots, nb,
                                                                R.cb_start, R.m0, h->colmap.as<int>(), h->slot_col.as<int>());
     HIPCHK(hipGetLastError());
+    }
     ScanParams S;
     S.slab = h->slab.as<float4>();
     S.qfrag = h->qfrag.as<float4>();
@@ -1168,6 +1220,10 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     S.col_thr = h->col_thr.as<float>();
     S.part_score = h->part_score.as<float>();
     S.part_row = h->part_row.as<unsigned>();
+    S.ts_start = nullptr;
+    S.ts_end_cell = nullptr;
+    unsigned long long* const p2_end_cell = reinterpret_cast<unsigned long long*>(h->head.as<unsigned>() + 32);
+    unsigned long long* const scan_end_cell = reinterpret_cast<unsigned long long*>(h->head.as<unsigned>() + 34);
     if (!fast) {
         long long total = ncb_bound * 32 * h->KGs;
         pack_gather_kernel<<<cdiv(total, 256), 256, 0, h->stream>>>(d_qs, h->d, h->colmap.as<int>(), nq, ncb_bound * 32,
@@ -1175,11 +1231,46 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         HIPCHK(hipGetLastError());
         CHK(side_join(h));   // the work queues
         CHK(record(h, 2));
+        S.ts_start = tsp(h, ST_SCAN0);
+        if (S.ts_start) { S.ts_end_cell = scan_end_cell; (void)tsp(h, ST_SCAN1); }
         scan_kernel<<<h->num_cus * h->scan_blocks_per_cu, 256, SCAN_LDS, h->stream>>>(S);
         HIPCHK(hipGetLastError());
         CHK(record(h, 3));
     } else {
         // fp16 prefilter + exact re-rank (lmi_prefilter.h)
+        if (use_front) {
+            FrontParams A;
+            A.bucket_order = d_order;
+            A.nq = nq; A.nb = nb; A.L = L;
+            // parts per bucket: enough blocks to fill the chip twice when the buckets that hold rows here are few (a sharded rank: 15)
+            int owned = 0;
+            for (int b = 0; b < L; ++b) owned += h->h_nb_rows[b] > 0;
+            A.parts = std::max(1, std::min(FR_MAX_PARTS, cdiv(2 * h->num_cus, std::max(1, owned))));
+            A.R = R;
+            A.Z = Z;
+            A.q = d_qs;
+            A.d = h->d; A.KG16 = h->KG16; A.f16x16 = frag16x16(h);
+            A.qnorm = h->qnorm.as<float>(); A.qdelta = h->qdelta.as<float>(); A.qscale = h->qscale.as<float>();
+            A.qfrag16 = h->qfrag16.as<uint4>();
+            A.slot_col = h->slot_col.as<int>();
+            A.eps2 = h->eps2.as<float>();
+            A.bnorm = h->bnorm.as<unsigned>(); A.bdelta = h->bdelta.as<unsigned>();
+            A.pf_bound = h->pf_bound.as<float>();
+            A.ncols = (long long)ncols;
+            A.bound_rows = P2_NSL * 16;
+            A.ts = tsp(h, ST_FRONT);
+            A.dbg = h->fr_dbg.as<unsigned long long>();
+            if (h->fr_parts > 0) A.parts = std::min(FR_MAX_PARTS, h->fr_parts);
+            const int fgrid = 1 + L * A.parts;
+            const size_t flds = fr_lds_bytes(L, h->KG16);
+            switch (nb) {   // the rank count as a compile-time constant: a wave's bucket ids of 8 steps are loaded at once (lmi_front.h, FrIds)
+#define LMI_FR_CASE(NBV) case NBV: front_kernel<NBV><<<fgrid, FR_THREADS, flds, h->stream>>>(A); break;
+                LMI_FR_CASE(1) LMI_FR_CASE(2) LMI_FR_CASE(3) LMI_FR_CASE(4) LMI_FR_CASE(5) LMI_FR_CASE(6) LMI_FR_CASE(8) LMI_FR_CASE(10) LMI_FR_CASE(16)
+#undef LMI_FR_CASE
+                default: front_kernel<0><<<fgrid, FR_THREADS, flds, h->stream>>>(A); break;
+            }
+            HIPCHK(hipGetLastError());
+        } else {
         query_norm_kernel<<<cdiv(nq, 4), 256, 0, h->stream>>>(d_qs, nq, h->d, h->qnorm.as<float>(), h->qdelta.as<float>(),
                                                               h->qscale.as<float>());
         HIPCHK(hipGetLastError());
@@ -1194,6 +1285,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
                                                                    h->bnorm.as<unsigned>(), h->bdelta.as<unsigned>(), h->eps2.as<float>());
         HIPCHK(hipGetLastError());
         CHK(side_join(h));   // the work queues
+        }
         CHK(record(h, 2));
         PrefilterParams F;
         F.slab16 = h->slab16.as<uint4>();
@@ -1232,6 +1324,8 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         F.x.launch = 0;
         h->stamps_off = (ncols * P2_NSL * 16 * 4 + 255) / 256 * 256;
         F.stamps = reinterpret_cast<unsigned long long*>(static_cast<char*>(h->pf_bound.p) + h->stamps_off);
+        F.ts_start = tsp(h, ST_P1);
+        F.ts_end_cell = nullptr;
 #if defined(LMI_P2_STAMPS)
         HIPCHK(hipMemsetAsync(F.stamps, 0, 2 * 8 * 12 * 8, h->stream));
 #endif
@@ -1246,15 +1340,18 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         }
         if (h->debug_emit_all) {  // test hook: bound = -inf, every row of the bucket is a candidate
             FillRanges D;
-            D.count = 1; D.p[0] = reinterpret_cast<unsigned*>(F.bound1); D.n[0] = (long long)ncols; D.v[0] = 0xFF800000u;
+            D.count = 1; D.p[0] = reinterpret_cast<unsigned*>(F.bound1); D.n[0] = (long long)ncols; D.v[0] = 0xFF800000u; D.ts = nullptr;
             fill_ranges_kernel<<<h->num_cus * 4, 256, 0, h->stream>>>(D);
             HIPCHK(hipGetLastError());
         }
         CHK(record(h, 5));
 
-        // pass 2: candidates.  The query-resident form (opt-in: measured slower) needs a col-block's
-        // fragments to fit a wave's registers (d <= 768)
+        // pass 2: candidates
+        F.ts_start = tsp(h, ST_P2);
+        F.ts_end_cell = F.ts_start ? p2_end_cell : nullptr;
         CHK(launch_pass2<false>(h, F));
+        F.ts_start = nullptr;
+        F.ts_end_cell = nullptr;
         CHK(record(h, 6));
         if (h->pf_redo && !h->debug_emit_all) {
             // columns whose candidate buffer overflowed get the 10th best stored score as their bound and one more run of pass 2
@@ -1305,6 +1402,9 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         Q.x_head = F.x.head;
         Q.x_cap = F.x.cap;
         Q.redo_col = sorted_overflow ? reinterpret_cast<const unsigned char*>(h->redo.as<unsigned>() + 1 + L) : nullptr;
+        Q.ts = h->ts_set;
+        Q.p2_end = p2_end_cell;
+        if (Q.ts) { (void)tsp(h, ST_TAIL); (void)tsp(h, ST_P2END); (void)tsp(h, ST_FB); }
 #ifndef LMI_ABL_NOEMIT  // timing-only ablation builds emit nothing: no re-rank, no fallback
         if (rescore_is_streamed(h)) {
             // selection at full occupancy, then the survivors' rows streamed through LDS in coalesced pieces (lmi_rescore.h)
@@ -1364,6 +1464,9 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     M.qn2 = d_qn2;
     M.rank_d = h->rank_d.as<float>();
     M.rank_id = h->rank_id.as<unsigned>();
+    M.ts = h->ts_set;
+    M.scan_end = (!fast && h->ts_set) ? scan_end_cell : nullptr;
+    if (M.ts) { (void)tsp(h, ST_MERGE); (void)tsp(h, ST_END); }
     M.out_d = d_dists;
     M.out_id = d_ids;
     M.out_key = d_keys;
@@ -1686,16 +1789,46 @@ static int read_event_set(const hipEvent_t* ev, const bool* ev_valid, float* ms)
     return 0;
 }
 
+// the same phases from one set of device stamps (timing level 2): `v` the set's ST_COUNT words, `mask` the stamps this call's
+// kernels were given; ticks of the chip's constant clock -> ms
+static void read_stamp_set(const lmi_index* h, const unsigned long long* v, unsigned mask, float* ms) {
+    for (int i = 0; i < LMI_T_COUNT; ++i) ms[i] = 0.0f;
+    auto have = [&](int a) { return (mask >> a) & 1u; };
+    auto span = [&](int a, int b, float* out) {
+        if (have(a) && have(b) && v[b] >= v[a]) *out = (float)((double)(v[b] - v[a]) / h->wall_khz);
+    };
+    span(ST_MLP0, have(ST_MLP1) ? ST_MLP1 : ST_FRONT, &ms[LMI_T_INFERENCE]);
+    span(ST_FRONT, have(ST_P1) ? ST_P1 : ST_SCAN0, &ms[LMI_T_ROUTE]);
+    if (have(ST_P1)) {
+        span(ST_P1, ST_P2, &ms[LMI_T_PF_SAMPLE]);
+        span(ST_P2, ST_P2END, &ms[LMI_T_PF_EMIT]);
+        span(ST_P2END, ST_FB, &ms[LMI_T_RESCORE]);
+        span(ST_FB, ST_MERGE, &ms[LMI_T_FALLBACK]);
+        span(ST_P1, ST_MERGE, &ms[LMI_T_SCAN]);
+    } else {
+        span(ST_SCAN0, ST_SCAN1, &ms[LMI_T_SCAN]);
+    }
+    span(ST_MERGE, ST_END, &ms[LMI_T_MERGE]);
+    const int first = have(ST_MLP0) ? ST_MLP0 : ST_FRONT, last = have(ST_END) ? ST_END : ST_MLP1;
+    span(first, last, &ms[LMI_T_TOTAL]);
+}
+
 extern "C" LMI_API int lmi_timings(lmi_index* h, float* ms) {
     if (!h || !ms) return fail("lmi_timings: NULL argument");
     CHK(set_dev(h));
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->timing_level == 2) {
+        unsigned long long v[ST_COUNT] = {};
+        if (h->ts_set) HIPCHK(hipMemcpy(v, h->ts_set, sizeof(v), hipMemcpyDeviceToHost));
+        read_stamp_set(h, v, h->ts_set ? h->ts_mask[h->ev_cur] : 0u, ms);
+        return 0;
+    }
     return read_event_set(h->ev, h->ev_valid, ms);
 }
 
 extern "C" LMI_API int lmi_set_timing(lmi_index* h, int level) {
     if (!h) return fail("lmi_set_timing: NULL handle");
-    if (level < 0 || level > 2) return fail("lmi_set_timing: level %d outside 0..2", level);
+    if (level < 0 || level > 3) return fail("lmi_set_timing: level %d outside 0..3", level);
     h->timing_level = level;
     return 0;
 }
@@ -1712,9 +1845,18 @@ extern "C" LMI_API int lmi_timings_mean(lmi_index* h, float* ms, int* n_calls) {
     HIPCHK(hipStreamSynchronize(h->stream));
     const int n = (int)std::min<long long>(h->ev_calls, lmi_index::EV_RING);
     double sum[LMI_T_COUNT] = {};
+    std::vector<unsigned long long> ring;
+    if (h->timing_level == 2 && h->ts_ring.p) {
+        ring.resize((size_t)lmi_index::EV_RING * ST_COUNT);
+        HIPCHK(hipMemcpy(ring.data(), h->ts_ring.p, ring.size() * 8, hipMemcpyDeviceToHost));
+    }
     for (int j = 0; j < n; ++j) {
         const int r = ((h->ev_cur - j) % lmi_index::EV_RING + lmi_index::EV_RING) % lmi_index::EV_RING;
         float one[LMI_T_COUNT];
+        if (h->timing_level == 2) {
+            if (ring.empty()) break;
+            read_stamp_set(h, ring.data() + (size_t)r * ST_COUNT, h->ts_mask[r], one);
+        } else
         CHK(read_event_set(h->ev_ring[r], h->valid_ring[r], one));
         for (int i = 0; i < LMI_T_COUNT; ++i) sum[i] += one[i];
     }
@@ -1795,6 +1937,7 @@ extern "C" LMI_API int lmi_nav_order(lmi_index* h, const float* queries_nav, int
     fill(d_ent, (long long)nq * nb, 0xFFFFFFFFu);
     fill(h->nav_count.p, 2 * (nm + 1), 0u);
     if (!fill_ok) return fail("internal: more than %d fill ranges queued (%s:%d)", FillRanges::MAXR, __FILE__, __LINE__);
+    Z.ts = tsp(h, ST_MLP0);
     fill_ranges_kernel<<<h->num_cus * 2, 256, 0, h->stream>>>(Z);
     HIPCHK(hipGetLastError());
     FusedParams P;
@@ -1843,6 +1986,7 @@ extern "C" LMI_API int lmi_nav_order(lmi_index* h, const float* queries_nav, int
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     CHK(record(h, 1));
+    CHK(stamp_end(h, ST_MLP1));
     if (!on_device) {
         HIPCHK(hipMemcpyAsync(slab_ids, d_slab, (size_t)nq * nb * 4, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(entries, d_ent, (size_t)nq * nb * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1893,6 +2037,7 @@ extern "C" LMI_API int lmi_debug_peek(lmi_index* h, const char* name, void* dst,
     DevBuf* b = nullptr;
     size_t off = 0;
     if (!strcmp(name, "pf_bound")) b = &h->pf_bound;
+    if (!strcmp(name, "fr_dbg")) b = &h->fr_dbg;
     if (!strcmp(name, "pf_stamps")) { b = &h->pf_bound; off = h->stamps_off; }
     if (!strcmp(name, "cand_total")) {   // 8 bytes: candidates pass 2 emitted in the last scan, summed over the columns (capped counts not: the counters run on)
         if (bytes != 8 || !h->last_fast) return fail("lmi_debug_peek: cand_total is 8 bytes after a prefilter scan");

@@ -38,6 +38,26 @@ constexpr int NGRP = 8;               // work-queue groups = XCDs of the MI355X
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // ------------------------------------------------------------------------------------------------
+// Device-side phase stamps (lmi_set_timing 2).  A hipEvent between two kernels is a ~5 us bubble on the stream (eight of them:
+// 6 % of a C5 step); instead the kernels of a search write the chip's constant 100 MHz clock (s_memrealtime) into the call's set
+// of the handle's stamp ring: the FIRST workgroup of a launch its start (workgroups are dispatched in order), the LAST one of a
+// short launch its end; a persistent kernel's end is the maximum over its workgroups, folded into a per-call zeroed cell and
+// copied to the set by the next kernel on the stream.  Phases are differences of stamps (lmi_hip.hip, read_stamp_set); nothing is
+// synchronised, polled or waited for.  All pointers are null when stamps are off.
+// ------------------------------------------------------------------------------------------------
+enum { ST_MLP0 = 0, ST_MLP1, ST_FRONT, ST_P1, ST_P2, ST_P2END, ST_TAIL, ST_FB, ST_MERGE, ST_END, ST_SCAN0, ST_SCAN1, ST_COUNT = 16 };
+__device__ __forceinline__ void ts_first(unsigned long long* p) {   // the launch's first workgroup
+    if (p && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) *p = wall_clock64();
+}
+__device__ __forceinline__ void ts_last(unsigned long long* p) {    // the launch's last workgroup (1-D grids)
+    if (p && threadIdx.x == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1) *p = wall_clock64();
+}
+__device__ __forceinline__ void ts_max(unsigned long long* cell) {  // every workgroup of a persistent kernel, at its end
+    if (cell && threadIdx.x == 0) atomicMax(cell, (unsigned long long)wall_clock64());
+}
+__global__ void stamp_kernel(unsigned long long* p) { *p = wall_clock64(); }   // the end of a call whose last kernel carries no stamp
+
+// ------------------------------------------------------------------------------------------------
 // pack: row-major -> fragment-major.  One thread per (destination row, k-group).
 //   gather form  (rowmap != nullptr or identity): dst row p <- src row rowmap[p] (-1 -> zeros)
 //   scatter form (pos != nullptr): src row i of this chunk -> dst row pos[row0 + i] (-1 -> dropped)
@@ -48,7 +68,9 @@ __device__ __forceinline__ void load8(const float* __restrict__ src, int d, int 
 }
 
 __global__ void pack_gather_kernel(const float* __restrict__ src, int d, const int* __restrict__ rowmap,
-                                   int n_src_rows, long long n_dst_rows, int KG, float4* __restrict__ dst) {
+                                   int n_src_rows, long long n_dst_rows, int KG, float4* __restrict__ dst,
+                                   unsigned long long* ts = nullptr) {
+    ts_first(ts);
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_dst_rows * KG) return;
     int g = (int)(idx % KG);
@@ -484,21 +506,21 @@ __host__ __device__ inline size_t route_group_lds(int L) { return (size_t)route_
 constexpr int ROUTE_MAX_BUCKETS = 8000;   // up to here the sort runs in LDS (8 x 8 192 + 8 x 8 000 bytes); beyond (GLOBAL: fan-outs like
                                           // [100, 100]) in a global scratch buffer of route_group_lds(L) + 4 L bytes: slower, rare
 constexpr int ROUTE_ID_BITS = 20;         // bucket ids in the sort key: lmi_buckets_begin refuses 2^20 buckets or more
+// (the body: also the queue-building block of front_kernel, lmi_front.h, which passes the per-bucket counts it holds in LDS as R.m / R.m0;
+// `base`: route_group_lds(L) bytes of LDS, or the global scratch; `active_sp`: one LDS word; 1 024 threads)
 template <bool GLOBAL>
-__global__ __launch_bounds__(1024) void route_group_kernel(int L, RouteArrays R, char* scratch) {
+__device__ __forceinline__ void route_group_body(int L, const RouteArrays& R, char* base, int* active_sp) {
     // Everything in LDS: the ranking is a bitonic sort of one 64-bit key per bucket (work descending, id ascending), O(L log^2 L / 1024)
     // per thread.  (Until round 4 every thread counted the buckets ahead of its own: O(L^2 / 1024) -- a few us at L = 120, 196 us
     // at L = 2 000, on the critical path in front of pass 1.)
-    extern __shared__ __attribute__((aligned(16))) char grp_smem[];
+    int& active_s = *active_sp;
     const int P = route_group_pow2(L);
-    char* base = GLOBAL ? scratch : grp_smem;
     unsigned long long* key_s = reinterpret_cast<unsigned long long*>(base);
     int* items_s = reinterpret_cast<int*>(key_s + P);
     int* items1_s = items_s + L;
     // the sorted bucket ids: written over the keys once they are read (LDS), or behind the item counts (GLOBAL)
     int* order_s = GLOBAL ? items1_s + L : reinterpret_cast<int*>(base);
     const int t = threadIdx.x;
-    __shared__ int active_s;
     if (t == 0) active_s = 0;
     __syncthreads();
     {
@@ -598,6 +620,12 @@ __global__ __launch_bounds__(1024) void route_group_kernel(int L, RouteArrays R,
         }
     }
 }
+template <bool GLOBAL>
+__global__ __launch_bounds__(1024) void route_group_kernel(int L, RouteArrays R, char* scratch) {
+    extern __shared__ __attribute__((aligned(16))) char grp_smem[];
+    __shared__ int active_s;
+    route_group_body<GLOBAL>(L, R, GLOBAL ? scratch : grp_smem, &active_s);
+}
 
 __global__ void route_fill_kernel(const int* __restrict__ bucket_order, const int* __restrict__ slot_local,
                                   int nslots, int nb, const int* __restrict__ cb_start, const int* __restrict__ m0,
@@ -647,6 +675,8 @@ struct ScanParams {
                      // similarity, shared by the chunks of a bucket; -inf before the launch
     float* part_score;
     unsigned* part_row;
+    unsigned long long* ts_start;   // nullable: device stamps (ts_first / ts_max above)
+    unsigned long long* ts_end_cell;
 };
 
 __device__ __forceinline__ void glds16(const float4* gsrc, float4* lds_wave_base) {
@@ -926,6 +956,7 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void scan_kernel(ScanParams P
     __shared__ __attribute__((aligned(16))) float4 sB1[4 * STAGE_G * 64];
     const ScanLds S{sA0, sA1, sB0, sB1};
     int* s_item = reinterpret_cast<int*>(sB1);  // item broadcast: no DMA is in flight between items
+    ts_first(P.ts_start);
     // home queue = this block's XCD (HW_REG_XCC_ID, id 20, bits [3:0]); any value works: speed only
     int grp = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & (NGRP - 1));
     for (;;) {
@@ -955,7 +986,7 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void scan_kernel(ScanParams P
         __syncthreads();
         const int b = s_item[0], local = s_item[1];
         __syncthreads();
-        if (b < 0) return;
+        if (b < 0) { ts_max(P.ts_end_cell); return; }
         const int m_b = P.m[b];
         const int nqt = (m_b + TILE_COLS - 1) / TILE_COLS;
         const int qt = local % nqt, ch = local / nqt;
@@ -997,10 +1028,19 @@ struct MergeParams {
     float* out_d;       // [nq][kout]
     unsigned* out_id;
     unsigned* out_key;  // nullable
+    unsigned long long* ts;              // nullable: the call's stamp set (ST_MERGE at the start, ST_END by the last workgroup)
+    const unsigned long long* scan_end;  // nullable: scan_kernel's end cell, copied to ST_SCAN1
 };
+__device__ __forceinline__ void merge_stamps_begin(const MergeParams& P) {
+    if (P.ts && threadIdx.x == 0 && blockIdx.x == 0) {
+        P.ts[ST_MERGE] = wall_clock64();
+        if (P.scan_end) P.ts[ST_SCAN1] = *P.scan_end;
+    }
+}
 
 __global__ __launch_bounds__(64) void merge_kernel(MergeParams P) {
     const int q = blockIdx.x, lane = threadIdx.x;
+    merge_stamps_begin(P);
     if (q >= P.nq) return;
     float* rd = P.rank_d + (size_t)q * P.nb * KPB;
     unsigned* ri = P.rank_id + (size_t)q * P.nb * KPB;
@@ -1108,6 +1148,7 @@ __global__ __launch_bounds__(64) void merge_kernel(MergeParams P) {
             }
         }
     }
+    if (P.ts) ts_last(P.ts + ST_END);
 }
 
 // Phase B alone, one THREAD per query, for nb <= 16 rank lists that already exist (the prefilter path): a
@@ -1115,6 +1156,7 @@ __global__ __launch_bounds__(64) void merge_kernel(MergeParams P) {
 // argmin costs 18 ds_bpermute round trips per output: 43 us for 10 000 queries; this one 6 us.)
 __global__ __launch_bounds__(64) void merge_ranks_kernel(MergeParams P) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    merge_stamps_begin(P);
     if (q >= P.nq) return;
     const float* rd = P.rank_d + (size_t)q * P.nb * KPB;
     const unsigned* ri = P.rank_id + (size_t)q * P.nb * KPB;
@@ -1142,6 +1184,7 @@ __global__ __launch_bounds__(64) void merge_ranks_kernel(MergeParams P) {
             if (P.out_key) P.out_key[o] = (unsigned)brk * 16u + (unsigned)bpos;
         }
     }
+    if (P.ts) ts_last(P.ts + ST_END);   // (thread 0 of the last workgroup always holds a query)
 }
 
 // ------------------------------------------------------------------------------------------------

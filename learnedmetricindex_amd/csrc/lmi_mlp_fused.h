@@ -64,6 +64,7 @@ struct FusedParams {
     int reverse;                 // root: children pushed least probable first (LearnedIndex.py:220-227)
     int* zero_counts;            // block 0 clears the NEXT step's counters
     int n_zero;
+    unsigned long long* ts;      // nullable: device stamp of the launch's start (lmi_kernels.h)
 };
 
 template <int MODE>
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(FusedParams P) {
     __shared__ float s_max[FM_COLS], s_sum[FM_COLS];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the row-block tests below are s_cbranch, not exec masks
+    ts_first(P.ts);
     if (tid == 0) {
         int model = -1, ncols = 0, first = 0;
         if (!P.node_count) {

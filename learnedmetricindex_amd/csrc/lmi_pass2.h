@@ -861,6 +861,7 @@ __global__ __launch_bounds__(64 * P2_WAVES, 2) __attribute__((amdgpu_num_vgpr(LM
     __shared__ int s_item[2];
     __shared__ int s_prefix[P2_PREFIX_CAP_K];
     if (!SAMPLE && P.redo_count && *P.redo_count == 0u) return;  // the redo launch of a batch without overflowed columns
+    ts_first(P.ts_start);
     P2Queue<SAMPLE, false, 64 * P2_WAVES, P2_PREFIX_CAP_K> queue{P, s_item, s_prefix};
     queue.init();
     P2Item item;
@@ -874,6 +875,7 @@ __global__ __launch_bounds__(64 * P2_WAVES, 2) __attribute__((amdgpu_num_vgpr(LM
         }
 #undef P2_CASE
     }
+    ts_max(P.ts_end_cell);
 }
 
 }  // namespace lmi

@@ -91,6 +91,7 @@ __global__ __launch_bounds__(64 * ps_waves(KG, WIDE), ps_blocks_per_cu(KG, WIDE)
     __shared__ int s_item[2];
     __shared__ int s_prefix[PS_PREFIX_CAP];
     if (!SAMPLE && P.redo_count && *P.redo_count == 0u) return;  // the redo launch of a batch without overflowed columns
+    ts_first(P.ts_start);
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, c = lane & 31;
@@ -404,6 +405,7 @@ __global__ __launch_bounds__(64 * ps_waves(KG, WIDE), ps_blocks_per_cu(KG, WIDE)
         for (int i = 0; i < 8; ++i) atomicAdd(g + i, st_acc[i]);
     }
 #endif
+    ts_max(P.ts_end_cell);
 }
 
 }  // namespace lmi

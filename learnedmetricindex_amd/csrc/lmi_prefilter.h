@@ -177,6 +177,7 @@ struct FillRanges {
     long long n[MAXR];   // 32-bit words
     unsigned v[MAXR];
     int count;
+    unsigned long long* ts;   // nullable: device stamp of the launch's start (the first kernel of a scan on the separate-kernels route)
     // host side: false (and nothing written) when the list is full -- callers turn that into an error, never a stray write
     bool add(void* ptr, long long words, unsigned value) {
         if (count >= MAXR) return false;
@@ -185,6 +186,7 @@ struct FillRanges {
     }
 };
 __global__ void fill_ranges_kernel(FillRanges F) {
+    ts_first(F.ts);
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (int r = 0; r < F.count; ++r)
         for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < F.n[r]; i += stride) F.p[r][i] = F.v[r];
@@ -354,6 +356,8 @@ struct PrefilterParams {
     unsigned* cand_row;   // [columns][PF_CAP]
     float* cand_s;        // [columns][PF_CAP]
     unsigned long long* stamps;  // LMI_P2_STAMPS builds: phase cycles (behind the pass-1 lists in pf_bound)
+    unsigned long long* ts_start;     // nullable: device stamp of the launch's start (lmi_kernels.h: ts_first)
+    unsigned long long* ts_end_cell;  // nullable: the launch's end as the maximum over its workgroups (a per-call zeroed cell; ts_max)
     // second run of pass 2 for the columns whose candidate buffer overflowed (overflow_rebound_kernel); all null in the first
     const unsigned* redo_count;      // [1] columns to redo: 0 -> the launch returns at once
     const int* redo_bucket;          // [L] the bucket has such a column: its items are run again, the others skipped
@@ -411,7 +415,16 @@ struct RescoreParams {
     const unsigned* x_head;
     unsigned x_cap;
     const unsigned char* redo_col;   // [columns] nullable: columns emitted again by the redo launch
+    unsigned long long* ts;               // nullable: the call's stamp set (lmi_kernels.h)
+    const unsigned long long* p2_end;     // pass 2's end cell: the selection kernel copies it to ST_P2END
 };
+// the first workgroup of the selection launch: its own start + pass 2's end (known now: the stream ran pass 2 to completion)
+__device__ __forceinline__ void select_stamps(const RescoreParams& P) {
+    if (P.ts && threadIdx.x == 0 && blockIdx.x == 0) {
+        P.ts[ST_TAIL] = wall_clock64();
+        if (P.p2_end) P.ts[ST_P2END] = *P.p2_end;
+    }
+}
 
 // The overflow log -> the columns' ranges of x_ext (every block of the selection kernel's grid calls this first; the ranges were
 // handed out by overflow_rebound_kernel; fallback_kernel, a later launch, reads them).  Empty log: one cached scalar load.
@@ -480,6 +493,7 @@ constexpr int RS_WAVES = 4;
 constexpr int RS_MAXD = 1024;  // queries up to this many dims are staged in LDS (else read from L2)
 
 __global__ __launch_bounds__(64 * RS_WAVES) __attribute__((amdgpu_waves_per_eu(LMI_RS_WAVES_PER_EU))) void select_rescore_kernel(RescoreParams P) {
+    select_stamps(P);
     pf_x_scatter(P, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
     __shared__ unsigned keep_row[RS_WAVES][PF_KEEP];
     __shared__ __attribute__((aligned(16))) float qs[RS_WAVES][RS_MAXD];
@@ -721,6 +735,7 @@ __global__ __launch_bounds__(256) void fallback_kernel(RescoreParams P) {
     __shared__ float fs[256 * KPB];
     __shared__ unsigned fr[256 * KPB];
     const int tid = threadIdx.x, lane = tid & 63;
+    if (P.ts) ts_first(P.ts + ST_FB);
     // the flagged slots are on a list (select_kernel / the re-rank append): the blocks stride over it -- one block per slot at a
     // time, every block of the grid busy when thousands of slots are flagged (duplicate-heavy data); an empty list costs one
     // round of blocks reading the count

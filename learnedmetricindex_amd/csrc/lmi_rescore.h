@@ -142,6 +142,7 @@ __device__ __forceinline__ void select_tail(const RescoreParams& P, const Select
 
 // That + survivors of one slot; unvisited slots get their (inf, 0) rank list here.
 __global__ __launch_bounds__(256) void select_kernel(RescoreParams P, SelectOut O) {
+    select_stamps(P);
     pf_x_scatter(P, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int p = blockIdx.x * 4 + wv;

@@ -161,6 +161,11 @@ def test_timings_ring_mean(capi):
     d2, i2, _ = idx.search(Qn, Qs, nb, k)
     assert idx.timings()[capi.T_SCAN] > 0
     np.testing.assert_array_equal(i0, i2)
+    idx.set_timing(3)   # every phase from hipEvents between the kernels (the round-1..4 form of level 2)
+    d3, i3, _ = idx.search(Qn, Qs, nb, k)
+    t3 = idx.timings()
+    assert t3[capi.T_SCAN] > 0 and t3[capi.T_PF_EMIT] >= 0
+    np.testing.assert_array_equal(i0, i3)
     with pytest.raises(capi.LmiError):
-        idx.set_timing(3)
+        idx.set_timing(4)
     idx.close()
