@@ -479,6 +479,26 @@ def cpu_baselines(wl, res, args, reference_full=True, reference_sample=True, ora
             "host_cpu_count": host_cores, "usable_cpus": usable, "index_copy_to_host_s": round(t_copy, 2), "variants": variants}
 
 
+def pmc_replay(roof, path, how):
+    """`traffic` (HBM bytes per launch) and the MFMA pipe's busy fraction cannot be measured inside the run (counters need rocprofv3
+    passes of their own): they are REPLAYED from a committed summary of separate `rocprofv3 --pmc` passes, and only when that summary
+    was collected from the very library this process loaded -- the source hash the profiled run reported must be known (not None,
+    not 'unknown': a library built outside build.sh) and equal to the loaded library's, and the profiled kernel must be this leg's."""
+    roof.setdefault("traffic", None)
+    roof.setdefault("mfma_pipe_busy_frac", None)
+    if not os.path.exists(path):
+        return
+    pj = json.load(open(path))
+    have = (pj.get("lib") or {}).get("built_from_source_sha16")
+    mine = lib_provenance()["built_from_source_sha16"]
+    kern = str(pj.get("kernel", "")).rstrip("(").split("<")[0]
+    same = bool(have) and have != "unknown" and have == mine and bool(kern) and kern in roof["kernel"]
+    if same:
+        roof["traffic"], roof["mfma_pipe_busy_frac"] = pj.get("hbm_bytes_per_launch"), pj.get("mfma_pipe_busy_frac")
+    roof["traffic_source"] = {"file": os.path.relpath(path, ROOT), "collected_utc": pj.get("collected_utc"), "commit": pj.get("commit"),
+                              "matches_loaded_library": same, "how": "replayed from separate rocprofv3 --pmc passes of " + how}
+
+
 def dominant_roofline(args, cfg, res, sizes, owner, rank, capi, exact=None):
     """Roofline of the dominant kernel of one timed leg.  Algorithmic work per launch: flops = 2*d*sum over (query, rank)
     slots of the bucket size (sharded runs: this rank's slots); bytes = every visited bucket read once in the kernel's
@@ -510,6 +530,100 @@ def dominant_roofline(args, cfg, res, sizes, owner, rank, capi, exact=None):
                  "launches_timed": res["n_timed"], "floors_ms": {"mfma": round(t_mfma * 1e3, 3), "hbm": round(t_hbm * 1e3, 3)},
                  "k_padded_to": dpad})
     return roof, flops, dom_s
+
+
+def notebook_leg(args, dev):
+    """The reference's OTHER published configuration (/root/reference/01-Introduction.ipynb cells 15-24, the shape
+    of search/search.py's default CLI, :308-327): 100 000 x 768 scan vectors, 32-d navigation vectors, a 2-level index [10, 10] of
+    `MLP` (128 hidden) models, 10 buckets per query, 10 000 queries, k = 10 -> 7.75 s = ~1 290 queries/s published.  Here: synthetic
+    unit-norm mixture vectors, navigation vectors = a fixed random projection to 32-d (the notebook's pca32 stand-in), the index built by
+    li.LearnedIndexBuilder, searched through li.LearnedIndex (lmi_nav_order: the batched priority-queue walk, LearnedIndex.py:216-325,
+    then lmi_scan_topk), host arrays in -> host arrays out per call.  Checked on a query sample by the oracle's restatement of that walk
+    (precompute_bucket_order_multilevel) + per-bucket knn + stable merge; the reference-structured CPU loop runs IN FULL beside it."""
+    import pandas as pd
+    import torch
+    from threadpoolctl import threadpool_limits
+
+    from learnedmetricindex_amd import _capi
+    from learnedmetricindex_amd.li.BuildConfiguration import BuildConfiguration
+    from learnedmetricindex_amd.li.clustering import algorithms
+    from learnedmetricindex_amd.li.LearnedIndexBuilder import LearnedIndexBuilder
+    from learnedmetricindex_amd.li.model import linear_layers
+    from oracle import cpu_baseline as cb
+    from oracle import lmi_oracle
+
+    N, d, d_nav, ncat, nb, nq, k = 100_000, 768, 32, [10, 10], 10, 10_000, 10
+    t_setup = time.time()
+    g = torch.Generator(device=dev).manual_seed(args.seed * 31 + 5)
+    centres = torch.randn(100, d, generator=g, device=dev)
+    draw = lambda n: torch.nn.functional.normalize(centres[torch.randint(0, 100, (n,), generator=g, device=dev)]   # noqa: E731
+                                                   + torch.randn(n, d, generator=g, device=dev), dim=1)
+    X, Q = draw(N).cpu().numpy(), draw(nq).cpu().numpy()
+    proj = (np.random.RandomState(args.seed).randn(d, d_nav) / np.sqrt(d_nav)).astype(np.float32)
+    Xn, Qn = (X @ proj).astype(np.float32), (Q @ proj).astype(np.float32)
+    nav = pd.DataFrame(Xn)
+    nav.index += 1                                     # 1-based labels (search.py:190-191)
+    srch = pd.DataFrame(X)
+    srch.index += 1
+    torch.manual_seed(args.seed)
+    cfg = BuildConfiguration([algorithms["scikit_kmeans"]], [min(args.epochs, 40)], ["MLP"], [0.01], ncat)
+    li, dp, n_buckets, build_s, _ = LearnedIndexBuilder(nav, cfg).build()
+    d0, n0, mt0 = li.search(nav, Qn, srch, Q, dp, ncat, nb, k)          # uploads the resident index
+    steps = max(5, args.steps // 2)
+    for _ in range(2):
+        li.search_resident(Qn, Q, ncat, nb, k)
+    torch.cuda.synchronize()
+    acc = {}
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        dg, ng, mt = li.search_resident(Qn, Q, ncat, nb, k)
+        for kk, v in mt.items():
+            acc[kk] = acc.get(kk, 0.0) + float(v)
+    elapsed = time.perf_counter() - t0
+    assert np.array_equal(ng, n0) and np.array_equal(dg, d0)
+    log(f"[bench:nb100k] built in {time.time() - t_setup:.1f}s ({n_buckets} buckets); {nq * steps / elapsed:.0f} q/s")
+    # ---- the oracle on a sample: the walk's bucket order, then ids and distance bits
+    ns = min(args.cpu_queries, 256)
+    root = linear_layers(li.root_model.model)
+    internal = [(pth, linear_layers(m.model)) for pth, m in li.internal_models.items()]
+    t1 = time.perf_counter()
+    bo = lmi_oracle.precompute_bucket_order_multilevel(root, internal, li.bucket_paths, Qn[:ns], nb, ncat, nthreads=args.cpu_threads or 16)
+    do, no, _ = lmi_oracle.search(root, Qn[:ns], X, Q[:ns], dp, nb, k, bucket_order=bo, nthreads=args.cpu_threads or 16)
+    t_or = time.perf_counter() - t1
+    assert np.array_equal(no, ng[:ns]) and np.array_equal(do, dg[:ns]), "nb100k_2level: CPU oracle and GPU results differ"
+    # ---- recall@10 against exact brute force (notebook cell 31)
+    gt = np.argsort(-(Q[:1000].astype(np.float64) @ X.astype(np.float64).T), axis=1)[:, :k] + 1
+    recall = float(np.mean([len(set(a) & set(b)) / float(k) for a, b in zip(ng[:1000].astype(np.int64), gt)]))
+    # ---- the reference-structured pandas loop IN FULL (all 10 000 queries, all 10 ranks, the whole index): a bucket = a distinct path,
+    # flattened to one id (the reference groups by [category_L1, category_L2]: the same groupby + .loc gather per bucket and rank);
+    # the bucket order is the device walk's (checked above on the sample): navigation is 0.6 % of the reference's own time (cell 24)
+    cpu = None
+    if not args.no_cpu_baseline:
+        nthr = args.cpu_threads or min(16, cb.usable_cpus())
+        order_paths, _ = li._precompute_bucket_order(Qn, nb, ncat)
+        flat = lambda a: np.where(a[..., 0] < 0, -1, a[..., 0] * 100 + np.maximum(a[..., 1], 0))   # noqa: E731
+        torch.set_num_threads(nthr)
+        with threadpool_limits(limits=nthr):
+            t1 = time.perf_counter()
+            rd, rn, parts = cb.reference_structured(nav.copy(), srch, Q, flat(order_paths).astype(np.int32), flat(dp), k)
+            t_ref = time.perf_counter() - t1
+        parts.pop("ranks_done", None)
+        cpu = {"value": round(nq / t_ref, 2), "unit": "queries/s", "cores": nthr, "kind": "port", "queries": nq, "estimated": False,
+               "measured_seconds": round(t_ref, 3), "seconds_by_part": {kk: round(v, 3) for kk, v in parts.items()},
+               "id_set_agreement_with_gpu": round(cb.id_agreement(rn, ng), 6),
+               "sample": f"the reference's loop (LearnedIndex.py:101-157, 328-373) in full: all {nq} queries x {nb} ranks over the whole "
+                         f"{N} x {d} frame on {nthr} threads; bucket order from the device walk (navigation not timed)"}
+    li.close()
+    return {"workload": f"{N}x{d} scan vectors, {d_nav}-d navigation vectors (random projection), 2-level [10,10] MLP(128) index, "
+                        f"{nb} buckets, {nq}-query batch, k={k}; li.LearnedIndex.search_resident (lmi_nav_order + lmi_scan_topk), host in -> host out",
+            "value": round(nq * steps / elapsed, 2), "unit": "queries/s", "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 4),
+            "published_reference_qps": 1290, "published_reference_note": "01-Introduction.ipynb cell 24: 10 000 queries in 7.75 s on LAION-100K (other hardware, real data)",
+            "recall_at_10": round(recall, 5), "buckets": int(n_buckets), "build_s": round(build_s, 2),
+            "phases_ms": {"inference": round(acc.get("inference", 0.0) / steps * 1e3, 4), "seq_search": round(acc.get("seq_search", 0.0) / steps * 1e3, 4),
+                          "search_within_buckets": round(acc.get("search_within_buckets", 0.0) / steps * 1e3, 4), "sort": round(acc.get("sort", 0.0) / steps * 1e3, 4),
+                          "search_wall": round(acc.get("search", 0.0) / steps * 1e3, 4)},
+            "oracle_check": {"queries": ns, "identical_ids_and_distances": True, "checker_queries_per_s": round(ns / t_or, 3)},
+            "cpu_baseline": cpu}
 
 
 class Watchdog:
@@ -684,6 +798,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-hard-leg", action="store_true", help="skip the second, harder workload (overlapping clusters)")
+    ap.add_argument("--hard-only", action="store_true", help="profiling aid: the MAIN leg runs on the hard generator (overlapping clusters, zipf sizes); nothing else")
     ap.add_argument("--no-exact-leg", action="store_true", help="skip the all-f32 leg (the same workload with lmi_set_prefilter(0))")
     ap.add_argument("--hard-sigma", type=float, default=1.0)
     ap.add_argument("--hard-centre-scale", type=float, default=0.26)
@@ -739,7 +854,11 @@ def main():
 
     from learnedmetricindex_amd import _capi
 
-    wl = Workload(args, cfg, dev, rank, world, local_rank)
+    if args.hard_only:   # (tools/profile_round.sh: the PMC passes of the hard leg's dominant kernel)
+        args.no_cpu_baseline = args.no_recall = args.no_hard_leg = args.no_other_configs = args.no_exact_leg = True
+        wl = Workload(args, cfg, dev, rank, world, local_rank, sigma=args.hard_sigma, zipf=args.hard_zipf, centre_scale=args.hard_centre_scale, tag="hard")
+    else:
+        wl = Workload(args, cfg, dev, rank, world, local_rank)
     res = wl.run(args.steps, args.warmup, shard_inference=True)
     elapsed, phases, out_d, out_i, bo = res["elapsed"], res["phases"], res["out_d"], res["out_i"], res["bo"]
     flops, pairs, items = res["scan_stats"]
@@ -787,6 +906,8 @@ def main():
                       centre_scale=args.hard_centre_scale, tag="hard")
         rh = wh.run(max(5, args.steps // 2), 2, measure_resident=True)
         hs = wh.sizes
+        hroof, _, _ = dominant_roofline(args, cfg, rh, wh.sizes, wh.owner, rank, _capi)
+        pmc_replay(hroof, os.path.join(ROOT, "profiles", "scan_pmc_hard.json"), "bench.py --hard-only")
         hard_checked = None
         if rank == 0 and not args.no_cpu_baseline:   # the checker on the HARD workload too: small score gaps, the bound's window matters
             nthr_h = args.cpu_threads or min(16, os.cpu_count() or 1)
@@ -801,7 +922,7 @@ def main():
                 "bucket_sizes_min_median_max": [int(hs.min()), int(np.median(hs)), int(hs.max())],
                 "survivors_per_slot": round(rh["pf_stats"][1] / max(1, nq * nb), 2), "fallback_slots": int(rh["pf_stats"][2]),
                 "overflowed_columns": rh.get("pf_redo_columns"),
-                "scan_pairs": int(rh["scan_stats"][1]), "oracle_check": hard_checked,
+                "scan_pairs": int(rh["scan_stats"][1]), "oracle_check": hard_checked, "roofline": hroof,
                 "phases_ms": {"pf_sample": round(float(rh["phases"][5]), 4), "pf_emit": round(float(rh["phases"][6]), 4),
                               "rescore": round(float(rh["phases"][7]), 4), "fallback": round(float(rh["phases"][8]), 4)}}
 
@@ -821,16 +942,9 @@ def main():
         eroof, eflops, _ = dominant_roofline(args, cfg, re_, we.sizes, we.owner, rank, _capi, exact=True)
         same = bool(np.array_equal(re_["out_i"], out_i) and np.array_equal(re_["out_d"], out_d))
         assert same, "the all-f32 leg and the default leg returned different results"
-        etj = os.path.join(ROOT, "profiles", "scan_pmc_c2_exact.json")   # counters of `bench.py --exact`, replayed like the default leg's
         eroof["traffic"] = eroof["mfma_pipe_busy_frac"] = None
-        if os.path.exists(etj) and not any(getattr(args, key) is not None for key in ("n", "nq", "nb", "leaves", "d")):
-            epj = json.load(open(etj))
-            esame = ((epj.get("lib") or {}).get("built_from_source_sha16") == lib_provenance()["built_from_source_sha16"]
-                     and str(epj.get("kernel", "")).rstrip("(") in eroof["kernel"])
-            if esame:
-                eroof["traffic"], eroof["mfma_pipe_busy_frac"] = epj.get("hbm_bytes_per_launch"), epj.get("mfma_pipe_busy_frac")
-            eroof["traffic_source"] = {"file": os.path.relpath(etj, ROOT), "collected_utc": epj.get("collected_utc"), "commit": epj.get("commit"),
-                                       "matches_loaded_library": bool(esame), "how": "replayed from separate rocprofv3 --pmc passes of bench.py --exact"}
+        if not any(getattr(args, key) is not None for key in ("n", "nq", "nb", "leaves", "d")):
+            pmc_replay(eroof, os.path.join(ROOT, "profiles", "scan_pmc_c2_exact.json"), "bench.py --exact")
         echeck = None
         if rank == 0 and not args.no_cpu_baseline:
             eq_ = min(args.cpu_queries, nq, 64)
@@ -862,16 +976,7 @@ def main():
             osteps = max(10, args.steps)
             ro = wo.run(osteps, 3, measure_resident=False)
             oroof, _, _ = dominant_roofline(args, ocfg, ro, wo.sizes, wo.owner, rank, _capi)
-            otj = os.path.join(ROOT, "profiles", f"scan_pmc_{cname}.json")
-            oroof["traffic"] = None
-            if os.path.exists(otj):
-                opj = json.load(open(otj))
-                osame = ((opj.get("lib") or {}).get("built_from_source_sha16") == lib_provenance()["built_from_source_sha16"]
-                         and str(opj.get("kernel", "")).split("<")[0] in oroof["kernel"])
-                oroof["traffic"] = opj.get("hbm_bytes_per_launch") if osame else None
-                oroof["mfma_pipe_busy_frac"] = opj.get("mfma_pipe_busy_frac") if osame else None
-                oroof["traffic_source"] = {"file": os.path.relpath(otj, ROOT), "collected_utc": opj.get("collected_utc"), "commit": opj.get("commit"),
-                                           "matches_loaded_library": bool(osame), "how": "replayed from separate rocprofv3 --pmc passes of bench.py --config " + cname}
+            pmc_replay(oroof, os.path.join(ROOT, "profiles", f"scan_pmc_{cname}.json"), "bench.py --config " + cname)
             others[cname] = {"workload": f"{ocfg['n']}x{ocfg['d']}, {ocfg['leaves']} leaves, top-{ocfg['nb']}, {ocfg['nq']}-query batch",
                              "value": round(ocfg["nq"] * osteps / ro["elapsed"], 2), "unit": "queries/s",
                              "ms_per_step": round(ro["elapsed"] / osteps * 1e3, 4),
@@ -919,6 +1024,16 @@ def main():
             wo.eng.close()
             wo.eng = None
 
+    nb100k = None
+    if world == 1 and args.config == "c2" and not args.no_other_configs and not args.exact and not args.emulate_shard and rank == 0:
+        for w_ in (wl, locals().get("wh")):
+            if w_ is not None and getattr(w_, "eng", None) is not None:
+                w_.eng.close()
+                w_.eng = None
+        torch.cuda.empty_cache()
+        nb100k = notebook_leg(args, dev)
+        others["nb100k_2level"] = nb100k
+
     if rank == 0:
         scan_s = max(float(phases[_capi.T_SCAN]) * 1e-3, 1e-12)
         roof, flops, dom_s = dominant_roofline(args, cfg, res, sizes, owner, rank, _capi)
@@ -928,7 +1043,7 @@ def main():
         # summary was collected from the library sources this run was built from -- otherwise they are null.
         traffic = mfma_busy = None
         prov = lib_provenance()
-        tj = args.traffic_json or os.path.join(ROOT, "profiles", f"scan_pmc_{args.config}{'_exact' if args.exact else ''}.json")
+        tj = args.traffic_json or os.path.join(ROOT, "profiles", f"scan_pmc_{'hard' if args.hard_only else args.config}{'_exact' if args.exact else ''}.json")
         overridden = any(getattr(args, key) is not None for key in ("n", "nq", "nb", "leaves", "d", "emulate_shard"))
         traffic_source = None
         if world == 1 and not overridden and os.path.exists(tj):
@@ -1005,6 +1120,28 @@ def main():
                           "pf_sample": round(float(phases[5]), 4), "pf_emit": round(float(phases[6]), 4),
                           "rescore": round(float(phases[7]), 4), "fallback": round(float(phases[8]), 4)},
         }
+        # every leg once more, compact and LAST on the line (the driver keeps the line's tail): queries/s, ms per step, the dominant
+        # kernel's roofline fraction and duration, whether the oracle check passed (it asserts: a leg that ran it passed it)
+        def leg(v, ms, roofv, checked, **extra):
+            out = {"qps": None if v is None else round(v), "ms": None if ms is None else round(ms, 4),
+                   "frac": None if not roofv else roofv.get("frac"), "kernel_ms": None if not roofv else roofv.get("avg_launch_ms"),
+                   "oracle_ok": bool(checked)}
+            out.update(extra)
+            return out
+        legs = {"c2": leg(result["value"], result["ms_per_step"], roof, cpu is not None, recall=result["recall_at_10"])}
+        if hard:
+            legs["hard"] = leg(hard["value"], hard["ms_per_step"], hard.get("roofline"), hard.get("oracle_check"), recall=hard["recall_at_10"])
+        if exact_leg:
+            legs["exact"] = leg(exact_leg["value"], exact_leg["ms_per_step"], exact_leg["roofline"], exact_leg.get("oracle_check"), same_as_c2=exact_leg["identical_to_default_leg"])
+        for cname in ("c1", "c5"):
+            if others and cname in others:
+                o_ = others[cname]
+                legs[cname] = leg(o_["value"], o_["ms_per_step"], o_["roofline"], o_.get("oracle_check"), recall=o_["recall_at_10"])
+        if nb100k:
+            legs["nb100k_2level"] = leg(nb100k["value"], nb100k["ms_per_step"], None, nb100k["oracle_check"], recall=nb100k["recall_at_10"],
+                                        nav_ms=nb100k["phases_ms"]["inference"], ref_published_qps=1290,
+                                        cpu_ref_qps=None if not nb100k["cpu_baseline"] else nb100k["cpu_baseline"]["value"])
+        result["legs"] = legs
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -180,6 +180,8 @@ LMI_API int lmi_merge_gathered(lmi_index *h, const float *gathered_dists, const 
  * submitting host thread for milliseconds behind queued kernels (ROCm 7.2).  Both pointers 16-byte aligned.
  * Replaces the `.cpu().numpy()` of model.py:240-241 / the numpy results of LearnedIndex.py:340-341. */
 LMI_API int lmi_copy_out(lmi_index *h, void *dst, const void *src, int64_t bytes);
+/* Up to 4 such copies as ONE launch (dists, ids and the bucket order of a batch: three launches were 25 us of a 0.6-ms search). */
+LMI_API int lmi_copy_out_many(lmi_index *h, int n, void *const *dst, const void *const *src, const int64_t *bytes);
 
 /* The same exchange through RCCL inside the library (no reference counterpart; SURVEY 8b `lmi_allgather_merge(h,
  * ncclComm_t, ...)`): a C/C++ caller runs the bucket-sharded mode without torch.distributed.

@@ -61,6 +61,7 @@ SIGNATURES = {
                                            _vp, _vp]),
     "lmi_bucket_read": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp]),
     "lmi_copy_out": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64]),
+    "lmi_copy_out_many": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp]),
     "lmi_knn_ip": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int64, _vp, ctypes.c_int64, ctypes.c_int,
                                   ctypes.c_int, _vp, _vp]),
     "lmi_timings": (ctypes.c_int, [_vp, _vp]),
@@ -373,6 +374,18 @@ class Index:
         assert dst_pinned_t.is_pinned() and dst_pinned_t.numel() * dst_pinned_t.element_size() == nbytes
         assert src_dev_t.is_contiguous() and dst_pinned_t.is_contiguous()
         _check(lib().lmi_copy_out(self._h, _ptr(dst_pinned_t), _ptr(src_dev_t), nbytes))
+
+    def copy_out_many(self, pairs) -> None:
+        """[(dst pinned host tensor, src device tensor), ..] (up to 4) by ONE kernel on the handle's stream."""
+        n = len(pairs)
+        dst = (ctypes.c_void_p * n)()
+        src = (ctypes.c_void_p * n)()
+        nby = (ctypes.c_int64 * n)()
+        for i, (d_t, s_t) in enumerate(pairs):
+            nbytes = s_t.numel() * s_t.element_size()
+            assert d_t.is_pinned() and d_t.numel() * d_t.element_size() == nbytes and s_t.is_contiguous() and d_t.is_contiguous()
+            dst[i], src[i], nby[i] = d_t.data_ptr(), s_t.data_ptr(), nbytes
+        _check(lib().lmi_copy_out_many(self._h, n, dst, src, nby))
 
     # ---- RCCL inside the library (the sharded exchange without torch.distributed) ----------------------------
     @staticmethod

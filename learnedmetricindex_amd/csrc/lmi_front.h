@@ -66,25 +66,34 @@ __host__ __device__ inline size_t fr_stage_bytes(int L, int KG16) {
 __host__ __device__ inline int fr_lpad(int L) { return (L + 3) & ~3; }   // (the staging area stays 16-byte aligned)
 __host__ __device__ inline size_t fr_lds_bytes(int L, int KG16) { return (size_t)fr_lpad(L) * 12 + 256 + (size_t)FR_CAPW * 4 + fr_stage_bytes(L, KG16); }
 
-__device__ __forceinline__ void fr_load8(const float* __restrict__ row, int d, int k0, bool vec, float (&v)[8]) {
-    if (vec && k0 + 8 <= d) {
-        const float4 lo = *reinterpret_cast<const float4*>(row + k0), hi = *reinterpret_cast<const float4*>(row + k0 + 4);
-        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+// 8 consecutive floats of a query row starting at k0, zeros past the row's end or when !ok -- BRANCH-FREE (clamped addresses + selects): a
+// wave's loads of several rows / chunks then issue back to back and are waited for once (with a branch per load hipcc waits per load:
+// four serial round trips per col-block, round 5's first form: 8-12 us per col-block instead of ~3).  VEC: d % 8 == 0 (16-byte loads).
+template <bool VEC>
+__device__ __forceinline__ void fr_load8(const float* __restrict__ row, int d, int k0, bool ok, float (&v)[8]) {
+    if constexpr (VEC) {
+        const int kk = ok ? k0 : 0;
+        const float4 lo = *reinterpret_cast<const float4*>(row + kk), hi = *reinterpret_cast<const float4*>(row + kk + 4);
+        v[0] = ok ? lo.x : 0.0f; v[1] = ok ? lo.y : 0.0f; v[2] = ok ? lo.z : 0.0f; v[3] = ok ? lo.w : 0.0f;
+        v[4] = ok ? hi.x : 0.0f; v[5] = ok ? hi.y : 0.0f; v[6] = ok ? hi.z : 0.0f; v[7] = ok ? hi.w : 0.0f;
     } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (k0 + j < d) ? row[k0 + j] : 0.0f;
+        for (int j = 0; j < 8; ++j) {
+            const bool in = ok && k0 + j < d;
+            const float x = row[in ? k0 + j : 0];
+            v[j] = in ? x : 0.0f;
+        }
     }
 }
 
 // One col-block (32 columns) of a bucket: rows -> scale, norms, eps', fp16 fragments (through the LDS image `stage`), pass-1 lists.
 // GS lanes per query row (a power of two >= the row's 8-float chunks, capped at the wave); CP chunks per lane and row: a row is read
 // ONCE, all of a wave's loads in flight together (a wave's NCOL rows x CP chunks), and stays in registers through the k-slices.
-template <int GS, int CP>
+template <int GS, int CP, bool VEC>
 __device__ __forceinline__ void fr_pack_colblock(const FrontParams& P, const int* __restrict__ colq32, int b, size_t cb_global,
                                                  char* stage, int tid) {
     const int lane = tid & 63, w = tid >> 6;
     const int d = P.d, KG16 = P.KG16;
-    const bool vec = (d & 3) == 0;
     const int nchunk_row = (d + 7) >> 3;               // chunks that hold data; the slab pads K to 16 KG16
     constexpr int CPW = 64 / GS;                       // rows per wave instruction
     constexpr int NCOL = (32 + FR_WAVES * CPW - 1) / (FR_WAVES * CPW);   // rows per wave and col-block (2 at GS = 64, else 1 or none)
@@ -93,20 +102,18 @@ __device__ __forceinline__ void fr_pack_colblock(const FrontParams& P, const int
     const float guard = norm_guard(d);
     float v[NCOL][CP][8];
     int qi[NCOL];
-    float s[NCOL];
 #pragma unroll
     for (int c = 0; c < NCOL; ++c) {
         const int cc = w * CPW + sub + c * FR_WAVES * CPW;
         qi[c] = cc < 32 ? colq32[cc] : -1;
+    }
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) {
         const float* row = P.q + (size_t)(qi[c] < 0 ? 0 : qi[c]) * d;
 #pragma unroll
         for (int i = 0; i < CP; ++i) {
             const int j = gl + GS * i;
-            if (qi[c] >= 0 && j < nchunk_row) fr_load8(row, d, 8 * j, vec, v[c][i]);
-            else {
-#pragma unroll
-                for (int t = 0; t < 8; ++t) v[c][i][t] = 0.0f;
-            }
+            fr_load8<VEC>(row, d, 8 * j, qi[c] >= 0 && j < nchunk_row, v[c][i]);
         }
     }
 #pragma unroll
@@ -119,13 +126,13 @@ __device__ __forceinline__ void fr_pack_colblock(const FrontParams& P, const int
             for (int t = 0; t < 8; ++t) mx = fmaxf(mx, fabsf(v[c][i][t]));
 #pragma unroll
         for (int o = GS / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        s[c] = scale_of_max(__float_as_uint(mx));   // (an idle column: 1)
+        const float s = scale_of_max(__float_as_uint(mx));   // (an idle column: 1)
         float acc = 0.0f, dl = 0.0f;
 #pragma unroll
         for (int i = 0; i < CP; ++i)
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                const float vs = v[c][i][t] * s[c];
+                const float vs = v[c][i][t] * s;
                 const float e = (float)(_Float16)vs - vs;
                 acc += vs * vs;
                 dl += e * e;
@@ -137,7 +144,7 @@ __device__ __forceinline__ void fr_pack_colblock(const FrontParams& P, const int
             const size_t col = cb_global * 32 + cc;
             if (qi[c] >= 0) {
                 const float qn = sqrtf(acc) * guard, dq = sqrtf(dl) * guard;
-                P.qnorm[qi[c]] = qn; P.qdelta[qi[c]] = dq; P.qscale[qi[c]] = s[c];
+                P.qnorm[qi[c]] = qn; P.qdelta[qi[c]] = dq; P.qscale[qi[c]] = s;
                 // slot_bound_kernel's bound (lmi_prefilter.h): Cauchy-Schwarz on the measured norms + the two binary32 summations
                 const float e = dq * (xn + dx) + qn * dx + 4.0f * (float)(KG16 * 16) * 5.96046448e-8f * (qn + dq) * (xn + dx);
                 P.eps2[col] = 2.0f * e * 1.001f;
@@ -160,47 +167,57 @@ __device__ __forceinline__ void fr_pack_colblock(const FrontParams& P, const int
 #pragma unroll
                     for (int t = 0; t < 8; ++t) h[t] = (_Float16)v[c][i][t];
                     int slot;
-                    if (P.f16x16) slot = (2 * (g >> 1) + (cc >> 4) - g0) * 64 + 16 * (2 * (g & 1) + hh) + (cc & 15);   // convert16_kernel's K > 128 shape
-                    else slot = (g - g0) * 64 + hh * 32 + cc;
+                    if (P.f16x16) {   // convert16_kernel's K > 128 shape; the LDS image is XOR-swizzled in 16-slot rows: a row's 64 chunks would
+                                      // otherwise all fall into ONE 16-byte bank group (a 64-way conflict per ds_write_b128)
+                        slot = (2 * (g >> 1) + (cc >> 4) - g0) * 64 + 16 * (2 * (g & 1) + hh) + (cc & 15);
+                        slot ^= ((slot >> 4) & 3) | (((slot >> 7) & 3) << 2);
+                    } else {
+                        slot = (g - g0) * 64 + hh * 32 + cc;
+                    }
                     *reinterpret_cast<uint4*>(stage + (size_t)slot * 16) = *reinterpret_cast<uint4*>(&h);
                 }
             }
         }
         __syncthreads();
         uint4* dst = P.qfrag16 + (cb_global * (size_t)KG16 + (size_t)g0) * 64;
-        for (int i = tid; i < gs * 64; i += FR_THREADS) dst[i] = *reinterpret_cast<const uint4*>(stage + (size_t)i * 16);
+        for (int i = tid; i < gs * 64; i += FR_THREADS) {
+            const int src = P.f16x16 ? (i ^ (((i >> 4) & 3) | (((i >> 7) & 3) << 2))) : i;
+            dst[i] = *reinterpret_cast<const uint4*>(stage + (size_t)src * 16);
+        }
         __syncthreads();
-    }
-    // the col-block's pass-1 lists: bound_rows x 32 floats of -inf, 128 contiguous bytes per row
-    const float ninf = -INFINITY;
-    const float4 f4 = make_float4(ninf, ninf, ninf, ninf);
-    for (int i = tid; i < P.bound_rows * 4; i += FR_THREADS) {
-        float* dstp = P.pf_bound + (size_t)(i >> 2) * (size_t)P.ncols + cb_global * 32 + (size_t)(i & 3) * 8;
-        *reinterpret_cast<float4*>(dstp) = f4;
-        *reinterpret_cast<float4*>(dstp + 4) = f4;
     }
 }
 
-// the wave's bucket ids of FR_U consecutive 64-query steps: every load issued before the first use.  NB > 0: the rank count is a
-// compile-time constant (registers); NB == 0: any count, one step at a time
-constexpr int FR_U = 8;
-template <int NB>
-struct FrIds {
-    static constexpr int U = NB > 0 ? (NB <= 4 ? FR_U : NB <= 8 ? FR_U / 2 : 2) : 1;
-    int v[U][NB > 0 ? NB : 1];
-    __device__ __forceinline__ void load(const int* __restrict__ bo, int nb, int q_first, int lane, int q_end) {
-        if constexpr (NB > 0) {
+// the bucket ids of U consecutive 64-query steps of a wave (NB ranks each) and the sizes of those buckets: every global load issued
+// before the first use (clamped addresses, selects: no branch between them), then every LDS lookup, each waited for once
+template <int NB, int U>
+struct FrChunk {
+    int id[U][NB];
+    int rows[U][NB];
+    __device__ __forceinline__ void load(const int* __restrict__ bo, int q_first, int lane, int q_end) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int q = q_first + 64 * u + lane;
+        for (int u = 0; u < U; ++u) {
+            const int q = q_first + 64 * u + lane;
+            const int qq = min(q, q_end - 1);
 #pragma unroll
-                for (int r = 0; r < NB; ++r) v[u][r] = q < q_end ? bo[(size_t)q * NB + r] : -1;
-            }
+            for (int r = 0; r < NB; ++r) id[u][r] = bo[(size_t)qq * NB + r];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool live = q_first + 64 * u + lane < q_end;
+#pragma unroll
+            for (int r = 0; r < NB; ++r) id[u][r] = live ? id[u][r] : -1;
         }
     }
-    __device__ __forceinline__ int get(const int* __restrict__ bo, int nb, int q, int q_end, int u, int r) const {
-        if constexpr (NB > 0) return v[u][r];
-        else return q < q_end ? bo[(size_t)q * nb + r] : -1;
+    __device__ __forceinline__ void sizes(const int* nbr, int L) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                const bool inr = id[u][r] >= 0 && id[u][r] < L;
+                const int x = nbr[inr ? id[u][r] : 0];
+                rows[u][r] = inr ? x : 0;
+            }
     }
 };
 
@@ -218,6 +235,9 @@ __global__ __launch_bounds__(FR_THREADS) void front_kernel(FrontParams P) {
     const int bid = blockIdx.x;
     const int b = bid == 0 ? -1 : (bid - 1) / P.parts, part = bid == 0 ? 0 : (bid - 1) % P.parts;
     if (bid == 0 && tid == 0 && P.ts) *P.ts = wall_clock64();
+    // ---- the small per-call arrays (the old fill_ranges_kernel list): every block its share, before anything can make it leave ----
+    for (int r = 0; r < P.Z.count; ++r)
+        for (long long i = (long long)bid * FR_THREADS + tid; i < P.Z.n[r]; i += (long long)gridDim.x * FR_THREADS) P.Z.p[r][i] = P.Z.v[r];
     if (b >= 0 && P.R.nb_rows[b] == 0) return;   // an empty (or unowned) bucket: nothing is routed to it
     const int dbg_base = bid == 0 ? 0 : bid == 1 ? 8 : bid == (int)gridDim.x - 1 ? 16 : -1;
     FR_DBG(0);
@@ -227,21 +247,39 @@ __global__ __launch_bounds__(FR_THREADS) void front_kernel(FrontParams P) {
     const int Qw = (((nq + FR_WAVES - 1) / FR_WAVES) + 63) / 64 * 64;
     const int q0w = w * Qw, q1w = min(nq, q0w + Qw);
     const bool use_primary = P.R.primary_nb > 0;
-    constexpr int U = FrIds<NB>::U;
-    constexpr int RUNR = NB > 0 ? NB : 1;   // unroll count of the rank loops (a run-time rank count: not unrolled)
+    constexpr int NBC = NB > 0 ? NB : 1;
+    constexpr int U = NB > 0 ? (NB <= 4 ? 4 : NB <= 8 ? 2 : 1) : 1;
     int own0 = 0, own1 = 0;   // wave-uniform
-    for (int qs = q0w; qs < q1w; qs += 64 * U) {
-        FrIds<NB> ids;
-        ids.load(P.bucket_order, nb, qs, lane, q1w);
+    if constexpr (NB > 0) {
+        for (int qs = q0w; qs < q1w; qs += 64 * U) {
+            FrChunk<NBC, U> C;
+            C.load(P.bucket_order, qs, lane, q1w);
+            C.sizes(nbr, L);
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int q = qs + 64 * u + lane;
-            if (qs + 64 * u >= q1w) break;   // wave-uniform
+            for (int u = 0; u < U; ++u) {
+                const int q = qs + 64 * u + lane;
+                bool big = false;   // a lower rank of this query holds a bucket of >= 64 rows: the slot is not primary (route_count_kernel)
+#pragma unroll
+                for (int r = 0; r < NBC; ++r) {
+                    const int br = C.id[u][r], rows = C.rows[u][r];
+                    const bool valid = rows > 0;
+                    const bool other = use_primary && big;
+                    if (valid) atomicAdd(&cnt[other ? L + br : br], 1);
+                    const bool mine = valid && br == b;
+                    own0 += (int)__popcll(__ballot(mine && !other));
+                    own1 += (int)__popcll(__ballot(mine && other));
+                    if (bid == 0 && q < q1w && !valid) P.slot_col[(size_t)q * NBC + r] = -1;   // unvisited (LearnedIndex.py:340-341)
+                    big = big || rows >= 64;
+                }
+            }
+        }
+    } else {   // any rank count: one step at a time
+        for (int qs = q0w; qs < q1w; qs += 64) {
+            const int q = qs + lane;
             const bool live = q < q1w;
-            bool big = false;   // a lower rank of this query holds a bucket of >= 64 rows: the slot is not primary (route_count_kernel)
-#pragma unroll RUNR
+            bool big = false;
             for (int r = 0; r < nb; ++r) {
-                const int br = ids.get(P.bucket_order, nb, q, q1w, u, r);
+                const int br = live ? P.bucket_order[(size_t)q * nb + r] : -1;
                 const bool inr = br >= 0 && br < L;
                 const int rows = inr ? nbr[br] : 0;
                 const bool valid = rows > 0;
@@ -250,8 +288,8 @@ __global__ __launch_bounds__(FR_THREADS) void front_kernel(FrontParams P) {
                 const bool mine = valid && br == b;
                 own0 += (int)__popcll(__ballot(mine && !other));
                 own1 += (int)__popcll(__ballot(mine && other));
-                if (bid == 0 && live && !valid) P.slot_col[(size_t)q * nb + r] = -1;   // unvisited (LearnedIndex.py:340-341)
-                big = big || (inr && rows >= 64);
+                if (bid == 0 && live && !valid) P.slot_col[(size_t)q * nb + r] = -1;
+                big = big || rows >= 64;
             }
         }
     }
@@ -292,11 +330,8 @@ __global__ __launch_bounds__(FR_THREADS) void front_kernel(FrontParams P) {
             P.R.stats[0] = ps;
             P.R.stats[1] = is;
         }
-        FR_DBG(2);
-        // ---- the small per-call arrays (the old fill_ranges_kernel list) ----
-        for (int r = 0; r < P.Z.count; ++r)
-            for (long long i = tid; i < P.Z.n[r]; i += FR_THREADS) P.Z.p[r][i] = P.Z.v[r];
         __syncthreads();
+        FR_DBG(2);
         FR_DBG(3);
         // ---- the XCD-affine work queues from the LDS histogram: cnt[0, L) = m0 as it stands, cnt[L, 2L) <- m ----
         for (int i = tid; i < L; i += FR_THREADS) cnt[L + i] += cnt[i];
@@ -332,6 +367,17 @@ __global__ __launch_bounds__(FR_THREADS) void front_kernel(FrontParams P) {
     int cbs = 0;
     for (int i = 0; i < FR_WAVES; ++i) cbs += misc[32 + i];
     FR_DBG(2);
+    // the pass-1 lists of the part's col-blocks: bound_rows rows of -inf, (cb_hi - cb_lo) * 128 contiguous bytes each (stores only:
+    // they leave while the block walks on)
+    {
+        const float ninf = -INFINITY;
+        const float4 f4 = make_float4(ninf, ninf, ninf, ninf);
+        const int per_row = (cb_hi - cb_lo) * 8;   // float4 per row
+        for (int i = tid; i < P.bound_rows * per_row; i += FR_THREADS) {
+            const int row = i / per_row, x = i - row * per_row;
+            *reinterpret_cast<float4*>(P.pf_bound + (size_t)row * (size_t)P.ncols + ((size_t)cbs + cb_lo) * 32 + (size_t)x * 4) = f4;
+        }
+    }
 
     for (int wlo = cb_lo * 32; wlo < cb_hi * 32; wlo += FR_CAPW) {
         const int whi = min(cb_hi * 32, wlo + FR_CAPW);
@@ -340,46 +386,71 @@ __global__ __launch_bounds__(FR_THREADS) void front_kernel(FrontParams P) {
         // ---- walk B: the columns of this bucket's slots, in the fixed order (wave range, step, rank, lane) ----
         int c0 = base0, c1 = base1;
         const bool write_sc = part == 0 && wlo == 0;
-        for (int qs = q0w; qs < q1w; qs += 64 * U) {
-            FrIds<NB> ids;
-            ids.load(P.bucket_order, nb, qs, lane, q1w);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        if constexpr (NB > 0) {
+            for (int qs = q0w; qs < q1w; qs += 64 * U) {
+                FrChunk<NBC, U> C;
+                C.load(P.bucket_order, qs, lane, q1w);
+                C.sizes(nbr, L);
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int q = qs + 64 * u + lane;
-                if (qs + 64 * u >= q1w) break;
+                for (int u = 0; u < U; ++u) {
+                    const int q = qs + 64 * u + lane;
+                    bool big = false;
+#pragma unroll
+                    for (int r = 0; r < NBC; ++r) {
+                        const int br = C.id[u][r], rows = C.rows[u][r];
+                        const bool other = use_primary && big;
+                        const bool mine = rows > 0 && br == b;
+                        const unsigned long long bal0 = __ballot(mine && !other), bal1 = __ballot(mine && other);
+                        if (mine) {
+                            const int cpos = other ? n0 + c1 + (int)__popcll(bal1 & lt) : c0 + (int)__popcll(bal0 & lt);
+                            if (write_sc) P.slot_col[(size_t)q * NBC + r] = cbs * 32 + cpos;
+                            if (cpos >= wlo && cpos < whi) colq[cpos - wlo] = q;
+                        }
+                        c0 += (int)__popcll(bal0);
+                        c1 += (int)__popcll(bal1);
+                        big = big || rows >= 64;
+                    }
+                }
+            }
+        } else {
+            for (int qs = q0w; qs < q1w; qs += 64) {
+                const int q = qs + lane;
+                const bool live = q < q1w;
                 bool big = false;
-#pragma unroll RUNR
                 for (int r = 0; r < nb; ++r) {
-                    const int br = ids.get(P.bucket_order, nb, q, q1w, u, r);
+                    const int br = live ? P.bucket_order[(size_t)q * nb + r] : -1;
                     const bool inr = br >= 0 && br < L;
                     const int rows = inr ? nbr[br] : 0;
                     const bool other = use_primary && big;
                     const bool mine = rows > 0 && br == b;
                     const unsigned long long bal0 = __ballot(mine && !other), bal1 = __ballot(mine && other);
                     if (mine) {
-                        const unsigned long long lt = (1ull << lane) - 1ull;
                         const int cpos = other ? n0 + c1 + (int)__popcll(bal1 & lt) : c0 + (int)__popcll(bal0 & lt);
                         if (write_sc) P.slot_col[(size_t)q * nb + r] = cbs * 32 + cpos;
                         if (cpos >= wlo && cpos < whi) colq[cpos - wlo] = q;
                     }
                     c0 += (int)__popcll(bal0);
                     c1 += (int)__popcll(bal1);
-                    big = big || (inr && rows >= 64);
+                    big = big || rows >= 64;
                 }
             }
         }
         __syncthreads();
         FR_DBG(3);
         const int nchunk = (P.d + 7) >> 3;
+        const bool vec = (P.d & 7) == 0;
         for (int cbi = wlo / 32; cbi * 32 < whi; ++cbi) {
             const int* colq32 = colq + (cbi * 32 - wlo);
             const size_t cbg = (size_t)cbs + (size_t)cbi;
-            if (nchunk <= 8) fr_pack_colblock<8, 1>(P, colq32, b, cbg, stage, tid);
-            else if (nchunk <= 16) fr_pack_colblock<16, 1>(P, colq32, b, cbg, stage, tid);
-            else if (nchunk <= 32) fr_pack_colblock<32, 1>(P, colq32, b, cbg, stage, tid);
-            else if (nchunk <= 64) fr_pack_colblock<64, 1>(P, colq32, b, cbg, stage, tid);
-            else if (nchunk <= 128) fr_pack_colblock<64, 2>(P, colq32, b, cbg, stage, tid);
-            else fr_pack_colblock<64, 4>(P, colq32, b, cbg, stage, tid);
+#define FR_PACK(GSV, CPV) { if (vec) fr_pack_colblock<GSV, CPV, true>(P, colq32, b, cbg, stage, tid); else fr_pack_colblock<GSV, CPV, false>(P, colq32, b, cbg, stage, tid); }
+            if (nchunk <= 8) FR_PACK(8, 1)
+            else if (nchunk <= 16) FR_PACK(16, 1)
+            else if (nchunk <= 32) FR_PACK(32, 1)
+            else if (nchunk <= 64) FR_PACK(64, 1)
+            else if (nchunk <= 128) FR_PACK(64, 2)
+            else FR_PACK(64, 4)
+#undef FR_PACK
             if (cbi == wlo / 32) FR_DBG(4);
         }
         __syncthreads();

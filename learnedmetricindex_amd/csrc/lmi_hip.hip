@@ -8,6 +8,7 @@
 #include "lmi_mlp_fused.h"
 #include "lmi_rescore.h"
 #include "lmi_front.h"
+#include "lmi_tail.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -184,6 +185,7 @@ struct lmi_index {
     double wall_khz = 100000.0;
     DevBuf fr_dbg;                // LMI_FR_DEBUG=1: front_kernel's phase stamps (lmi_debug_peek "fr_dbg")
     int fr_parts = 0;             // LMI_FR_PARTS=n pins front_kernel's parts per bucket (developer aid)
+    bool use_tail = true;         // tail_kernel (lmi_tail.h): selection + re-rank + rank merge in one wave per query (LMI_TAIL=0: the five launches of round 4)
     bool use_front = false;       // front_kernel (lmi_front.h) instead of the eight preparation launches (LMI_FRONT=0 in the environment: off)
 };
 
@@ -252,6 +254,7 @@ extern "C" LMI_API int lmi_create(int device, lmi_index** out) {
     if (const char* e = getenv("LMI_PF_PRIMARY")) h->pf_primary = e[0] && e[0] != '0';
     if (const char* e = getenv("LMI_PS_WIDE")) h->ps_force_wide = e[0] == '1' ? 1 : e[0] == '0' ? 0 : -1;
     if (const char* e = getenv("LMI_FRONT")) h->use_front = !(e[0] == '0');
+    if (const char* e = getenv("LMI_TAIL")) h->use_tail = !(e[0] == '0');
     if (const char* e = getenv("LMI_FR_PARTS")) h->fr_parts = atoi(e);
     if (const char* e = getenv("LMI_FR_DEBUG")) { if (e[0] == '1') { CHK(h->fr_dbg.reserve(256)); HIPCHK(hipMemset(h->fr_dbg.p, 0, 256)); } }
     {
@@ -281,6 +284,11 @@ extern "C" LMI_API int lmi_create(int device, lmi_index** out) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+#define LMI_TL_ATTR(GV) \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<GV>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_big_kernel<GV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    LMI_TL_ATTR(1) LMI_TL_ATTR(2) LMI_TL_ATTR(3) LMI_TL_ATTR(4)
+#undef LMI_TL_ATTR
     *out = h;
     return 0;
 }
@@ -1075,6 +1083,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     // partial-list bound (exact mode only; the prefilter path writes rank lists, not chunk partials): a row of
     // bucket_order is caller data and may repeat a bucket, so a query owns at most nb x the largest chunk count
     const bool fast = h->prefilter && h->have16;
+    bool use_tail = false;   // (set where the prefilter path picks its tail)
     int max_nch = 0;
     for (int b = 0; b < L; ++b) max_nch = std::max(max_nch, h->h_nch[b]);
     const long long part_lists = fast ? 1 : std::max<long long>(1, (long long)nb * max_nch * nq);
@@ -1242,10 +1251,10 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
             FrontParams A;
             A.bucket_order = d_order;
             A.nq = nq; A.nb = nb; A.L = L;
-            // parts per bucket: enough blocks to fill the chip twice when the buckets that hold rows here are few (a sharded rank: 15)
+            // parts per bucket: the buckets that hold rows here (a sharded rank: 15 of 120) spread over the CUs, one round of blocks
             int owned = 0;
             for (int b = 0; b < L; ++b) owned += h->h_nb_rows[b] > 0;
-            A.parts = std::max(1, std::min(FR_MAX_PARTS, cdiv(2 * h->num_cus, std::max(1, owned))));
+            A.parts = std::max(1, std::min(FR_MAX_PARTS, (h->num_cus - 1) / std::max(1, owned)));   // (one round of blocks: a block per CU)
             A.R = R;
             A.Z = Z;
             A.q = d_qs;
@@ -1405,8 +1414,38 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         Q.ts = h->ts_set;
         Q.p2_end = p2_end_cell;
         if (Q.ts) { (void)tsp(h, ST_TAIL); (void)tsp(h, ST_P2END); (void)tsp(h, ST_FB); }
+        Q.merge_pending = nullptr; Q.m_kout = 0; Q.m_out_d = nullptr; Q.m_out_id = nullptr; Q.m_out_key = nullptr;
+        // the fused tail (lmi_tail.h): a wave per query selects, re-ranks and merges -- n_buckets <= 4 (one wave holds the query's slots)
+        use_tail = rescore_is_streamed(h) && h->use_tail && nb <= 4 && RC_WAVES * tail_wave_lds(h->dp, nb, true) <= 64 * 1024;
 #ifndef LMI_ABL_NOEMIT  // timing-only ablation builds emit nothing: no re-rank, no fallback
-        if (rescore_is_streamed(h)) {
+        if (use_tail) {
+            const int G = nb, groups = nq;
+            CHK(h->surv_row.reserve((size_t)nslots * RC_KEEP * 4));
+            const int sub_cap = cdiv(groups, RC_SUB);
+            SelectOut O;
+            O.surv_row = h->surv_row.as<unsigned>();
+            O.G = G;
+            O.grp_flag = nullptr;
+            O.active = h->rs_active.as<int>();
+            O.sub_cap = sub_cap;
+            O.big = O.active + RC_SUB + RC_SUB * sub_cap;
+            TailParams T;
+            T.nq = nq; T.kout = kout;
+            T.out_d = d_dists; T.out_id = d_ids; T.out_key = d_keys;
+            T.pending = h->rs_flag.as<int>();   // [groups = nq]
+            Q.merge_pending = T.pending; Q.m_kout = kout; Q.m_out_d = d_dists; Q.m_out_id = d_ids; Q.m_out_key = d_keys;
+            if (Q.ts) (void)tsp(h, ST_END);
+            const int lds_s = RC_WAVES * tail_wave_lds(h->dp, G, true);
+            int wb = RC_WAVES;
+            while (wb > 1 && wb * tail_wave_lds(h->dp, G, false) > 160 * 1024 - 512) wb >>= 1;
+            const int lds_b = wb * tail_wave_lds(h->dp, G, false);
+            const int blocks = cdiv(nq, RC_WAVES), blocks_b = std::min(cdiv(nq, wb), h->num_cus);
+#define LMI_TL_LAUNCH(GV) { tail_kernel<GV><<<blocks, 64 * RC_WAVES, lds_s, h->stream>>>(Q, O, T); \
+                            tail_big_kernel<GV><<<blocks_b, 64 * wb, lds_b, h->stream>>>(Q, O, T); }
+            if (G == 4) LMI_TL_LAUNCH(4) else if (G == 3) LMI_TL_LAUNCH(3) else if (G == 2) LMI_TL_LAUNCH(2) else LMI_TL_LAUNCH(1)
+#undef LMI_TL_LAUNCH
+            HIPCHK(hipGetLastError());
+        } else if (rescore_is_streamed(h)) {
             // selection at full occupancy, then the survivors' rows streamed through LDS in coalesced pieces (lmi_rescore.h)
             const int G = rescore_group_size(nb);  // slots of one query per wave
             const int groups = nslots / G;
@@ -1466,11 +1505,12 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     M.rank_id = h->rank_id.as<unsigned>();
     M.ts = h->ts_set;
     M.scan_end = (!fast && h->ts_set) ? scan_end_cell : nullptr;
-    if (M.ts) { (void)tsp(h, ST_MERGE); (void)tsp(h, ST_END); }
+    if (M.ts && !use_tail) { (void)tsp(h, ST_MERGE); (void)tsp(h, ST_END); }
     M.out_d = d_dists;
     M.out_id = d_ids;
     M.out_key = d_keys;
-    if (M.skip_a && nb <= 16) merge_ranks_kernel<<<cdiv(nq, 64), 64, 0, h->stream>>>(M);  // rank lists exist: a thread per query
+    if (use_tail) { /* merged by tail_kernel / tail_big_kernel / fallback_kernel */ }
+    else if (M.skip_a && nb <= 16) merge_ranks_kernel<<<cdiv(nq, 64), 64, 0, h->stream>>>(M);  // rank lists exist: a thread per query
     else merge_kernel<<<nq, 64, 0, h->stream>>>(M);
     HIPCHK(hipGetLastError());
     CHK(record(h, 4));
@@ -1803,8 +1843,9 @@ static void read_stamp_set(const lmi_index* h, const unsigned long long* v, unsi
         span(ST_P1, ST_P2, &ms[LMI_T_PF_SAMPLE]);
         span(ST_P2, ST_P2END, &ms[LMI_T_PF_EMIT]);
         span(ST_P2END, ST_FB, &ms[LMI_T_RESCORE]);
-        span(ST_FB, ST_MERGE, &ms[LMI_T_FALLBACK]);
-        span(ST_P1, ST_MERGE, &ms[LMI_T_SCAN]);
+        const int after = have(ST_MERGE) ? ST_MERGE : ST_END;   // (the fused tail merges in its own kernels: no merge launch)
+        span(ST_FB, after, &ms[LMI_T_FALLBACK]);
+        span(ST_P1, after, &ms[LMI_T_SCAN]);
     } else {
         span(ST_SCAN0, ST_SCAN1, &ms[LMI_T_SCAN]);
     }
@@ -1891,6 +1932,30 @@ extern "C" LMI_API int lmi_copy_out(lmi_index* h, void* dst, const void* src, in
     CHK(set_dev(h));
     const int blocks = (int)std::min<long long>(h->num_cus * 2, cdiv(cdiv(bytes, 16), 256));
     copy_bytes_kernel<<<std::max(1, blocks), 256, 0, h->stream>>>(static_cast<const unsigned char*>(src), static_cast<unsigned char*>(dst), bytes);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" LMI_API int lmi_copy_out_many(lmi_index* h, int n, void* const* dst, const void* const* src, const int64_t* bytes) {
+    if (!h) return fail("lmi_copy_out_many: NULL handle");
+    if (n < 0 || n > 4 || (n > 0 && (!dst || !src || !bytes))) return fail("lmi_copy_out_many: bad arguments (1..4 ranges)");
+    CopyRanges C;
+    long long most = 0;
+    int used = 0;
+    for (int i = 0; i < n; ++i) {
+        if (bytes[i] < 0 || (bytes[i] > 0 && (!dst[i] || !src[i]))) return fail("lmi_copy_out_many: bad range %d", i);
+        if ((reinterpret_cast<uintptr_t>(dst[i]) | reinterpret_cast<uintptr_t>(src[i])) & 15) return fail("lmi_copy_out_many: pointers must be 16-byte aligned");
+        if (bytes[i] == 0) continue;
+        C.src[used] = static_cast<const unsigned char*>(src[i]);
+        C.dst[used] = static_cast<unsigned char*>(dst[i]);
+        C.bytes[used] = bytes[i];
+        most = std::max<long long>(most, bytes[i]);
+        ++used;
+    }
+    if (used == 0) return 0;
+    CHK(set_dev(h));
+    const int bx = (int)std::max<long long>(1, std::min<long long>(h->num_cus, cdiv(cdiv(most, 16), 256)));
+    copy_ranges_kernel<<<dim3(bx, used), 256, 0, h->stream>>>(C);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -153,6 +153,19 @@ __global__ void copy_bytes_kernel(const unsigned char* __restrict__ src, unsigne
     if (t < bytes) dst[t] = src[t];
 }
 
+// up to 4 ranges in one launch: blockIdx.y picks the range (lmi_copy_out_many)
+struct CopyRanges { const unsigned char* src[4]; unsigned char* dst[4]; long long bytes[4]; };
+__global__ void copy_ranges_kernel(CopyRanges C) {
+    const unsigned char* __restrict__ src = C.src[blockIdx.y];
+    unsigned char* __restrict__ dst = C.dst[blockIdx.y];
+    const long long bytes = C.bytes[blockIdx.y], n16 = bytes >> 4;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride)
+        reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+    const long long t = (n16 << 4) + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < bytes) dst[t] = src[t];
+}
+
 // ------------------------------------------------------------------------------------------------
 // MLP layer:  Y^T = W . X^T + b  (ReLU unless last).   model.py:45-49, 97-99, 232
 //   Wf   [n_rb][KG][64]  weights, rows = output features (padded with zero rows)

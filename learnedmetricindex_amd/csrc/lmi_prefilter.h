@@ -417,6 +417,12 @@ struct RescoreParams {
     const unsigned char* redo_col;   // [columns] nullable: columns emitted again by the redo launch
     unsigned long long* ts;               // nullable: the call's stamp set (lmi_kernels.h)
     const unsigned long long* p2_end;     // pass 2's end cell: the selection kernel copies it to ST_P2END
+    // the fused tail (lmi_tail.h; all null / 0 on the five-launch route): fallback_kernel merges a query once its last flagged slot is re-scored
+    int* merge_pending;                   // [nq] flagged slots of the query not yet re-scored (tail_kernel writes it for every query)
+    int m_kout;
+    float* m_out_d;                       // [nq][kout]
+    unsigned* m_out_id;
+    unsigned* m_out_key;                  // nullable
 };
 // the first workgroup of the selection launch: its own start + pass 2's end (known now: the stream ran pass 2 to completion)
 __device__ __forceinline__ void select_stamps(const RescoreParams& P) {
@@ -729,6 +735,28 @@ __global__ void prefilter_stats_kernel(const int* __restrict__ nkeep, const int*
     if ((threadIdx.x & 63) == 0) { atomicAdd(out, a); atomicAdd(out + 1, b); }
 }
 
+// N = G * KPB entries (distance, id), entry e = rank (e / KPB), position (e % KPB): lane e's output position is the number of
+// entries in front of it by (distance, e) -- every list is sorted by distance, so this is the heads-cursor merge of
+// merge_ranks_kernel (ties: the lower rank, then the earlier position).  raw (lmi_knn_ip): larger first.
+template <int G>
+__device__ __forceinline__ void merge_entries(float dv, unsigned iv, int lane, int raw, int kout, size_t q, float* out_d, unsigned* out_id,
+                                              unsigned* out_key) {
+    constexpr int N = G * KPB;
+    int pos = 0;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        const float od = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dv), e));
+        const bool front = raw ? od > dv : od < dv;
+        pos += (front || (od == dv && e < lane)) ? 1 : 0;
+    }
+    if (lane < N && pos < kout) {
+        const size_t o = q * (size_t)kout + pos;
+        out_d[o] = dv;
+        out_id[o] = iv;
+        if (out_key) out_key[o] = (unsigned)(lane / KPB) * 16u + (unsigned)(lane % KPB);
+    }
+}
+
 // Exact fallback for overflowed slots: one block per slot, brute force over the whole bucket with the
 // canonical chain on the VALU (slow, rare, always correct).
 __global__ __launch_bounds__(256) void fallback_kernel(RescoreParams P) {
@@ -818,9 +846,35 @@ __global__ __launch_bounds__(256) void fallback_kernel(RescoreParams P) {
     }
     write_rank_list(lane, my_s, my_r, n_b, rb0, P.raw, P.ids_slab, P.rank_d + (size_t)p * KPB,
                     P.rank_id + (size_t)p * KPB, P.qn2, p / P.nb);
+    if (P.merge_pending) {
+        // The fused tail (lmi_tail.h) left this query unmerged: whoever re-scores its LAST flagged slot merges it from the rank lists in
+        // global memory (the others': written by earlier launches or by other workgroups of this one -- agent-scope release before the
+        // counter, acquire behind it; the waits after the fences are asm: ROCm 7.2 can drop the fence's own).
+        const int q = p / P.nb;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int old = 0;
+        if (lane == 0) old = atomicSub(&P.merge_pending[q], 1);
+        old = __shfl(old, 0);
+        if (old == 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int n = P.nb * KPB;   // nb <= 4
+            const float dv = lane < n ? P.rank_d[(size_t)q * n + lane] : 0.0f;
+            const unsigned iv = lane < n ? P.rank_id[(size_t)q * n + lane] : 0u;
+            switch (P.nb) {
+                case 1: merge_entries<1>(dv, iv, lane, P.raw, P.m_kout, (size_t)q, P.m_out_d, P.m_out_id, P.m_out_key); break;
+                case 2: merge_entries<2>(dv, iv, lane, P.raw, P.m_kout, (size_t)q, P.m_out_d, P.m_out_id, P.m_out_key); break;
+                case 3: merge_entries<3>(dv, iv, lane, P.raw, P.m_kout, (size_t)q, P.m_out_d, P.m_out_id, P.m_out_key); break;
+                default: merge_entries<4>(dv, iv, lane, P.raw, P.m_kout, (size_t)q, P.m_out_d, P.m_out_id, P.m_out_key); break;
+            }
+        }
+    }
     }
     __syncthreads();  // fs / fr are reused by the block's next slot
     }
+    if (P.ts && P.merge_pending) ts_last(P.ts + ST_END);   // the fused tail: this is the search's last launch
 }
 
 }  // namespace lmi

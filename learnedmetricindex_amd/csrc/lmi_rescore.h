@@ -194,44 +194,44 @@ __host__ inline int rc_waves_for(int d, int G) {
 }
 static_assert(RC_CHUNK % 32 == 0 && (RC_ROWS == 32 || RC_ROWS == 64) && RC_DEPTH >= 2 && RC_DEPTH <= 4, "rescore_kernel shapes");
 
+// LDS of one re-rank wave: chunk ring | q [d] | rows [KEEPW] | scores [KEEPW]
 template <int G, bool SMALL>
-__device__ __forceinline__ void rescore_group(const RescoreParams& P, const SelectOut& O, unsigned char* rc_smem, int wv, int lane, int p0) {
-    constexpr int RINGB = SMALL ? RC_SMALL_RING : RC_DEPTH * RC_BUF;
-    constexpr int KEEPW = SMALL ? 32 : G * RC_KEEP;
+struct RcWave {
+    static constexpr int RINGB = SMALL ? RC_SMALL_RING : RC_DEPTH * RC_BUF;
+    static constexpr int KEEPW = SMALL ? 32 : G * RC_KEEP;
+    unsigned char* mine;
+    float* qs;
+    unsigned* krow;
+    float* ksc;
+    __device__ __forceinline__ RcWave(unsigned char* base, int d) : mine(base), qs(reinterpret_cast<float*>(base + RINGB)),
+        krow(reinterpret_cast<unsigned*>(base + RINGB + d * 4)), ksc(reinterpret_cast<float*>(base + RINGB + d * 4) + KEEPW) {}
+    // the wave's query -> LDS (rows of pitch dp: the tail behind d is zero)
+    __device__ __forceinline__ void stage_query(const RescoreParams& P, int q, int lane) const {
+        const int d = P.dp;
+        const float* qg = P.q + (size_t)q * P.d;
+        if (P.d == d) {
+            for (int k = lane * 4; k < d; k += 256) *reinterpret_cast<float4*>(qs + k) = *reinterpret_cast<const float4*>(qg + k);
+        } else {   // d not a multiple of 4: the query's rows are not 16-byte aligned, its tail is padded with zeros here
+            for (int k = lane; k < d; k += 64) qs[k] = k < P.d ? qg[k] : 0.0f;
+        }
+    }
+};
+
+// The re-rank proper, shared by rescore_kernel and tail_kernel (lmi_tail.h): the wave's survivors krow[0, off[G]) (absolute slab rows, slot after
+// slot) and its query are in LDS; rows streamed, canonical chains, then every slot's rank list.  LCOPY: the lists also go to the
+// wave's LDS copy rl_d / rl_i [G][KPB] (the caller merges them in the wave).  colv / fbv: the slots' columns and fallback flags.
+template <int G, bool SMALL, bool LCOPY>
+__device__ __forceinline__ void rescore_core(const RescoreParams& P, const RcWave<G, SMALL>& W, const int (&off)[G + 1], int p0, int lane,
+                                             const int (&colv)[G], const int (&fbv)[G], float* rl_d, unsigned* rl_i) {
+    constexpr int RINGB = RcWave<G, SMALL>::RINGB;
     const int d = P.dp;   // the rows' pitch: the chain runs over the zero padding too (+0 * +0 added to the sum changes nothing)
-    unsigned char* mine = rc_smem + (size_t)wv * rc_wave_lds(d, G, SMALL);
-    float* qs = reinterpret_cast<float*>(mine + RINGB);
-    unsigned* krow = reinterpret_cast<unsigned*>(mine + RINGB + d * 4);
-    float* ksc = reinterpret_cast<float*>(krow + KEEPW);
+    unsigned char* mine = W.mine;
+    unsigned* krow = W.krow;
+    float* ksc = W.ksc;
     const float FMAXV = 3.402823466e+38f;
-    // the survivor lists of the wave's slots, slot after slot, and the wave's query (G divides nb: one query per wave)
-    int off[G + 1];
-    off[0] = 0;
-    int colv[G], fbv[G], nkv[G];   // all 3 G loads in flight together (a short-circuit `&&` chained them: three round trips per slot)
-#pragma unroll
-    for (int sl = 0; sl < G; ++sl) { colv[sl] = P.slot_col[p0 + sl]; fbv[sl] = P.fallback[p0 + sl]; nkv[sl] = P.nkeep[p0 + sl]; }
-#pragma unroll
-    for (int sl = 0; sl < G; ++sl) off[sl + 1] = off[sl] + ((colv[sl] >= 0 && !fbv[sl]) ? nkv[sl] : 0);   // wave-uniform
-    if (SMALL && off[G] > RC_SMALL_ROWS) {   // more than this launch holds: the second launch takes the group
-        if (lane == 0) O.big[1 + atomicAdd(&O.big[0], 1)] = p0 / G;
-        return;
-    }
-#pragma unroll
-    for (int sl = 0; sl < G; ++sl) {
-        const int nk = off[sl + 1] - off[sl];
-        for (int i = lane; i < nk; i += 64) krow[off[sl] + i] = O.surv_row[(size_t)(p0 + sl) * RC_KEEP + i];
-    }
     const int total = off[G];
-    const float* qg = P.q + (size_t)(p0 / P.nb) * P.d;
-    if (P.d == d) {
-        for (int k = lane * 4; k < d; k += 256) *reinterpret_cast<float4*>(qs + k) = *reinterpret_cast<const float4*>(qg + k);
-    } else {   // d not a multiple of 4: the query's rows are not 16-byte aligned, its tail is padded with zeros here
-        for (int k = lane; k < d; k += 64) qs[k] = k < P.d ? qg[k] : 0.0f;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
     const int nchunks = (d + RC_CHUNK - 1) / RC_CHUNK;
-    const unsigned qaddr = (unsigned)reinterpret_cast<uintptr_t>(qs);
+    const unsigned qaddr = (unsigned)reinterpret_cast<uintptr_t>(W.qs);
     // One batch of <= RC_ROWS chains.  NP = LDS-DMA pieces per chunk that hold rows of THIS batch (a wave re-scores ~13 rows since
     // the bound is per query: 2 pieces instead of the 9 that cover 64 rows -- issuing the unused ones was most of the kernel's time).
     auto run_batch = [&](auto np_c, int base) {
@@ -343,9 +343,12 @@ __device__ __forceinline__ void rescore_group(const RescoreParams& P, const Sele
             for (int j = lo; j < hi; ++j) pos += better(ksc[j], krow[j], sc, row) ? 1 : 0;
             if (pos < KPB) {
                 const int p = p0 + sl;
-                P.rank_d[(size_t)p * KPB + pos] = P.raw ? sc : sim_to_dist(sc, P.qn2, p / P.nb);
+                const float dv = P.raw ? sc : sim_to_dist(sc, P.qn2, p / P.nb);
                 // (krow holds absolute slab rows; the raw form -- lmi_knn_ip -- returns the row inside its bucket)
-                P.rank_id[(size_t)p * KPB + pos] = P.raw ? row - (unsigned)P.rb_start[P.bucket_order[p]] * 32u : P.ids_slab[row];
+                const unsigned iv = P.raw ? row - (unsigned)P.rb_start[P.bucket_order[p]] * 32u : P.ids_slab[row];
+                P.rank_d[(size_t)p * KPB + pos] = dv;
+                P.rank_id[(size_t)p * KPB + pos] = iv;
+                if (LCOPY) { rl_d[sl * KPB + pos] = dv; rl_i[sl * KPB + pos] = iv; }
             }
         }
     }
@@ -354,16 +357,46 @@ __device__ __forceinline__ void rescore_group(const RescoreParams& P, const Sele
 #pragma unroll
         for (int sl = 0; sl < G; ++sl) {
             const int p = p0 + sl;
-            if (P.slot_col[p] < 0 || P.fallback[p]) continue;  // written by select_kernel / recomputed by fallback_kernel
+            if (colv[sl] < 0 || fbv[sl]) continue;  // written by the selection / recomputed by fallback_kernel
             const int b = P.bucket_order[p];
             const int rb0 = P.rb_start[b], n_b = P.nb_rows[b];
             const int nreal = min(min(off[sl + 1] - off[sl], KPB), n_b);
             if (lane >= nreal) {
-                P.rank_d[(size_t)p * KPB + lane] = P.raw ? -FMAXV : pad_dist(P.qn2);
-                P.rank_id[(size_t)p * KPB + lane] = P.raw ? NOROW : P.ids_slab[(size_t)rb0 * 32 + (n_b - 1)];
+                const float dv = P.raw ? -FMAXV : pad_dist(P.qn2);
+                const unsigned iv = P.raw ? NOROW : P.ids_slab[(size_t)rb0 * 32 + (n_b - 1)];
+                P.rank_d[(size_t)p * KPB + lane] = dv;
+                P.rank_id[(size_t)p * KPB + lane] = iv;
+                if (LCOPY) { rl_d[sl * KPB + lane] = dv; rl_i[sl * KPB + lane] = iv; }
             }
         }
     }
+}
+
+template <int G, bool SMALL>
+__device__ __forceinline__ void rescore_group(const RescoreParams& P, const SelectOut& O, unsigned char* rc_smem, int wv, int lane, int p0) {
+    const int d = P.dp;
+    const RcWave<G, SMALL> W(rc_smem + (size_t)wv * rc_wave_lds(d, G, SMALL), d);
+    // the survivor lists of the wave's slots, slot after slot, and the wave's query (G divides nb: one query per wave)
+    int off[G + 1];
+    off[0] = 0;
+    int colv[G], fbv[G], nkv[G];   // all 3 G loads in flight together (a short-circuit `&&` chained them: three round trips per slot)
+#pragma unroll
+    for (int sl = 0; sl < G; ++sl) { colv[sl] = P.slot_col[p0 + sl]; fbv[sl] = P.fallback[p0 + sl]; nkv[sl] = P.nkeep[p0 + sl]; }
+#pragma unroll
+    for (int sl = 0; sl < G; ++sl) off[sl + 1] = off[sl] + ((colv[sl] >= 0 && !fbv[sl]) ? nkv[sl] : 0);   // wave-uniform
+    if (SMALL && off[G] > RC_SMALL_ROWS) {   // more than this launch holds: the second launch takes the group
+        if (lane == 0) O.big[1 + atomicAdd(&O.big[0], 1)] = p0 / G;
+        return;
+    }
+#pragma unroll
+    for (int sl = 0; sl < G; ++sl) {
+        const int nk = off[sl + 1] - off[sl];
+        for (int i = lane; i < nk; i += 64) W.krow[off[sl] + i] = O.surv_row[(size_t)(p0 + sl) * RC_KEEP + i];
+    }
+    W.stage_query(P, p0 / P.nb, lane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    rescore_core<G, SMALL, false>(P, W, off, p0, lane, colv, fbv, nullptr, nullptr);
 }
 
 template <int G, bool SMALL>

@@ -139,10 +139,8 @@ class HostPipeline:
                 d_t, i_t, bo_t = s["d_d"], s["i_d"], s["bo_d"]
             else:
                 d_t, i_t, bo_t = self.search_fn(s["qn_d"], s["qn_d"] if self.same else s["qs_d"])
-            index.copy_out(s["d_h"], d_t)          # a kernel storing to the pinned buffers (see the module docstring)
-            index.copy_out(s["i_h"], i_t)
-            if self.want_bo:
-                index.copy_out(s["bo_h"], bo_t)
+            # ONE kernel storing to the pinned buffers (see the module docstring; three launches were 25 us of a 0.6-ms search)
+            index.copy_out_many([(s["d_h"], d_t), (s["i_h"], i_t)] + ([(s["bo_h"], bo_t)] if self.want_bo else []))
             s["ev_out"].record(s_run)
         self.t += 1
         return self.t - 1

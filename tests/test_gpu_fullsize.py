@@ -1,5 +1,6 @@
 """GPU (`-m gpu`): BASELINE.json's configurations at their full sizes, against the CPU oracle.
 
+* C1 (configs[0]): 100 000 x 768, 120 leaves, top-4, 1 000 queries: every query oracle-checked.
 * C2 (configs[1], the headline): 10M x 768, 120 buckets, top-4, 10 000 queries on one MI355X, placement and routing
   through the MLP kernels.  The fp16-prefilter mode and the all-f32 mode (two independently built indexes) must
   return bit-identical ids and distances for the WHOLE batch, and 256 sampled queries are re-computed by the oracle
@@ -136,6 +137,12 @@ def test_c2_full_size_modes_and_oracle(oracle):
     routing through the MLP kernels like C5's test, no longer by centre similarity)."""
     _need_hbm(150)
     _mlp_routed_case(oracle, d=D, L=120, NB=4, n=10_000_000, nq=10_000, tag="C2")
+
+
+def test_c1_full_size_every_query_against_the_oracle(oracle):
+    """C1 (configs[0], the reference's own CPU-runnable case): 100 000 x 768, 120 leaves, top-4, 1 000 queries, MLP-routed end to
+    end -- both scan modes identical for the whole batch and EVERY query re-computed by the oracle (bucket order, ids, distance bits)."""
+    _mlp_routed_case(oracle, d=D, L=120, NB=4, n=100_000, nq=1_000, n_oracle=1_000, tag="C1")
 
 
 def test_hard_generator_prefilter_equals_exact_and_oracle(oracle):
