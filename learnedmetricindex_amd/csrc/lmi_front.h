@@ -1,47 +1,53 @@
-// lmi_front.h -- the per-batch preparation of the prefilter path as ONE launch (gfx950).
+// lmi_front.h -- the per-batch preparation of the prefilter path as TWO lean launches (gfx950).
 //
 // Until round 4 a batch was prepared by eight launches on the critical path in front of pass 1 (fill_ranges, route_count,
-// route_scan, route_group on a side stream, route_fill, query_norm, pack_queries16, slot_bound: ~60 us of runs and gaps at C5,
-// ~100 us at C2, each kernel waiting for a grid-wide result of the one before).  front_kernel does all of it without any
-// communication between workgroups -- nothing to publish, poll, re-initialise or order, and nothing a graph replay could freeze:
+// route_scan, route_group on a side stream, route_fill, query_norm, pack_queries16, slot_bound: 57 us at the C5 shape, 79 us at C2's,
+// each kernel waiting for a grid-wide result of the one before).  Now:
 //
-//   * EVERY block walks the whole bucket_order array (40 000 slots = 160 KB, from L2) and builds the full routing histogram in
-//     LDS: m[b] / m0[b] (queries routed to bucket b; of them primary, RouteArrays) for every bucket.  From it a block knows the
-//     col-block prefix cb_start of its own bucket -- the one grid-wide quantity routing needs -- by itself.
-//   * block 0 writes the global copies (m, m0, cb_start, statistics), initialises the small per-call arrays (work-queue heads,
-//     candidate counters, flags ..: the old fill_ranges list), marks unvisited slots and builds the XCD-affine work queues
-//     (route_group_body: the same code as route_group_kernel, fed from the LDS histogram).
-//   * block 1 + b * parts + j owns part j of bucket b's columns.  A second walk gives every slot routed to b its column: positions
-//     are handed out in a FIXED order (wave's query range, 64-query step, rank, lane) from ballots, so every part of the bucket
-//     (and any other launch) derives the same columns without talking to anyone; primary slots first, the others behind them.
-//     Part 0 writes slot_col[].  Then, per owned col-block of 32 columns: each column's query row is read ONCE, coalesced (a group
-//     of 8..64 lanes per row): max |q| -> the query's power-of-two scale -> fp16 image -> ||q'||, ||q^ - q'|| -> eps' of the slot
-//     (the arithmetic of query_norm_kernel / slot_bound_kernel, lmi_prefilter.h) -- and the fp16 values go into an LDS image of
-//     the col-block's fragments, written out as whole 1-KiB fragments.  The owner also sets its columns' pass-1 lists to -inf
-//     (the one large fill of the old path: 1 KiB per column).
+//   route_kernel<NB>   a block per bucket, no communication between blocks.  The block walks the whole bucket_order array (40 000
+//                      slots = 160 KB, from L2; a wave's ids of several 64-query steps loaded at once) and counts the slots routed to
+//                      ITS bucket, primary and other (RouteArrays) -- ballots, no atomics; publishes the count as a tagged 8-byte granule
+//                      and sums the granules of the LOWER buckets (they are dispatched first and wait for nobody) into the bucket's
+//                      first col-block -- the one grid-wide quantity routing needs, without a launch boundary, a contended atomic or
+//                      anything to reset; walks again and hands every slot of the bucket its column in a FIXED order (wave's query
+//                      range, step, rank, lane): slot_col[], colmap[]; writes m[b], m0[b], cb_start[b].
+//   pack_kernel<..>    a block per col-block (32 columns): each column's query row is read ONCE, coalesced (8..64 lanes per row, all of
+//                      a wave's rows in flight together): max |q| -> the query's power-of-two scale -> fp16 image -> ||q'||, ||q^ - q'||
+//                      -> eps' of the slot (the arithmetic of query_norm_kernel / slot_bound_kernel, lmi_prefilter.h); the fp16 values go
+//                      through an LDS image of the col-block's fragments and leave as whole 1-KiB fragments; the block also sets its
+//                      columns' pass-1 lists to -inf.  Block 0 builds the XCD-affine work queues + statistics from m / m0
+//                      (route_group_body: route_group_kernel's code); all blocks share the small per-call fills (the old fill_ranges
+//                      list) and the marking of unvisited slots.
 //
-// The redundant walks cost each block ~5 us (LDS atomics); the launch replaces ~35 us of dependent launches at every shape and
-// the query rows are read once per slot instead of twice.  Used when the fan-out and the batch are moderate (FR_MAX_L buckets,
-// FR_MAX_SLOTS slots); beyond, scan_enqueue keeps the separate kernels.  Both routes give every slot a private column of its
-// bucket -- which column is irrelevant to the results (tests/test_gpu_front.py runs both).
+// A first form (one launch: every block built the batch's full routing histogram in LDS to learn its bucket's col-block prefix, then
+// packed its bucket's columns) was correct but slower than the eight launches: 40 000 LDS atomics per block (~10 us), one fat kernel
+// with 145 spilled registers, one block per CU (profiles/r05_front_experiments.txt).  Used when the fan-out and the batch are moderate
+// (FR_MAX_L buckets, FR_MAX_SLOTS slots, FR_MAX_D dims); beyond, scan_enqueue keeps the separate kernels.  Both routes give every slot a
+// private column of its bucket -- which column is irrelevant to the results (tests/test_gpu_front.py runs both).
 #pragma once
 #include "lmi_prefilter.h"
 
 namespace lmi {
 
-constexpr int FR_THREADS = 1024, FR_WAVES = FR_THREADS / 64;
-constexpr int FR_MAX_L = 2048;           // buckets: the histogram (8 L bytes), the bucket sizes (4 L) and the queue sort live in LDS
-constexpr int FR_MAX_SLOTS = 1 << 17;    // slots per batch: every block walks all of them twice
-constexpr int FR_CAPW = 1024;            // columns of a part handled per positioning walk (a larger part walks again per window)
+constexpr int FR_THREADS = 1024, FR_WAVES = FR_THREADS / 64;   // route_kernel / the queue block
+constexpr int FR_MAX_L = 512;            // buckets: one 1 024-thread block per bucket, each walking the whole batch and reading the lower buckets' counts
+                                         // (2 000 leaves: the separate kernels' 115 us are faster)
+constexpr int FR_MAX_SLOTS = 1 << 17;    // slots per batch: every block of route_kernel walks all of them twice
 constexpr int FR_SLICE_G = 48;           // k16-groups of a col-block staged at a time (48 KiB: d <= 768 in one slice)
-constexpr int FR_MAX_PARTS = 8;
+constexpr int FP_THREADS = 512, FP_WAVES = FP_THREADS / 64;    // pack_kernel
+constexpr int FR_MAX_D = 64 * 4 * 8;     // a row's chunks fit a wave's registers (4 per lane)
 static_assert(FR_SLICE_G % 2 == 0, "the 16 x 32 fragment shape pairs k16-groups");
 
 struct FrontParams {
     const int* bucket_order;   // [nq][nb]
-    int nq, nb, L, parts;
+    int nq, nb, L;
+    unsigned epoch;            // this call's tag of the granules below (per handle, never 0: stale entries of earlier calls never match)
+    unsigned long long* gran;  // [L + 1] {epoch << 32 | value}: [b] = queries routed to bucket b, published by its block with ONE 8-byte store
+                               // (the data is the flag); [L] = the batch's col-blocks, published by the last bucket's block
+    int* cb_bucket;            // [col-blocks] the bucket a col-block belongs to
+    int* colmap;               // [columns] the query of a column (-1: idle)
     RouteArrays R;             // out: m, m0, cb_start, stats, grp_* (item_base / part_base: exact mode only, not written)
-    FillRanges Z;              // the small per-call arrays block 0 initialises
+    FillRanges Z;              // the small per-call arrays (pack_kernel's blocks share them)
     const float* q;            // [nq][d] row-major queries of the scan
     int d, KG16, f16x16;
     float* qnorm; float* qdelta; float* qscale;   // [nq] (every block that packs a query's slot writes the same values)
@@ -52,23 +58,22 @@ struct FrontParams {
     float* pf_bound;           // [bound_rows][ncols] pass-1 lists
     long long ncols;
     int bound_rows;
-    unsigned long long* ts;    // nullable: device time stamp of the launch's start (lmi_set_timing 2)
-    unsigned long long* dbg;   // nullable (LMI_FR_DEBUG=1 in the environment): clock stamps of block 0 [0, 8), the first bucket block
-                               // with queries [8, 16) and the last one [16, 24) at their phase boundaries (tools/front_phases.py)
+    unsigned long long* ts;    // nullable: device time stamp of the first launch's start (lmi_set_timing 2)
+    unsigned long long* dbg;   // nullable (LMI_FR_DEBUG=1 in the environment): clock stamps (tools/front_phases.py)
 };
-#define FR_DBG(slot) do { if (P.dbg && tid == 0 && dbg_base >= 0) P.dbg[dbg_base + (slot)] = wall_clock64(); } while (0)
+#define FR_DBG(base, slot) do { if (P.dbg && threadIdx.x == 0 && (base) >= 0) P.dbg[(base) + (slot)] = wall_clock64(); } while (0)
 
-__host__ __device__ inline size_t fr_stage_bytes(int L, int KG16) {
-    const size_t pack = (size_t)(KG16 < FR_SLICE_G ? KG16 : FR_SLICE_G) * 1024, grp = route_group_lds(L) + 16;
+// dynamic LDS of route_kernel: the bucket sizes; of pack_kernel's col-block blocks: the fragment image; of its queue block: sizes + sort
+__host__ __device__ inline int fr_lpad(int L) { return (L + 3) & ~3; }
+__host__ __device__ inline size_t fr_route_lds(int L) { return (size_t)fr_lpad(L) * 4; }
+__host__ __device__ inline size_t fr_pack_lds(int L, int KG16) {
+    const size_t pack = (size_t)(KG16 < FR_SLICE_G ? KG16 : FR_SLICE_G) * 1024, grp = (size_t)fr_lpad(L) * 12 + route_group_lds(L) + 16;
     return pack > grp ? pack : grp;
 }
-// dynamic LDS: bucket sizes [L] | histogram [2][L] | 64 words | column window [FR_CAPW] | staging
-__host__ __device__ inline int fr_lpad(int L) { return (L + 3) & ~3; }   // (the staging area stays 16-byte aligned)
-__host__ __device__ inline size_t fr_lds_bytes(int L, int KG16) { return (size_t)fr_lpad(L) * 12 + 256 + (size_t)FR_CAPW * 4 + fr_stage_bytes(L, KG16); }
 
 // 8 consecutive floats of a query row starting at k0, zeros past the row's end or when !ok -- BRANCH-FREE (clamped addresses + selects): a
-// wave's loads of several rows / chunks then issue back to back and are waited for once (with a branch per load hipcc waits per load:
-// four serial round trips per col-block, round 5's first form: 8-12 us per col-block instead of ~3).  VEC: d % 8 == 0 (16-byte loads).
+// wave's loads of several rows / chunks then issue back to back and are waited for once (with a branch per load hipcc waits per load).
+// VEC: d % 8 == 0 (16-byte loads).
 template <bool VEC>
 __device__ __forceinline__ void fr_load8(const float* __restrict__ row, int d, int k0, bool ok, float (&v)[8]) {
     if constexpr (VEC) {
@@ -83,108 +88,6 @@ __device__ __forceinline__ void fr_load8(const float* __restrict__ row, int d, i
             const float x = row[in ? k0 + j : 0];
             v[j] = in ? x : 0.0f;
         }
-    }
-}
-
-// One col-block (32 columns) of a bucket: rows -> scale, norms, eps', fp16 fragments (through the LDS image `stage`), pass-1 lists.
-// GS lanes per query row (a power of two >= the row's 8-float chunks, capped at the wave); CP chunks per lane and row: a row is read
-// ONCE, all of a wave's loads in flight together (a wave's NCOL rows x CP chunks), and stays in registers through the k-slices.
-template <int GS, int CP, bool VEC>
-__device__ __forceinline__ void fr_pack_colblock(const FrontParams& P, const int* __restrict__ colq32, int b, size_t cb_global,
-                                                 char* stage, int tid) {
-    const int lane = tid & 63, w = tid >> 6;
-    const int d = P.d, KG16 = P.KG16;
-    const int nchunk_row = (d + 7) >> 3;               // chunks that hold data; the slab pads K to 16 KG16
-    constexpr int CPW = 64 / GS;                       // rows per wave instruction
-    constexpr int NCOL = (32 + FR_WAVES * CPW - 1) / (FR_WAVES * CPW);   // rows per wave and col-block (2 at GS = 64, else 1 or none)
-    const int gl = lane % GS, sub = lane / GS;
-    const float xn = __uint_as_float(P.bnorm[b]), dx = __uint_as_float(P.bdelta[b]);
-    const float guard = norm_guard(d);
-    float v[NCOL][CP][8];
-    int qi[NCOL];
-#pragma unroll
-    for (int c = 0; c < NCOL; ++c) {
-        const int cc = w * CPW + sub + c * FR_WAVES * CPW;
-        qi[c] = cc < 32 ? colq32[cc] : -1;
-    }
-#pragma unroll
-    for (int c = 0; c < NCOL; ++c) {
-        const float* row = P.q + (size_t)(qi[c] < 0 ? 0 : qi[c]) * d;
-#pragma unroll
-        for (int i = 0; i < CP; ++i) {
-            const int j = gl + GS * i;
-            fr_load8<VEC>(row, d, 8 * j, qi[c] >= 0 && j < nchunk_row, v[c][i]);
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < NCOL; ++c) {
-        const int cc = w * CPW + sub + c * FR_WAVES * CPW;
-        float mx = 0.0f;
-#pragma unroll
-        for (int i = 0; i < CP; ++i)
-#pragma unroll
-            for (int t = 0; t < 8; ++t) mx = fmaxf(mx, fabsf(v[c][i][t]));
-#pragma unroll
-        for (int o = GS / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        const float s = scale_of_max(__float_as_uint(mx));   // (an idle column: 1)
-        float acc = 0.0f, dl = 0.0f;
-#pragma unroll
-        for (int i = 0; i < CP; ++i)
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const float vs = v[c][i][t] * s;
-                const float e = (float)(_Float16)vs - vs;
-                acc += vs * vs;
-                dl += e * e;
-                v[c][i][t] = vs;
-            }
-#pragma unroll
-        for (int o = GS / 2; o > 0; o >>= 1) { acc += __shfl_xor(acc, o); dl += __shfl_xor(dl, o); }
-        if (gl == 0 && cc < 32) {
-            const size_t col = cb_global * 32 + cc;
-            if (qi[c] >= 0) {
-                const float qn = sqrtf(acc) * guard, dq = sqrtf(dl) * guard;
-                P.qnorm[qi[c]] = qn; P.qdelta[qi[c]] = dq; P.qscale[qi[c]] = s;
-                // slot_bound_kernel's bound (lmi_prefilter.h): Cauchy-Schwarz on the measured norms + the two binary32 summations
-                const float e = dq * (xn + dx) + qn * dx + 4.0f * (float)(KG16 * 16) * 5.96046448e-8f * (qn + dq) * (xn + dx);
-                P.eps2[col] = 2.0f * e * 1.001f;
-            } else {
-                P.eps2[col] = 0.0f;   // idle column of the bucket's last col-block (never tested: its threshold is +inf)
-            }
-        }
-    }
-    for (int g0 = 0; g0 < KG16; g0 += FR_SLICE_G) {
-        const int gs = min(FR_SLICE_G, KG16 - g0);
-#pragma unroll
-        for (int c = 0; c < NCOL; ++c) {
-            const int cc = w * CPW + sub + c * FR_WAVES * CPW;
-#pragma unroll
-            for (int i = 0; i < CP; ++i) {
-                const int j = gl + GS * i;
-                const int g = j >> 1, hh = j & 1;
-                if (cc < 32 && g >= g0 && g < g0 + gs) {
-                    half8 h;
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) h[t] = (_Float16)v[c][i][t];
-                    int slot;
-                    if (P.f16x16) {   // convert16_kernel's K > 128 shape; the LDS image is XOR-swizzled in 16-slot rows: a row's 64 chunks would
-                                      // otherwise all fall into ONE 16-byte bank group (a 64-way conflict per ds_write_b128)
-                        slot = (2 * (g >> 1) + (cc >> 4) - g0) * 64 + 16 * (2 * (g & 1) + hh) + (cc & 15);
-                        slot ^= ((slot >> 4) & 3) | (((slot >> 7) & 3) << 2);
-                    } else {
-                        slot = (g - g0) * 64 + hh * 32 + cc;
-                    }
-                    *reinterpret_cast<uint4*>(stage + (size_t)slot * 16) = *reinterpret_cast<uint4*>(&h);
-                }
-            }
-        }
-        __syncthreads();
-        uint4* dst = P.qfrag16 + (cb_global * (size_t)KG16 + (size_t)g0) * 64;
-        for (int i = tid; i < gs * 64; i += FR_THREADS) {
-            const int src = P.f16x16 ? (i ^ (((i >> 4) & 3) | (((i >> 7) & 3) << 2))) : i;
-            dst[i] = *reinterpret_cast<const uint4*>(stage + (size_t)src * 16);
-        }
-        __syncthreads();
     }
 }
 
@@ -221,243 +124,299 @@ struct FrChunk {
     }
 };
 
-template <int NB>
-__global__ __launch_bounds__(FR_THREADS) void front_kernel(FrontParams P) {
-    extern __shared__ __attribute__((aligned(16))) char fr_smem[];
-    const int L = P.L, nq = P.nq;
-    const int nb = NB > 0 ? NB : P.nb;
-    int* nbr = reinterpret_cast<int*>(fr_smem);
-    int* cnt = nbr + fr_lpad(L);    // [0, L): primary slots per bucket, [L, 2L): the others
-    int* misc = cnt + 2 * fr_lpad(L);   // 64 words
-    int* colq = misc + 64;          // [FR_CAPW] query of the window's columns (-1: idle)
-    char* stage = reinterpret_cast<char*>(colq + FR_CAPW);
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bid = blockIdx.x;
-    const int b = bid == 0 ? -1 : (bid - 1) / P.parts, part = bid == 0 ? 0 : (bid - 1) % P.parts;
-    if (bid == 0 && tid == 0 && P.ts) *P.ts = wall_clock64();
-    // ---- the small per-call arrays (the old fill_ranges_kernel list): every block its share, before anything can make it leave ----
-    for (int r = 0; r < P.Z.count; ++r)
-        for (long long i = (long long)bid * FR_THREADS + tid; i < P.Z.n[r]; i += (long long)gridDim.x * FR_THREADS) P.Z.p[r][i] = P.Z.v[r];
-    if (b >= 0 && P.R.nb_rows[b] == 0) return;   // an empty (or unowned) bucket: nothing is routed to it
-    const int dbg_base = bid == 0 ? 0 : bid == 1 ? 8 : bid == (int)gridDim.x - 1 ? 16 : -1;
-    FR_DBG(0);
-    for (int i = tid; i < L; i += FR_THREADS) { nbr[i] = P.R.nb_rows[i]; cnt[i] = 0; cnt[L + i] = 0; }
-    __syncthreads();
-    // ---- walk A: the routing histogram of the whole batch; this bucket's slots per wave range ----
-    const int Qw = (((nq + FR_WAVES - 1) / FR_WAVES) + 63) / 64 * 64;
-    const int q0w = w * Qw, q1w = min(nq, q0w + Qw);
+// One walk over the whole batch's bucket_order by the block of bucket b, in the FIXED order (wave's query range, 64-query step, rank,
+// lane).  COUNT: the wave's primary / other slots of the bucket -> own0 / own1.  !COUNT: every slot of the bucket gets its column
+// (c0 / c1: the wave's first primary / other position; n0: the bucket's primary slots) -> slot_col[], colmap[].
+template <int NB, bool COUNT>
+__device__ __forceinline__ void fr_walk(const FrontParams& P, const int* nbr, int b, int nbv, int lane, int q0w, int q1w, int& c0, int& c1, int n0, int col_base) {
+    const int L = P.L;
     const bool use_primary = P.R.primary_nb > 0;
-    constexpr int NBC = NB > 0 ? NB : 1;
-    constexpr int U = NB > 0 ? (NB <= 4 ? 4 : NB <= 8 ? 2 : 1) : 1;
-    int own0 = 0, own1 = 0;   // wave-uniform
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    auto slot = [&](int q, int r, int br, int rows, bool big) __attribute__((always_inline)) {
+        const bool other = use_primary && big;
+        const bool mine = rows > 0 && br == b;
+        const unsigned long long bal0 = __ballot(mine && !other), bal1 = __ballot(mine && other);
+        if (!COUNT && mine) {
+            const int cpos = other ? n0 + c1 + (int)__popcll(bal1 & lt) : c0 + (int)__popcll(bal0 & lt);
+            P.slot_col[(size_t)q * nbv + r] = col_base + cpos;
+            P.colmap[col_base + cpos] = q;
+        }
+        c0 += (int)__popcll(bal0);
+        c1 += (int)__popcll(bal1);
+    };
     if constexpr (NB > 0) {
+        constexpr int U = NB <= 4 ? 4 : NB <= 8 ? 2 : 1;
         for (int qs = q0w; qs < q1w; qs += 64 * U) {
-            FrChunk<NBC, U> C;
+            FrChunk<NB, U> C;
             C.load(P.bucket_order, qs, lane, q1w);
             C.sizes(nbr, L);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int q = qs + 64 * u + lane;
                 bool big = false;   // a lower rank of this query holds a bucket of >= 64 rows: the slot is not primary (route_count_kernel)
 #pragma unroll
-                for (int r = 0; r < NBC; ++r) {
-                    const int br = C.id[u][r], rows = C.rows[u][r];
-                    const bool valid = rows > 0;
-                    const bool other = use_primary && big;
-                    if (valid) atomicAdd(&cnt[other ? L + br : br], 1);
-                    const bool mine = valid && br == b;
-                    own0 += (int)__popcll(__ballot(mine && !other));
-                    own1 += (int)__popcll(__ballot(mine && other));
-                    if (bid == 0 && q < q1w && !valid) P.slot_col[(size_t)q * NBC + r] = -1;   // unvisited (LearnedIndex.py:340-341)
-                    big = big || rows >= 64;
+                for (int r = 0; r < NB; ++r) {
+                    slot(qs + 64 * u + lane, r, C.id[u][r], C.rows[u][r], big);
+                    big = big || C.rows[u][r] >= 64;
                 }
             }
         }
     } else {   // any rank count: one step at a time
         for (int qs = q0w; qs < q1w; qs += 64) {
             const int q = qs + lane;
-            const bool live = q < q1w;
             bool big = false;
-            for (int r = 0; r < nb; ++r) {
-                const int br = live ? P.bucket_order[(size_t)q * nb + r] : -1;
+            for (int r = 0; r < nbv; ++r) {
+                const int br = q < q1w ? P.bucket_order[(size_t)q * nbv + r] : -1;
                 const bool inr = br >= 0 && br < L;
                 const int rows = inr ? nbr[br] : 0;
-                const bool valid = rows > 0;
-                const bool other = use_primary && big;
-                if (valid) atomicAdd(&cnt[other ? L + br : br], 1);
-                const bool mine = valid && br == b;
-                own0 += (int)__popcll(__ballot(mine && !other));
-                own1 += (int)__popcll(__ballot(mine && other));
-                if (bid == 0 && live && !valid) P.slot_col[(size_t)q * nb + r] = -1;
+                slot(q, r, br, rows, big);
                 big = big || rows >= 64;
             }
         }
     }
-    if (lane == 0) { misc[w] = own0; misc[FR_WAVES + w] = own1; }
-    __syncthreads();
-    FR_DBG(1);
+}
 
-    if (bid == 0) {
-        // ---- global copies of the histogram, the col-block prefix and the statistics ----
-        static_assert(FR_MAX_L <= 2 * FR_THREADS, "two buckets per thread in the prefix");
-        const int b0 = 2 * tid, b1 = 2 * tid + 1;
-        const int m_0 = b0 < L ? cnt[b0] + cnt[L + b0] : 0, m_1 = b1 < L ? cnt[b1] + cnt[L + b1] : 0;
-        const int c_0 = (m_0 + 31) >> 5, c_1 = (m_1 + 31) >> 5;
-        long long pairs = 0, items = 0;
-        if (b0 < L) { pairs += (long long)m_0 * nbr[b0]; items += (long long)query_tiles(m_0, P.R.tile_cb) * P.R.nch[b0]; }
-        if (b1 < L) { pairs += (long long)m_1 * nbr[b1]; items += (long long)query_tiles(m_1, P.R.tile_cb) * P.R.nch[b1]; }
-        int incl = c_0 + c_1;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int up = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += up;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { pairs += __shfl_xor(pairs, o); items += __shfl_xor(items, o); }
-        long long* red = reinterpret_cast<long long*>(stage);   // [2][FR_WAVES]; the staging area is free until the queue sort
-        if (lane == 63) misc[32 + w] = incl;
-        if (lane == 0) { red[w] = pairs; red[FR_WAVES + w] = items; }
-        __syncthreads();
-        int wbase = 0, total = 0;
-        for (int i = 0; i < FR_WAVES; ++i) { const int vv = misc[32 + i]; if (i < w) wbase += vv; total += vv; }
-        const int ex = wbase + incl - (c_0 + c_1);
-        if (b0 < L) { P.R.m[b0] = m_0; P.R.m0[b0] = cnt[b0]; P.R.cb_start[b0] = ex; }
-        if (b1 < L) { P.R.m[b1] = m_1; P.R.m0[b1] = cnt[b1]; P.R.cb_start[b1] = ex + c_0; }
+// ---- launch 1: a block per bucket -- which slots go to the bucket, in which columns --------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(FR_THREADS) void route_kernel(FrontParams P) {
+    extern __shared__ __attribute__((aligned(16))) char fr_smem[];
+    __shared__ int misc[2 * FR_WAVES + 2];
+    const int L = P.L, nq = P.nq, nb = NB > 0 ? NB : P.nb;
+    int* nbr = reinterpret_cast<int*>(fr_smem);
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x;
+    if (b == 0 && tid == 0 && P.ts) *P.ts = wall_clock64();
+    const int dbg_base = b == 0 ? 8 : b == (int)gridDim.x - 1 ? 16 : -1;
+    FR_DBG(dbg_base, 0);
+    if (P.R.nb_rows[b] == 0 && b != L - 1) {   // an empty (or unowned) bucket: nothing is routed to it (the last bucket's block stays: it publishes the total)
         if (tid == 0) {
-            long long ps = 0, is = 0;
-            for (int i = 0; i < FR_WAVES; ++i) { ps += red[i]; is += red[FR_WAVES + i]; }
-            P.R.cb_start[L] = total;
-            P.R.stats[0] = ps;
-            P.R.stats[1] = is;
+            P.R.m[b] = 0; P.R.m0[b] = 0; P.R.cb_start[b] = 0;
+            __hip_atomic_store(P.gran + b, (unsigned long long)P.epoch << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        __syncthreads();
-        FR_DBG(2);
-        FR_DBG(3);
-        // ---- the XCD-affine work queues from the LDS histogram: cnt[0, L) = m0 as it stands, cnt[L, 2L) <- m ----
-        for (int i = tid; i < L; i += FR_THREADS) cnt[L + i] += cnt[i];
-        __syncthreads();
-        RouteArrays R2 = P.R;
-        R2.m = cnt + L;
-        R2.m0 = cnt;
-        R2.nb_rows = nbr;
-        route_group_body<false>(L, R2, stage, &misc[63]);
-        FR_DBG(4);
         return;
     }
-
-    // ---- a bucket's block: totals, this wave's bases, the bucket's first col-block ----
+    for (int i = tid; i < L; i += FR_THREADS) nbr[i] = P.R.nb_rows[i];
+    __syncthreads();
+    const int Qw = (((nq + FR_WAVES - 1) / FR_WAVES) + 63) / 64 * 64;
+    const int q0w = w * Qw, q1w = min(nq, q0w + Qw);
+    int own0 = 0, own1 = 0;   // wave-uniform
+    fr_walk<NB, true>(P, nbr, b, nb, lane, q0w, q1w, own0, own1, 0, 0);
+    if (lane == 0) { misc[w] = own0; misc[FR_WAVES + w] = own1; }
+    __syncthreads();
+    FR_DBG(dbg_base, 1);
     int base0 = 0, base1 = 0, n0 = 0, n1 = 0;
     for (int i = 0; i < FR_WAVES; ++i) {
         const int a = misc[i], c = misc[FR_WAVES + i];
         if (i < w) { base0 += a; base1 += c; }
         n0 += a; n1 += c;
     }
-    const int m_b = n0 + n1;
-    if (m_b == 0) return;   // no query visits this bucket
-    const int ncb = (m_b + 31) >> 5;
-    const int per = (ncb + P.parts - 1) / P.parts;
-    const int cb_lo = part * per, cb_hi = min(ncb, cb_lo + per);
-    if (cb_lo >= cb_hi) return;
-    int part_sum = 0;
-    for (int i = tid; i < b; i += FR_THREADS) part_sum += (cnt[i] + cnt[L + i] + 31) >> 5;
+    const int m_b = n0 + n1, ncb = (m_b + 31) >> 5;
+    // The bucket's first col-block = the col-blocks of the buckets before it: every block PUBLISHES its count as a tagged 8-byte granule
+    // (relaxed agent-scope store: no fence, nothing to reset -- a stale tag never matches) and one wave sweeps the granules of the LOWER
+    // buckets until all carry this call's tag.  Lower-indexed blocks are dispatched first and depend on nobody, so the sweep ends; it
+    // is bounded anyway (a give-up leaves a wrong layout and a word in stats[3] for the host to see).
+    if (tid == 0) {
+        __hip_atomic_store(P.gran + b, ((unsigned long long)P.epoch << 32) | (unsigned long long)(unsigned)m_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        P.R.m[b] = m_b;
+        P.R.m0[b] = n0;
+    }
+    if (w == 0) {
+        int sum = 0;
+        for (int i0 = 0; i0 < b; i0 += 64) {
+            const int i = i0 + lane;
+            unsigned long long x = (unsigned long long)P.epoch << 32;
+            for (unsigned spins = 0;; ++spins) {
+                if (i < b) x = __hip_atomic_load(P.gran + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all((unsigned)(x >> 32) == P.epoch)) break;
+                if (spins > (1u << 22)) { if (lane == 0) P.R.stats[3] = -1; break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            sum += ((int)(unsigned)x + 31) >> 5;   // (lanes past b carry 0)
+        }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) part_sum += __shfl_xor(part_sum, o);
-    if (lane == 0) misc[32 + w] = part_sum;
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if (lane == 0) {
+            misc[2 * FR_WAVES] = sum;
+            P.R.cb_start[b] = sum;
+            if (b == L - 1) __hip_atomic_store(P.gran + L, ((unsigned long long)P.epoch << 32) | (unsigned long long)(unsigned)(sum + ncb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     __syncthreads();
-    int cbs = 0;
-    for (int i = 0; i < FR_WAVES; ++i) cbs += misc[32 + i];
-    FR_DBG(2);
-    // the pass-1 lists of the part's col-blocks: bound_rows rows of -inf, (cb_hi - cb_lo) * 128 contiguous bytes each (stores only:
-    // they leave while the block walks on)
+    if (m_b == 0) return;
+    const int cbs = misc[2 * FR_WAVES];
+    for (int i = tid; i < ncb; i += FR_THREADS) P.cb_bucket[cbs + i] = b;
+    for (int i = m_b + tid; i < ncb * 32; i += FR_THREADS) P.colmap[cbs * 32 + i] = -1;   // the idle columns of the last col-block
+    int c0 = base0, c1 = base1;
+    fr_walk<NB, false>(P, nbr, b, nb, lane, q0w, q1w, c0, c1, n0, cbs * 32);
+    FR_DBG(dbg_base, 2);
+}
+
+// ---- launch 2: a block per col-block -- rows -> scale, norms, eps', fp16 fragments, pass-1 lists; block 0: the work queues -------
+// GS lanes per query row (a power of two >= the row's 8-float chunks, capped at the wave); CP chunks per lane and row: a row is read
+// ONCE (a wave's rows of a batch x CP chunks in flight together) and stays in registers through the k-slices.
+template <int GS, int CP, bool VEC>
+__global__ __launch_bounds__(FP_THREADS) void pack_kernel(FrontParams P) {
+    extern __shared__ __attribute__((aligned(16))) char fp_smem[];
+    __shared__ int active_s;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = blockIdx.x;
+    // ---- the small per-call arrays (the old fill_ranges_kernel list): every block its share, before anything can make it leave ----
+    for (int r = 0; r < P.Z.count; ++r)
+        for (long long i = (long long)bid * FP_THREADS + tid; i < P.Z.n[r]; i += (long long)gridDim.x * FP_THREADS) P.Z.p[r][i] = P.Z.v[r];
+    // ---- unvisited slots (LearnedIndex.py:340-341: a bucket id outside the index, or a bucket without rows here): every block its share
+    //      (one block walking all 40 000 slots, two dependent loads each, was 40 us: the launch's long pole) ----
+    for (long long p = (long long)bid * FP_THREADS + tid; p < (long long)P.nq * P.nb; p += (long long)gridDim.x * FP_THREADS) {
+        const int br = P.bucket_order[p];
+        if (!(br >= 0 && br < P.L && P.R.nb_rows[br] > 0)) P.slot_col[p] = -1;
+    }
+    if (bid == 0) {
+        // ---- the XCD-affine work queues + statistics from route_kernel's m / m0 (1 024-thread body: two passes of this block) ----
+        FR_DBG(0, 0);
+        const int L = P.L;
+        int* nbr = reinterpret_cast<int*>(fp_smem);
+        int* m_s = nbr + fr_lpad(L);
+        int* m0_s = m_s + fr_lpad(L);
+        char* sort_s = reinterpret_cast<char*>(m0_s + fr_lpad(L));
+        long long pairs = 0, items = 0;
+        for (int i = tid; i < L; i += FP_THREADS) {
+            const int rows = P.R.nb_rows[i], m = P.R.m[i];
+            nbr[i] = rows; m_s[i] = m; m0_s[i] = P.R.m0[i];
+            pairs += (long long)m * rows;
+            items += (long long)query_tiles(m, P.R.tile_cb) * P.R.nch[i];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { pairs += __shfl_xor(pairs, o); items += __shfl_xor(items, o); }
+        __shared__ long long red[2][FP_WAVES];
+        if (lane == 0) { red[0][w] = pairs; red[1][w] = items; }
+        __syncthreads();
+        if (tid == 0) {
+            long long ps = 0, is = 0;
+            for (int i = 0; i < FP_WAVES; ++i) { ps += red[0][i]; is += red[1][i]; }
+            P.R.stats[0] = ps;
+            P.R.stats[1] = is;
+        }
+        FR_DBG(0, 1);
+        RouteArrays R2 = P.R;
+        R2.m = m_s;
+        R2.m0 = m0_s;
+        R2.nb_rows = nbr;
+        route_group_body<false, FP_THREADS>(L, R2, sort_s, &active_s);
+        FR_DBG(0, 4);
+        return;
+    }
+    const unsigned long long alloc = P.gran[P.L];   // (route_kernel is complete: the launch boundary orders it)
+    const int n_cb = (unsigned)(alloc >> 32) == P.epoch ? (int)(unsigned)alloc : 0;
+    const int cb = bid - 1;
+    if (cb >= n_cb) return;
+    char* stage = fp_smem;
+    const int b = P.cb_bucket[cb];
+    const int d = P.d, KG16 = P.KG16;
+    const int nchunk_row = (d + 7) >> 3;               // chunks that hold data; the slab pads K to 16 KG16
+    constexpr int CPW = 64 / GS;                       // rows per wave instruction
+    constexpr int NCOL = (32 + FP_WAVES * CPW - 1) / (FP_WAVES * CPW);   // rows per wave and col-block (4 at GS = 64)
+    const int gl = lane % GS, sub = lane / GS;
+    const float xn = __uint_as_float(P.bnorm[b]), dx = __uint_as_float(P.bdelta[b]);
+    const float guard = norm_guard(d);
+    // The pass-1 lists of the live columns -> -inf: [bound_rows] rows of n_cb * 32 floats.  Block cb fills the cb-th 32-KiB piece of that
+    // (row-major) region -- CONTIGUOUS memory, not its own columns' 128-byte pieces of every row (48 MB in 128-byte pieces 200 KB apart
+    // ran at 1.4 TB/s: most of the launch).  Stores only: they leave while the rows are on their way.
     {
         const float ninf = -INFINITY;
         const float4 f4 = make_float4(ninf, ninf, ninf, ninf);
-        const int per_row = (cb_hi - cb_lo) * 8;   // float4 per row
-        for (int i = tid; i < P.bound_rows * per_row; i += FR_THREADS) {
-            const int row = i / per_row, x = i - row * per_row;
-            *reinterpret_cast<float4*>(P.pf_bound + (size_t)row * (size_t)P.ncols + ((size_t)cbs + cb_lo) * 32 + (size_t)x * 4) = f4;
+        const long long per_row = (long long)n_cb * 8;   // float4 per row
+        const long long total = (long long)P.bound_rows * per_row;
+        const long long lo = (long long)cb * P.bound_rows * 8, hi = min(total, lo + (long long)P.bound_rows * 8);
+        for (long long i = lo + tid; i < hi; i += FP_THREADS) {
+            const long long row = i / per_row, x = i - row * per_row;
+            *reinterpret_cast<float4*>(P.pf_bound + (size_t)row * (size_t)P.ncols + (size_t)x * 4) = f4;
         }
     }
-
-    for (int wlo = cb_lo * 32; wlo < cb_hi * 32; wlo += FR_CAPW) {
-        const int whi = min(cb_hi * 32, wlo + FR_CAPW);
-        for (int i = tid; i < FR_CAPW; i += FR_THREADS) colq[i] = -1;
-        __syncthreads();
-        // ---- walk B: the columns of this bucket's slots, in the fixed order (wave range, step, rank, lane) ----
-        int c0 = base0, c1 = base1;
-        const bool write_sc = part == 0 && wlo == 0;
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        if constexpr (NB > 0) {
-            for (int qs = q0w; qs < q1w; qs += 64 * U) {
-                FrChunk<NBC, U> C;
-                C.load(P.bucket_order, qs, lane, q1w);
-                C.sizes(nbr, L);
+    float v[NCOL][CP][8];
+    int qi[NCOL];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int q = qs + 64 * u + lane;
-                    bool big = false;
+    for (int c = 0; c < NCOL; ++c) {
+        const int cc = w * CPW + sub + c * FP_WAVES * CPW;
+        qi[c] = cc < 32 ? P.colmap[(size_t)cb * 32 + cc] : -1;
+    }
 #pragma unroll
-                    for (int r = 0; r < NBC; ++r) {
-                        const int br = C.id[u][r], rows = C.rows[u][r];
-                        const bool other = use_primary && big;
-                        const bool mine = rows > 0 && br == b;
-                        const unsigned long long bal0 = __ballot(mine && !other), bal1 = __ballot(mine && other);
-                        if (mine) {
-                            const int cpos = other ? n0 + c1 + (int)__popcll(bal1 & lt) : c0 + (int)__popcll(bal0 & lt);
-                            if (write_sc) P.slot_col[(size_t)q * NBC + r] = cbs * 32 + cpos;
-                            if (cpos >= wlo && cpos < whi) colq[cpos - wlo] = q;
-                        }
-                        c0 += (int)__popcll(bal0);
-                        c1 += (int)__popcll(bal1);
-                        big = big || rows >= 64;
-                    }
-                }
+    for (int c = 0; c < NCOL; ++c) {
+        const float* row = P.q + (size_t)(qi[c] < 0 ? 0 : qi[c]) * d;
+#pragma unroll
+        for (int i = 0; i < CP; ++i) {
+            const int j = gl + GS * i;
+            fr_load8<VEC>(row, d, 8 * j, qi[c] >= 0 && j < nchunk_row, v[c][i]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) {
+        const int cc = w * CPW + sub + c * FP_WAVES * CPW;
+        float mx = 0.0f;
+#pragma unroll
+        for (int i = 0; i < CP; ++i)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) mx = fmaxf(mx, fabsf(v[c][i][t]));
+#pragma unroll
+        for (int o = GS / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        const float s = scale_of_max(__float_as_uint(mx));   // (an idle column: 1)
+        float acc = 0.0f, dl = 0.0f;
+#pragma unroll
+        for (int i = 0; i < CP; ++i)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float vs = v[c][i][t] * s;
+                const float e = (float)(_Float16)vs - vs;
+                acc += vs * vs;
+                dl += e * e;
+                v[c][i][t] = vs;
             }
-        } else {
-            for (int qs = q0w; qs < q1w; qs += 64) {
-                const int q = qs + lane;
-                const bool live = q < q1w;
-                bool big = false;
-                for (int r = 0; r < nb; ++r) {
-                    const int br = live ? P.bucket_order[(size_t)q * nb + r] : -1;
-                    const bool inr = br >= 0 && br < L;
-                    const int rows = inr ? nbr[br] : 0;
-                    const bool other = use_primary && big;
-                    const bool mine = rows > 0 && br == b;
-                    const unsigned long long bal0 = __ballot(mine && !other), bal1 = __ballot(mine && other);
-                    if (mine) {
-                        const int cpos = other ? n0 + c1 + (int)__popcll(bal1 & lt) : c0 + (int)__popcll(bal0 & lt);
-                        if (write_sc) P.slot_col[(size_t)q * nb + r] = cbs * 32 + cpos;
-                        if (cpos >= wlo && cpos < whi) colq[cpos - wlo] = q;
+#pragma unroll
+        for (int o = GS / 2; o > 0; o >>= 1) { acc += __shfl_xor(acc, o); dl += __shfl_xor(dl, o); }
+        if (gl == 0 && cc < 32) {
+            const size_t col = (size_t)cb * 32 + cc;
+            if (qi[c] >= 0) {
+                const float qn = sqrtf(acc) * guard, dq = sqrtf(dl) * guard;
+                P.qnorm[qi[c]] = qn; P.qdelta[qi[c]] = dq; P.qscale[qi[c]] = s;
+                // slot_bound_kernel's bound (lmi_prefilter.h): Cauchy-Schwarz on the measured norms + the two binary32 summations
+                const float e = dq * (xn + dx) + qn * dx + 4.0f * (float)(KG16 * 16) * 5.96046448e-8f * (qn + dq) * (xn + dx);
+                P.eps2[col] = 2.0f * e * 1.001f;
+            } else {
+                P.eps2[col] = 0.0f;   // idle column of the bucket's last col-block (never tested: its threshold is +inf)
+            }
+        }
+    }
+    for (int g0 = 0; g0 < KG16; g0 += FR_SLICE_G) {
+        const int gs = min(FR_SLICE_G, KG16 - g0);
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c) {
+            const int cc = w * CPW + sub + c * FP_WAVES * CPW;
+#pragma unroll
+            for (int i = 0; i < CP; ++i) {
+                const int j = gl + GS * i;
+                const int g = j >> 1, hh = j & 1;
+                if (cc < 32 && g >= g0 && g < g0 + gs) {
+                    half8 h;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) h[t] = (_Float16)v[c][i][t];
+                    int slot;
+                    if (P.f16x16) {   // convert16_kernel's K > 128 shape; the LDS image is XOR-swizzled in 16-slot rows: a row's 64 chunks would
+                                      // otherwise all fall into ONE 16-byte bank group (a 64-way conflict per ds_write_b128)
+                        slot = (2 * (g >> 1) + (cc >> 4) - g0) * 64 + 16 * (2 * (g & 1) + hh) + (cc & 15);
+                        slot ^= ((slot >> 4) & 3) | (((slot >> 7) & 3) << 2);
+                    } else {
+                        slot = (g - g0) * 64 + hh * 32 + cc;
                     }
-                    c0 += (int)__popcll(bal0);
-                    c1 += (int)__popcll(bal1);
-                    big = big || rows >= 64;
+                    *reinterpret_cast<uint4*>(stage + (size_t)slot * 16) = *reinterpret_cast<uint4*>(&h);
                 }
             }
         }
         __syncthreads();
-        FR_DBG(3);
-        const int nchunk = (P.d + 7) >> 3;
-        const bool vec = (P.d & 7) == 0;
-        for (int cbi = wlo / 32; cbi * 32 < whi; ++cbi) {
-            const int* colq32 = colq + (cbi * 32 - wlo);
-            const size_t cbg = (size_t)cbs + (size_t)cbi;
-#define FR_PACK(GSV, CPV) { if (vec) fr_pack_colblock<GSV, CPV, true>(P, colq32, b, cbg, stage, tid); else fr_pack_colblock<GSV, CPV, false>(P, colq32, b, cbg, stage, tid); }
-            if (nchunk <= 8) FR_PACK(8, 1)
-            else if (nchunk <= 16) FR_PACK(16, 1)
-            else if (nchunk <= 32) FR_PACK(32, 1)
-            else if (nchunk <= 64) FR_PACK(64, 1)
-            else if (nchunk <= 128) FR_PACK(64, 2)
-            else FR_PACK(64, 4)
-#undef FR_PACK
-            if (cbi == wlo / 32) FR_DBG(4);
+        uint4* dst = P.qfrag16 + ((size_t)cb * (size_t)KG16 + (size_t)g0) * 64;
+        for (int i = tid; i < gs * 64; i += FP_THREADS) {
+            const int src = P.f16x16 ? (i ^ (((i >> 4) & 3) | (((i >> 7) & 3) << 2))) : i;
+            dst[i] = *reinterpret_cast<const uint4*>(stage + (size_t)src * 16);
         }
         __syncthreads();
     }
-    FR_DBG(5);
 }
 #undef FR_DBG
-constexpr int FR_MAX_D = 64 * 4 * 8;   // a row's chunks fit a wave's registers (4 per lane)
 
 }  // namespace lmi

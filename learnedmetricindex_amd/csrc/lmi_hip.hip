@@ -183,10 +183,11 @@ struct lmi_index {
     unsigned ts_mask[EV_RING] = {};
     unsigned long long* ts_set = nullptr;
     double wall_khz = 100000.0;
-    DevBuf fr_dbg;                // LMI_FR_DEBUG=1: front_kernel's phase stamps (lmi_debug_peek "fr_dbg")
-    int fr_parts = 0;             // LMI_FR_PARTS=n pins front_kernel's parts per bucket (developer aid)
+    DevBuf fr_dbg;                // LMI_FR_DEBUG=1: route_kernel's / pack_kernel's phase stamps (lmi_debug_peek "fr_dbg")
+    DevBuf cb_alloc, cb_bucket;   // lmi_front.h: the call-tagged granules of route_kernel (zero at allocation) and the col-blocks' buckets
+    unsigned fr_epoch = 0;        // this handle's calls through route_kernel (the granules' tag; never 0)
     bool use_tail = true;         // tail_kernel (lmi_tail.h): selection + re-rank + rank merge in one wave per query (LMI_TAIL=0: the five launches of round 4)
-    bool use_front = false;       // front_kernel (lmi_front.h) instead of the eight preparation launches (LMI_FRONT=0 in the environment: off)
+    bool use_front = true;        // route_kernel + pack_kernel (lmi_front.h) instead of the eight preparation launches (LMI_FRONT=0 in the environment: off)
 };
 
 // which fp16 fragment shape the index and the queries are packed in: 16 x 32 for pass2_kernel, 32 x 16 for the low-dimensional kernels
@@ -255,15 +256,11 @@ extern "C" LMI_API int lmi_create(int device, lmi_index** out) {
     if (const char* e = getenv("LMI_PS_WIDE")) h->ps_force_wide = e[0] == '1' ? 1 : e[0] == '0' ? 0 : -1;
     if (const char* e = getenv("LMI_FRONT")) h->use_front = !(e[0] == '0');
     if (const char* e = getenv("LMI_TAIL")) h->use_tail = !(e[0] == '0');
-    if (const char* e = getenv("LMI_FR_PARTS")) h->fr_parts = atoi(e);
     if (const char* e = getenv("LMI_FR_DEBUG")) { if (e[0] == '1') { CHK(h->fr_dbg.reserve(256)); HIPCHK(hipMemset(h->fr_dbg.p, 0, 256)); } }
     {
         int khz = 0;
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) h->wall_khz = (double)khz;
     }
-#define LMI_FR_ATTR(NBV) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&front_kernel<NBV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fr_lds_bytes(FR_MAX_L, 4 * FR_SLICE_G)));
-    LMI_FR_ATTR(0) LMI_FR_ATTR(1) LMI_FR_ATTR(2) LMI_FR_ATTR(3) LMI_FR_ATTR(4) LMI_FR_ATTR(5) LMI_FR_ATTR(6) LMI_FR_ATTR(8) LMI_FR_ATTR(10) LMI_FR_ATTR(16)
-#undef LMI_FR_ATTR
     // per handle = per device (a process may hold handles on several devices; the attribute is per device)
 #define LMI_PS_ATTR(K) \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pass2_small_kernel<K, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, ps_lds_bytes(K, false))); \
@@ -309,7 +306,7 @@ extern "C" LMI_API int lmi_destroy(lmi_index* h) {
                       &h->act[0], &h->act[1], &h->xfrag, &h->logits, &h->order, &h->q_nav, &h->q_srch, &h->m,
                       &h->cb_start, &h->item_base, &h->part_base, &h->stats, &h->head, &h->slot_local,
                       &h->slot_col, &h->colmap, &h->qfrag, &h->grp, &h->col_thr, &h->slab16, &h->rowmajor, &h->xscale, &h->xmaxbits, &h->bnorm, &h->bdelta, &h->qdelta, &h->qnorm, &h->qscale, &h->qfrag16, &h->eps2, &h->cand_cnt, &h->cand_row, &h->cand_s, &h->fallback, &h->pf_bound, &h->nkeep, &h->redo, &h->part_score, &h->part_row, &h->rank_d,
-                      &h->rank_id, &h->out_d, &h->out_id, &h->out_key, &h->x_log, &h->x_ext, &h->x_off, &h->fb_list, &h->grp_scratch, &h->ts_ring, &h->fr_dbg};
+                      &h->rank_id, &h->out_d, &h->out_id, &h->out_key, &h->x_log, &h->x_ext, &h->x_off, &h->fb_list, &h->grp_scratch, &h->ts_ring, &h->fr_dbg, &h->cb_alloc, &h->cb_bucket};
     for (DevBuf* b : bufs) b->release();
     for (auto& m : h->node_models) { for (auto& b : m.Wf) b.release(); for (auto& b : m.bias) b.release(); }
     DevBuf* nav[] = {&h->d_models, &h->d_child_offset, &h->d_child_model, &h->d_child_bucket, &h->pq_prob, &h->pq_ent, &h->pq_len, &h->surv_row, &h->rs_flag, &h->rs_active, &h->gather_send, &h->gather_recv, &h->aug_rows, &h->q_aug, &h->qn2,
@@ -349,7 +346,7 @@ extern "C" LMI_API int lmi_clone_view(lmi_index* h, lmi_index** out) {
                      &c->surv_row, &c->rs_flag, &c->rs_active, &c->act[0], &c->act[1], &c->xfrag, &c->logits, &c->order, &c->q_nav,
                      &c->q_srch, &c->m, &c->cb_start, &c->item_base, &c->part_base, &c->stats, &c->head, &c->slot_local, &c->slot_col,
                      &c->colmap, &c->qfrag, &c->grp, &c->col_thr, &c->part_score, &c->part_row, &c->rank_d, &c->rank_id, &c->out_d,
-                     &c->out_id, &c->out_key, &c->x_log, &c->x_ext, &c->x_off, &c->fb_list, &c->grp_scratch, &c->ts_ring, &c->fr_dbg};
+                     &c->out_id, &c->out_key, &c->x_log, &c->x_ext, &c->x_off, &c->fb_list, &c->grp_scratch, &c->ts_ring, &c->fr_dbg, &c->cb_alloc, &c->cb_bucket};
     for (DevBuf* b : own) b->forget();
     c->ts_set = nullptr;
     memset(c->ts_mask, 0, sizeof(c->ts_mask));
@@ -1121,6 +1118,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     R.grp_total = R.grp_n + NGRP;
     R.grp_base1 = R.grp_total + NGRP;
     R.grp_total1 = R.grp_base1 + (size_t)NGRP * (L + 1);
+    R.dbg = nullptr;
     const bool v2 = h->prefilter && h->have16;   // the prefilter's kernels: lmi_pass2.h (tiles of up to 12 col-blocks)
     // low-dimensional kernels: the wide form (one 8-wave block per CU, 12-col-block tiles) when the visited buckets receive more
     // queries than the narrow form's tile holds -- decided from the call's shape alone (no device round trip)
@@ -1251,11 +1249,15 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
             FrontParams A;
             A.bucket_order = d_order;
             A.nq = nq; A.nb = nb; A.L = L;
-            // parts per bucket: the buckets that hold rows here (a sharded rank: 15 of 120) spread over the CUs, one round of blocks
-            int owned = 0;
-            for (int b = 0; b < L; ++b) owned += h->h_nb_rows[b] > 0;
-            A.parts = std::max(1, std::min(FR_MAX_PARTS, (h->num_cus - 1) / std::max(1, owned)));   // (one round of blocks: a block per CU)
+            if (!h->cb_alloc.p) { CHK(h->cb_alloc.reserve((size_t)(FR_MAX_L + 1) * 8)); HIPCHK(hipMemsetAsync(h->cb_alloc.p, 0, (size_t)(FR_MAX_L + 1) * 8, h->stream)); }
+            CHK(h->cb_bucket.reserve((size_t)ncb_bound * 4));
+            if (++h->fr_epoch == 0u) h->fr_epoch = 1u;
+            A.epoch = h->fr_epoch;
+            A.gran = h->cb_alloc.as<unsigned long long>();
+            A.cb_bucket = h->cb_bucket.as<int>();
+            A.colmap = h->colmap.as<int>();
             A.R = R;
+            A.R.dbg = h->fr_dbg.as<unsigned long long>();
             A.Z = Z;
             A.q = d_qs;
             A.d = h->d; A.KG16 = h->KG16; A.f16x16 = frag16x16(h);
@@ -1269,15 +1271,28 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
             A.bound_rows = P2_NSL * 16;
             A.ts = tsp(h, ST_FRONT);
             A.dbg = h->fr_dbg.as<unsigned long long>();
-            if (h->fr_parts > 0) A.parts = std::min(FR_MAX_PARTS, h->fr_parts);
-            const int fgrid = 1 + L * A.parts;
-            const size_t flds = fr_lds_bytes(L, h->KG16);
-            switch (nb) {   // the rank count as a compile-time constant: a wave's bucket ids of 8 steps are loaded at once (lmi_front.h, FrIds)
-#define LMI_FR_CASE(NBV) case NBV: front_kernel<NBV><<<fgrid, FR_THREADS, flds, h->stream>>>(A); break;
+            const size_t rlds = fr_route_lds(L);
+            switch (nb) {   // the rank count as a compile-time constant: a wave's bucket ids of several steps are loaded at once (lmi_front.h, FrChunk)
+#define LMI_FR_CASE(NBV) case NBV: route_kernel<NBV><<<L, FR_THREADS, rlds, h->stream>>>(A); break;
                 LMI_FR_CASE(1) LMI_FR_CASE(2) LMI_FR_CASE(3) LMI_FR_CASE(4) LMI_FR_CASE(5) LMI_FR_CASE(6) LMI_FR_CASE(8) LMI_FR_CASE(10) LMI_FR_CASE(16)
 #undef LMI_FR_CASE
-                default: front_kernel<0><<<fgrid, FR_THREADS, flds, h->stream>>>(A); break;
+                default: route_kernel<0><<<L, FR_THREADS, rlds, h->stream>>>(A); break;
             }
+            HIPCHK(hipGetLastError());
+            A.ts = nullptr;
+            const int pgrid = 1 + (int)ncb_bound;
+            const size_t plds = fr_pack_lds(L, h->KG16);
+            const int nchunk = (h->d + 7) / 8;
+            const bool vec = h->d % 8 == 0;
+#define LMI_FP_LAUNCH(GSV, CPV) { if (vec) pack_kernel<GSV, CPV, true><<<pgrid, FP_THREADS, plds, h->stream>>>(A); \
+                                  else pack_kernel<GSV, CPV, false><<<pgrid, FP_THREADS, plds, h->stream>>>(A); }
+            if (nchunk <= 8) LMI_FP_LAUNCH(8, 1)
+            else if (nchunk <= 16) LMI_FP_LAUNCH(16, 1)
+            else if (nchunk <= 32) LMI_FP_LAUNCH(32, 1)
+            else if (nchunk <= 64) LMI_FP_LAUNCH(64, 1)
+            else if (nchunk <= 128) LMI_FP_LAUNCH(64, 2)
+            else LMI_FP_LAUNCH(64, 4)
+#undef LMI_FP_LAUNCH
             HIPCHK(hipGetLastError());
         } else {
         query_norm_kernel<<<cdiv(nq, 4), 256, 0, h->stream>>>(d_qs, nq, h->d, h->qnorm.as<float>(), h->qdelta.as<float>(),

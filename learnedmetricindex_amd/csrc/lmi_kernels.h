@@ -350,6 +350,7 @@ struct RouteArrays {
     int primary_nb;       // > 0 (= n_buckets): a slot is primary iff no lower rank of its query holds a bucket of >= 64 rows here
     int sample_items;     // 1: also build the pass-1 queues of lmi_pass2.h (grp_base1 / grp_total1: query tiles x SAMPLED tiles)
     int sample_max;       // pass 1's largest sampling stride (PF_SAMPLE; PF_SAMPLE_LOWD at K <= 64)
+    unsigned long long* dbg;  // nullable developer aid: route_group_body stamps the clock after its key pass [2] and its sort [3]
 };
 
 // ---- prefilter pass 1: which tiles of a bucket are sampled (shared by the routing kernels and lmi_prefilter.h / lmi_pass2.h) ----
@@ -521,7 +522,7 @@ constexpr int ROUTE_MAX_BUCKETS = 8000;   // up to here the sort runs in LDS (8 
 constexpr int ROUTE_ID_BITS = 20;         // bucket ids in the sort key: lmi_buckets_begin refuses 2^20 buckets or more
 // (the body: also the queue-building block of front_kernel, lmi_front.h, which passes the per-bucket counts it holds in LDS as R.m / R.m0;
 // `base`: route_group_lds(L) bytes of LDS, or the global scratch; `active_sp`: one LDS word; 1 024 threads)
-template <bool GLOBAL>
+template <bool GLOBAL, int NT = 1024>   // NT: threads of the block (1 024: route_group_kernel; 512: pack_kernel's queue block, lmi_front.h)
 __device__ __forceinline__ void route_group_body(int L, const RouteArrays& R, char* base, int* active_sp) {
     // Everything in LDS: the ranking is a bitonic sort of one 64-bit key per bucket (work descending, id ascending), O(L log^2 L / 1024)
     // per thread.  (Until round 4 every thread counted the buckets ahead of its own: O(L^2 / 1024) -- a few us at L = 120, 196 us
@@ -538,7 +539,7 @@ __device__ __forceinline__ void route_group_body(int L, const RouteArrays& R, ch
     __syncthreads();
     {
         int mine = 0;
-        for (int b = t; b < P; b += 1024) {
+        for (int b = t; b < P; b += NT) {
             unsigned long long key = ~0ull;   // padding sorts last
             if (b < L) {
                 const int m = R.m[b];
@@ -555,9 +556,31 @@ __device__ __forceinline__ void route_group_body(int L, const RouteArrays& R, ch
         if (mine) atomicAdd(&active_s, mine);
     }
     __syncthreads();
+    if (R.dbg && t == 0) R.dbg[2] = wall_clock64();
+    bool ranked = false;
+    int my_rank[2] = {0, 0}, my_id[2] = {0, 0};
+    if (!GLOBAL && P <= 2 * NT && P <= 1024) {
+        // Few buckets (C2: 120, C5: 256): RANK BY COUNTING -- a thread per key counts the smaller keys (the keys are distinct: work | id):
+        // P broadcast reads from LDS, no barrier per step (the bitonic network below: log^2 P steps with a block barrier each, ~9 us of
+        // a 12-us block at 256 buckets; a single-wave register network with 8 lane shuffles per step measured 8-11 us; this: ~1 us)
+        ranked = true;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = t + u * NT;
+            if (i < P) {
+                const unsigned long long mine = key_s[i];
+                int r = 0;
+#pragma unroll 8
+                for (int o = 0; o < P; ++o) r += key_s[o] < mine ? 1 : 0;
+                my_rank[u] = r;
+                my_id[u] = (int)(mine & ((1ull << ROUTE_ID_BITS) - 1));
+            }
+        }
+        __syncthreads();   // every key is read: the ids may go over them
+    } else
     for (int k = 2; k <= P; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = t; i < P; i += 1024) {
+            for (int i = t; i < P; i += NT) {
                 const int ixj = i ^ j;
                 if (ixj > i) {
                     const unsigned long long a = key_s[i], c = key_s[ixj];
@@ -568,21 +591,29 @@ __device__ __forceinline__ void route_group_body(int L, const RouteArrays& R, ch
             __syncthreads();
         }
     }
+    if (R.dbg && t == 0) R.dbg[3] = wall_clock64();
+    if (ranked) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = t + u * NT;
+            if (i < P && my_rank[u] < L) order_s[my_rank[u]] = my_id[u];   // (over the keys: every one was read before the barrier above)
+        }
+    } else
     if constexpr (GLOBAL) {
-        for (int i = t; i < L; i += 1024) order_s[i] = (int)(key_s[i] & ((1ull << ROUTE_ID_BITS) - 1));
+        for (int i = t; i < L; i += NT) order_s[i] = (int)(key_s[i] & ((1ull << ROUTE_ID_BITS) - 1));
     } else {
         // rank -> bucket id, in place: every thread reads its keys before anyone writes an id over a key
-        constexpr int PER = (8192 + 1023) / 1024;
+        constexpr int PER = (8192 + NT - 1) / NT;
         int ids[PER];
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
-            const int i = t + u * 1024;
+            const int i = t + u * NT;
             ids[u] = i < P ? (int)(key_s[i] & ((1ull << ROUTE_ID_BITS) - 1)) : 0;
         }
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
-            const int i = t + u * 1024;
+            const int i = t + u * NT;
             if (i < L) order_s[i] = ids[u];
         }
     }
@@ -592,10 +623,9 @@ __device__ __forceinline__ void route_group_body(int L, const RouteArrays& R, ch
     // LPT is serial: 54-73 us at L = 120 whichever way it was written; the snake's queue loads differ by a few per cent and draining
     // queues steal anyway.)  Wave g scans queue g's item counts (its members are rank 8 r + (r odd ? 7 - g : g), r = 0, 1, ..), wave
     // NGRP + g its pass-1 item counts: 64 members per step, a shuffle scan + a carry.
-    static_assert(2 * NGRP <= 1024 / 64, "one wave per queue and kind of item");
     const int A = active_s;  // buckets with work: ranks 0 .. A-1 (the others have zero work and sort last)
-    const int wv = t >> 6, ln = t & 63;
-    if (wv < 2 * NGRP) {
+    const int ln = t & 63;
+    for (int wv = t >> 6; wv < 2 * NGRP; wv += NT / 64) {   // (a wave per queue and kind of item; a block of fewer waves: several each)
         const int g = wv % NGRP;
         const bool second = wv >= NGRP;   // the pass-1 items
         const int rows = A / NGRP, rem = A % NGRP;

@@ -3,7 +3,7 @@
 index size, so a small index is enough.  LMI_FR_DEBUG=1 makes block 0, the first bucket block and the last one stamp the chip's 100 MHz
 clock at their phase boundaries; this prints the phases (us) and the launch's duration from the handle's device stamps.
 
-  python3 tools/front_phases.py [d L nq nb [parts]]"""
+  python3 tools/front_phases.py [d L nq nb]"""
 import os
 import sys
 
@@ -12,10 +12,9 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def main(d=768, L=120, nq=10000, nb=4, parts=0):
+def main(d=768, L=120, nq=10000, nb=4):
     os.environ["LMI_FR_DEBUG"] = "1"
-    if parts:
-        os.environ["LMI_FR_PARTS"] = str(parts)
+    os.environ.setdefault("LMI_FRONT", "1")   # (LMI_FRONT=0: the separate preparation kernels, for the route phase's baseline)
     from learnedmetricindex_amd import _capi
 
     rs = np.random.RandomState(1)
@@ -35,17 +34,16 @@ def main(d=768, L=120, nq=10000, nb=4, parts=0):
         idx.scan_topk(Q, order, 10)
     tm, n = idx.timings_mean()
     st = idx.debug_peek("fr_dbg", 24 * 8).view(np.uint64).astype(np.int64)
-    names0 = ["walk A", "global copies", "fills", "queue sort"]
-    namesb = ["walk A", "prefix", "walk B", "first col-block", "rest"]
-    print(f"d={d} L={L} nq={nq} nb={nb} parts={parts or 'auto'}: route phase {tm[_capi.T_ROUTE] * 1e3:.1f} us (mean of {n})")
+    print(f"d={d} L={L} nq={nq} nb={nb}: route phase {tm[_capi.T_ROUTE] * 1e3:.1f} us (mean of {n})")
     t = st[0:5]
-    print("  block 0      :", ", ".join(f"{nm} {(t[i + 1] - t[i]) / 100:.1f}" for i, nm in enumerate(names0)), f"| total {(t[4] - t[0]) / 100:.1f} us")
-    for base, who in ((8, "first bucket"), (16, "last bucket ")):
-        t = st[base:base + 6]
-        if t[0] == 0:
-            continue
-        print(f"  {who} :", ", ".join(f"{nm} {(t[i + 1] - t[i]) / 100:.1f}" for i, nm in enumerate(namesb)), f"| total {(t[5] - t[0]) / 100:.1f} us; "
-              f"starts {(t[0] - st[0]) / 100:.1f} us after block 0")
+    if t[0]:
+        print(f"  pack_kernel block 0 (queues): statistics {(t[1] - t[0]) / 100:.1f}, keys {(t[2] - t[1]) / 100:.1f}, sort {(t[3] - t[2]) / 100:.1f}, "
+              f"queues {(t[4] - t[3]) / 100:.1f} us")
+    for base, who in ((8, "route_kernel first block"), (16, "route_kernel last block ")):
+        t = st[base:base + 3]
+        if t[0] and t[2]:
+            print(f"  {who}: counting walk {(t[1] - t[0]) / 100:.1f}, allocation + placing walk {(t[2] - t[1]) / 100:.1f} us"
+                  + (f"; pack block 0 starts {(st[0] - t[0]) / 100:.1f} us after it" if base == 8 and st[0] else ""))
     idx.close()
 
 

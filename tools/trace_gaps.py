@@ -4,7 +4,7 @@ duration and the average idle gap before it (start minus the latest end of anyth
 
   python3 tools/trace_gaps.py gpurun_out/trace_<tag>/trace [anchor-kernel-substring]
 
-A step is cut at each occurrence of the anchor kernel (default: front_kernel when the trace has it, else pack_queries16_kernel)."""
+A step is cut at each occurrence of the anchor kernel (default: route_kernel when the trace has it, else pack_queries16_kernel)."""
 import collections
 import csv
 import glob
@@ -14,8 +14,8 @@ import sys
 def main(src, anchor=None):
     f = glob.glob(src + "/**/*kernel_trace.csv", recursive=True)[0]
     rows = list(csv.DictReader(open(f)))
-    if anchor is None:   # the first kernel of a scan: front_kernel (round 5), else the old preparation's pack kernel
-        anchor = "front_kernel" if any("front_kernel" in r["Kernel_Name"] for r in rows) else "pack_queries16_kernel"
+    if anchor is None:   # the first kernel of a scan: route_kernel (round 5), else the old preparation's pack kernel
+        anchor = "route_kernel" if any("route_kernel" in r["Kernel_Name"] for r in rows) else "pack_queries16_kernel"
     by_q = collections.defaultdict(list)
     for r in rows:
         by_q[r["Queue_Id"]].append(r)
