@@ -193,6 +193,7 @@ class Workload:
             searcher = ReplicaSearcher(eng, rank, world)
         else:
             searcher = ShardedSearcher(eng, rank, world, shard_inference=shard_inference, lib_comm=lib_comm)
+            searcher.time_collectives = world > 1   # two events per collective: the time a rank waits in each exchange (per_rank)
 
         def sync_all():
             torch.cuda.synchronize()
@@ -210,7 +211,10 @@ class Workload:
         ov = os.environ.get("LMI_PIPE_OVERLAP", "1")
         pipe = HostPipeline(eng, nq, d, d, nb, k, depth=int(os.environ.get("LMI_PIPE_DEPTH", "2")), same_queries=True, want_bucket_order=True,
                             overlap_inference=(ov == "1") if world == 1 else os.environ.get("LMI_PIPE_OVERLAP_SHARDED", "0") == "1",
-                            two_handles=ov == "2", sharded=searcher if world > 1 else None)
+                            two_handles=ov == "2", sharded=searcher if world > 1 else None,
+                            use_graph=world == 1 and os.environ.get("LMI_PIPE_GRAPH", "0") == "1")
+        for qh in q_hosts:   # LMI_PIPE_GRAPH=1: hipGraph replay (opt-in: measured SLOWER than eager submission on ROCm 7.2 -- C1 0.27 against 0.22 ms
+            pipe.capture(qh)  # per batch: two graph launches cost more than the dozen eager ones); the graphs are built here, untimed
         # (world > 1: the rank's MLP slice of batch i+1 beside the scan of batch i is opt-in -- it could only be rehearsed with
         # gloo on one card, where it was slower; on a single GPU the same overlap is measured: -1.9 %)
         for i in range(warmup):
@@ -228,8 +232,8 @@ class Workload:
         elapsed = time.perf_counter() - t0
         if os.environ.get("LMI_BENCH_DEBUG") and rank == 0:
             log(f"[bench:{self.tag}] submit returned at (ms): {[round(v * 1e3, 2) for v in stamps]}; end {elapsed * 1e3:.2f}")
-        # hipEvents recorded on the kernels' own stream around every phase of every step; read once, after the
-        # timed region (the handle keeps the newest 128 sets), so the loop itself has no host synchronisation
+        # device clock stamps (or, at --timing-level 3, hipEvents) on the kernels' own stream around every phase of every step; read
+        # once, after the timed region (the handle keeps the newest 128 sets), so the loop itself has no host synchronisation
         phases, n_timed = eng.timings_mean()
         calls = searcher.calls_per_search * pipe.calls_per_batch
         phases = phases * calls
@@ -238,7 +242,8 @@ class Workload:
         tm = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-        res = dict(elapsed=float(tm.item()), elapsed_local=elapsed, phases=phases, n_timed=int(n_timed) // calls,
+        coll = searcher.collective_ms() if getattr(searcher, "time_collectives", False) else None
+        res = dict(elapsed=float(tm.item()), elapsed_local=elapsed, phases=phases, n_timed=int(n_timed) // calls, collectives_ms=coll,
                    out_d=out_d, out_i=out_i, bo=bo, calls=calls, overlapped=bool(pipe.overlap or pipe.sh_overlap))
         if measure_resident:
             eng.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -260,6 +265,19 @@ class Workload:
                 dist.all_reduce(tr, op=dist.ReduceOp.MAX)
             res["resident_elapsed"] = float(tr.item())
             assert np.array_equal(ri.cpu().numpy().view(np.uint32), out_i), "resident and host-boundary results differ"
+            if self.args.timing_level == 2:
+                # cross-check of the device stamps: the same phases from hipEvents recorded between the kernels (timing level 3: each
+                # event is a ~5 us bubble, so this loop is slower than the timed one and not part of it)
+                eng.set_timing(3)
+                for _ in range(2):
+                    searcher.search(q, q, nb, k)
+                sync_all()
+                eng.timings_reset()
+                for i in range(min(5, steps)):
+                    searcher.search(rot[i % nrot], rot[i % nrot], nb, k)
+                sync_all()
+                res["phases_events"] = eng.timings_mean()[0] * searcher.calls_per_search
+                eng.set_timing(2)
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
         res["scan_stats"] = eng.scan_stats()
         res["pf_stats"] = eng.prefilter_stats()
@@ -526,6 +544,13 @@ def dominant_roofline(args, cfg, res, sizes, owner, rank, capi, exact=None):
     else:
         roof = {"bound": "hbm", "achieved": round(alg_bytes / dom_s / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": round(alg_bytes / dom_s / 1e9 / PEAK_HBM_GBS, 4)}
+    clk = float(phases[capi.T_CLOCK_MHZ]) if len(phases) > capi.T_CLOCK_MHZ else 0.0
+    roof["shader_clock_mhz_under_kernel"] = round(clk, 1) if clk > 0 else None   # s_memtime / s_memrealtime over the life of the kernel's block 0
+    roof["timed_with"] = ("device clock stamps written by the kernel's own workgroups in the timed region (lmi_set_timing 2: no hipEvent bubbles); "
+                          "avg_launch_ms_hipevents: the same launch between two hipEvents on its stream in a separate 5-step loop"
+                          if args.timing_level == 2 else "hipEvents on the kernel's stream in the timed region")
+    ev = res.get("phases_events")
+    roof["avg_launch_ms_hipevents"] = None if ev is None else round(float(ev[dom_slot]), 4)
     roof.update({"kernel": kernel, "flops_per_launch": flops, "bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom_s * 1e3, 4),
                  "launches_timed": res["n_timed"], "floors_ms": {"mfma": round(t_mfma * 1e3, 3), "hbm": round(t_hbm * 1e3, 3)},
                  "k_padded_to": dpad})
@@ -805,8 +830,8 @@ def main():
     ap.add_argument("--hard-zipf", type=float, default=20.0)
     ap.add_argument("--chunk-rows", type=int, default=None)
     ap.add_argument("--timing-level", type=int, default=2, choices=(0, 1, 2, 3),
-                    help="lmi_set_timing: 2 (default) times every phase with hipEvents -- the roofline needs the dominant "
-                         "kernel's duration; 0/1 show the step without the events' bubbles (roofline fields then null/0)")
+                    help="lmi_set_timing: 2 (default) times every phase with device-side clock stamps (no bubbles); 3: with hipEvents "
+                         "between the kernels (each a ~5 us bubble); 0/1: nothing / the whole call only (roofline fields then null/0)")
     ap.add_argument("--exact", action="store_true",
                     help="all-f32 scan (lmi_set_prefilter(0)) instead of fp16 prefilter + exact re-rank; same results")
     ap.add_argument("--shard-mode", choices=("bucket", "replica"), default="bucket",
@@ -887,7 +912,9 @@ def main():
         mine = {"rank": rank, "scan_pairs": int(pairs), "scan_items": int(items),
                 "rows_owned": int(sizes[owner == rank].sum()), "buckets_owned": int((owner == rank).sum()),
                 "step_ms_this_rank": round(res["elapsed_local"] / args.steps * 1e3, 4),
-                "phases_ms": {n_: round(float(phases[i]), 4) for i, n_ in enumerate(names)}}
+                "phases_ms": {n_: round(float(phases[i]), 4) for i, n_ in enumerate(names)},
+                # what the rank WAITS in each exchange (events around the collective on its stream: the other ranks' lateness included)
+                "collectives_exposed_ms": res.get("collectives_ms")}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
 
@@ -1108,6 +1135,12 @@ def main():
             "rccl_version": None if up is None else up["rccl_version"],
             "rank_devices": None if up is None else up["devices"],
             "per_rank": per_rank,
+            # N > 1: how uneven the ranks' dominant kernel was (max / mean of pf_emit over the ranks: 1.0 = perfectly balanced shards)
+            "per_rank_imbalance": None if not per_rank else {
+                "pf_emit_max_ms": round(max(p_["phases_ms"]["pf_emit"] for p_ in per_rank), 4),
+                "pf_emit_mean_ms": round(float(np.mean([p_["phases_ms"]["pf_emit"] for p_ in per_rank])), 4),
+                "pf_emit_max_over_mean": round(max(p_["phases_ms"]["pf_emit"] for p_ in per_rank) / max(1e-9, float(np.mean([p_["phases_ms"]["pf_emit"] for p_ in per_rank]))), 4),
+                "step_ms_max": round(max(p_["step_ms_this_rank"] for p_ in per_rank), 4)},
             "hard_leg": hard,
             "exact_leg": exact_leg,
             "other_configs": others,

@@ -65,6 +65,8 @@ enum {
     LMI_T_PF_EMIT = 6,   /* prefilter pass 2 (fp16 scan + candidate emission) -- the dominant kernel */
     LMI_T_RESCORE = 7,   /* select + exact re-rank of the survivors                                  */
     LMI_T_FALLBACK = 8,  /* exact brute-force fallback for overflowed slots (normally empty)         */
+    LMI_T_CLOCK_MHZ = 9, /* NOT a time: the shader clock (MHz) the chip held under pass 2 -- block 0's life in s_memtime cycles over the
+                            same in 100 MHz s_memrealtime ticks (timing level 2 only; 0 otherwise)             */
     LMI_T_COUNT = 12
 };
 

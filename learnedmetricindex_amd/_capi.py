@@ -15,8 +15,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LMI_LIB") or os.path.join(_HERE, "liblmi_hip.so")  # LMI_LIB: A/B builds (tools/)
 K_PER_BUCKET = 10
-T_INFERENCE, T_ROUTE, T_SCAN, T_MERGE, T_TOTAL, T_PF_SAMPLE, T_PF_EMIT, T_RESCORE, T_FALLBACK, T_COUNT = (
-    0, 1, 2, 3, 4, 5, 6, 7, 8, 12)
+T_INFERENCE, T_ROUTE, T_SCAN, T_MERGE, T_TOTAL, T_PF_SAMPLE, T_PF_EMIT, T_RESCORE, T_FALLBACK, T_CLOCK_MHZ, T_COUNT = (
+    0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 12)   # (T_CLOCK_MHZ is not a time: the shader clock held under pass 2, from in-kernel counters)
 
 _lib = None
 

@@ -41,7 +41,9 @@ static_assert(FR_SLICE_G % 2 == 0, "the 16 x 32 fragment shape pairs k16-groups"
 struct FrontParams {
     const int* bucket_order;   // [nq][nb]
     int nq, nb, L;
-    unsigned epoch;            // this call's tag of the granules below (per handle, never 0: stale entries of earlier calls never match)
+    const unsigned* epoch_dev; // this call's tag of the granules below: a DEVICE word (never 0; stale entries of earlier calls never match),
+                               // bumped by the launch behind pack_kernel's consumers (bound_merge2_kernel) -- not a kernel argument, which a
+                               // graph replay of the call would freeze
     unsigned long long* gran;  // [L + 1] {epoch << 32 | value}: [b] = queries routed to bucket b, published by its block with ONE 8-byte store
                                // (the data is the flag); [L] = the batch's col-blocks, published by the last bucket's block
     int* cb_bucket;            // [col-blocks] the bucket a col-block belongs to
@@ -181,6 +183,7 @@ __global__ __launch_bounds__(FR_THREADS) void route_kernel(FrontParams P) {
     extern __shared__ __attribute__((aligned(16))) char fr_smem[];
     __shared__ int misc[2 * FR_WAVES + 2];
     const int L = P.L, nq = P.nq, nb = NB > 0 ? NB : P.nb;
+    const unsigned epoch_v = *P.epoch_dev;
     int* nbr = reinterpret_cast<int*>(fr_smem);
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(FR_THREADS) void route_kernel(FrontParams P) {
     if (P.R.nb_rows[b] == 0 && b != L - 1) {   // an empty (or unowned) bucket: nothing is routed to it (the last bucket's block stays: it publishes the total)
         if (tid == 0) {
             P.R.m[b] = 0; P.R.m0[b] = 0; P.R.cb_start[b] = 0;
-            __hip_atomic_store(P.gran + b, (unsigned long long)P.epoch << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(P.gran + b, (unsigned long long)epoch_v << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         return;
     }
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(FR_THREADS) void route_kernel(FrontParams P) {
     // buckets until all carry this call's tag.  Lower-indexed blocks are dispatched first and depend on nobody, so the sweep ends; it
     // is bounded anyway (a give-up leaves a wrong layout and a word in stats[3] for the host to see).
     if (tid == 0) {
-        __hip_atomic_store(P.gran + b, ((unsigned long long)P.epoch << 32) | (unsigned long long)(unsigned)m_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(P.gran + b, ((unsigned long long)epoch_v << 32) | (unsigned long long)(unsigned)m_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         P.R.m[b] = m_b;
         P.R.m0[b] = n0;
     }
@@ -223,10 +226,10 @@ __global__ __launch_bounds__(FR_THREADS) void route_kernel(FrontParams P) {
         int sum = 0;
         for (int i0 = 0; i0 < b; i0 += 64) {
             const int i = i0 + lane;
-            unsigned long long x = (unsigned long long)P.epoch << 32;
+            unsigned long long x = (unsigned long long)epoch_v << 32;
             for (unsigned spins = 0;; ++spins) {
                 if (i < b) x = __hip_atomic_load(P.gran + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__all((unsigned)(x >> 32) == P.epoch)) break;
+                if (__all((unsigned)(x >> 32) == epoch_v)) break;
                 if (spins > (1u << 22)) { if (lane == 0) P.R.stats[3] = -1; break; }
                 __builtin_amdgcn_s_sleep(4);
             }
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(FR_THREADS) void route_kernel(FrontParams P) {
         if (lane == 0) {
             misc[2 * FR_WAVES] = sum;
             P.R.cb_start[b] = sum;
-            if (b == L - 1) __hip_atomic_store(P.gran + L, ((unsigned long long)P.epoch << 32) | (unsigned long long)(unsigned)(sum + ncb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (b == L - 1) __hip_atomic_store(P.gran + L, ((unsigned long long)epoch_v << 32) | (unsigned long long)(unsigned)(sum + ncb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     __syncthreads();
@@ -259,6 +262,7 @@ __global__ __launch_bounds__(FP_THREADS) void pack_kernel(FrontParams P) {
     __shared__ int active_s;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bid = blockIdx.x;
+    const unsigned epoch_v = *P.epoch_dev;
     // ---- the small per-call arrays (the old fill_ranges_kernel list): every block its share, before anything can make it leave ----
     for (int r = 0; r < P.Z.count; ++r)
         for (long long i = (long long)bid * FP_THREADS + tid; i < P.Z.n[r]; i += (long long)gridDim.x * FP_THREADS) P.Z.p[r][i] = P.Z.v[r];
@@ -304,7 +308,7 @@ __global__ __launch_bounds__(FP_THREADS) void pack_kernel(FrontParams P) {
         return;
     }
     const unsigned long long alloc = P.gran[P.L];   // (route_kernel is complete: the launch boundary orders it)
-    const int n_cb = (unsigned)(alloc >> 32) == P.epoch ? (int)(unsigned)alloc : 0;
+    const int n_cb = (unsigned)(alloc >> 32) == epoch_v ? (int)(unsigned)alloc : 0;
     const int cb = bid - 1;
     if (cb >= n_cb) return;
     char* stage = fp_smem;

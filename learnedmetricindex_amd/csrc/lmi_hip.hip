@@ -185,7 +185,8 @@ struct lmi_index {
     double wall_khz = 100000.0;
     DevBuf fr_dbg;                // LMI_FR_DEBUG=1: route_kernel's / pack_kernel's phase stamps (lmi_debug_peek "fr_dbg")
     DevBuf cb_alloc, cb_bucket;   // lmi_front.h: the call-tagged granules of route_kernel (zero at allocation) and the col-blocks' buckets
-    unsigned fr_epoch = 0;        // this handle's calls through route_kernel (the granules' tag; never 0)
+    bool fr_bump_pending = false; // route_kernel was launched and the launch that bumps the granules' tag (bound_merge2_kernel) not yet: a call that
+                                  // failed in between is repaired by a bump launch of its own at the next call
     bool use_tail = true;         // tail_kernel (lmi_tail.h): selection + re-rank + rank merge in one wave per query (LMI_TAIL=0: the five launches of round 4)
     bool use_front = true;        // route_kernel + pack_kernel (lmi_front.h) instead of the eight preparation launches (LMI_FRONT=0 in the environment: off)
 };
@@ -1249,10 +1250,21 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
             FrontParams A;
             A.bucket_order = d_order;
             A.nq = nq; A.nb = nb; A.L = L;
-            if (!h->cb_alloc.p) { CHK(h->cb_alloc.reserve((size_t)(FR_MAX_L + 1) * 8)); HIPCHK(hipMemsetAsync(h->cb_alloc.p, 0, (size_t)(FR_MAX_L + 1) * 8, h->stream)); }
+            // granules [FR_MAX_L + 1] | the tag word (device-resident: a kernel argument would be frozen by a graph replay of this call)
+            if (!h->cb_alloc.p) {
+                CHK(h->cb_alloc.reserve((size_t)(FR_MAX_L + 2) * 8));
+                HIPCHK(hipMemsetAsync(h->cb_alloc.p, 0, (size_t)(FR_MAX_L + 2) * 8, h->stream));
+                front_epoch_bump_kernel<<<1, 1, 0, h->stream>>>(reinterpret_cast<unsigned*>(h->cb_alloc.as<unsigned long long>() + FR_MAX_L + 1));   // 0 -> 1
+                HIPCHK(hipGetLastError());
+            }
             CHK(h->cb_bucket.reserve((size_t)ncb_bound * 4));
-            if (++h->fr_epoch == 0u) h->fr_epoch = 1u;
-            A.epoch = h->fr_epoch;
+            unsigned* const epoch_dev = reinterpret_cast<unsigned*>(h->cb_alloc.as<unsigned long long>() + FR_MAX_L + 1);
+            if (h->fr_bump_pending) {   // an earlier call left after route_kernel and before its bump: bump now
+                front_epoch_bump_kernel<<<1, 1, 0, h->stream>>>(epoch_dev);
+                HIPCHK(hipGetLastError());
+            }
+            h->fr_bump_pending = true;
+            A.epoch_dev = epoch_dev;
             A.gran = h->cb_alloc.as<unsigned long long>();
             A.cb_bucket = h->cb_bucket.as<int>();
             A.colmap = h->colmap.as<int>();
@@ -1355,8 +1367,10 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
 #endif
         {
             CHK(launch_pass2<true>(h, F));   // pass 1: slot maxima of the sampled tiles
-            bound_merge2_kernel<<<cdiv((long long)ncols, 64), 256, 0, h->stream>>>(F.bound, (long long)ncols, F.bound1);
+            bound_merge2_kernel<<<cdiv((long long)ncols, 64), 256, 0, h->stream>>>(F.bound, (long long)ncols, F.bound1,
+                use_front ? reinterpret_cast<unsigned*>(h->cb_alloc.as<unsigned long long>() + FR_MAX_L + 1) : nullptr);
             HIPCHK(hipGetLastError());
+            h->fr_bump_pending = false;
             if (qbound) {   // the caller keeps the k <= 10 best over all ranks: one bound per query
                 query_bound_kernel<<<cdiv(nq, 256), 256, 0, h->stream>>>(h->slot_col.as<int>(), nq, nb, F.eps2, F.bound1);
                 HIPCHK(hipGetLastError());
@@ -1373,6 +1387,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         // pass 2: candidates
         F.ts_start = tsp(h, ST_P2);
         F.ts_end_cell = F.ts_start ? p2_end_cell : nullptr;
+        if (F.ts_start) { (void)tsp(h, ST_CLK_WALL); (void)tsp(h, ST_CLK_CYC); }
         CHK(launch_pass2<false>(h, F));
         F.ts_start = nullptr;
         F.ts_end_cell = nullptr;
@@ -1558,7 +1573,9 @@ extern "C" LMI_API int lmi_workspace_bytes(lmi_index* h, int nq, int nb, int64_t
         t += ncols * (4 + 4 + 2ll * PF_CAP * 4 + 1);             // eps2, candidate counts + buffers, redo flags
         t += ncols * P2_NSL * 16 * 4 + 4096;                     // pass-1 lists
         t += nslots * (4 + 4 + (long long)RC_KEEP * 4) + nslots; // fallback, nkeep, survivor rows, re-rank lists
-        t += nslots * 4 + 32 + ncols * 4;                        // fallback list, overflow offsets (the 96-MiB overflow log is per handle, not per call)
+        t += nslots * 4 + 32 + ncols * 4;                        // fallback list, overflow offsets
+        t += ((long long)1 << LMI_PF_X_LOG2) * (16 + 8);         // the handle's overflow log + its sorted form (96 MiB, allocated with the first prefilter batch:
+                                                                 // part of what a caller's memory budget must leave room for, whatever nq is)
     } else {
         t += std::max<long long>(1, (long long)nb * max_nch * nq) * KPB * 8;   // chunk partial lists of the exact scan
     }
@@ -1867,6 +1884,8 @@ static void read_stamp_set(const lmi_index* h, const unsigned long long* v, unsi
     span(ST_MERGE, ST_END, &ms[LMI_T_MERGE]);
     const int first = have(ST_MLP0) ? ST_MLP0 : ST_FRONT, last = have(ST_END) ? ST_END : ST_MLP1;
     span(first, last, &ms[LMI_T_TOTAL]);
+    // the clock the chip held under the dominant kernel: block 0's life in shader cycles (s_memtime) over the same in 100 MHz ticks
+    if (have(ST_CLK_WALL) && have(ST_CLK_CYC) && v[ST_CLK_WALL] > 0) ms[LMI_T_CLOCK_MHZ] = (float)((double)v[ST_CLK_CYC] / (double)v[ST_CLK_WALL] * (h->wall_khz / 1000.0));
 }
 
 extern "C" LMI_API int lmi_timings(lmi_index* h, float* ms) {

@@ -45,7 +45,20 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
 // copied to the set by the next kernel on the stream.  Phases are differences of stamps (lmi_hip.hip, read_stamp_set); nothing is
 // synchronised, polled or waited for.  All pointers are null when stamps are off.
 // ------------------------------------------------------------------------------------------------
-enum { ST_MLP0 = 0, ST_MLP1, ST_FRONT, ST_P1, ST_P2, ST_P2END, ST_TAIL, ST_FB, ST_MERGE, ST_END, ST_SCAN0, ST_SCAN1, ST_COUNT = 16 };
+enum { ST_MLP0 = 0, ST_MLP1, ST_FRONT, ST_P1, ST_P2, ST_P2END, ST_TAIL, ST_FB, ST_MERGE, ST_END, ST_SCAN0, ST_SCAN1,
+       ST_CLK_WALL, ST_CLK_CYC,   // the dominant kernel's block 0: its own life in 100 MHz ticks and in shader-clock cycles (s_memtime): cycles / ticks x 100 = the held clock in MHz
+       ST_COUNT = 16 };
+// block 0 of a persistent kernel: (s_memrealtime, s_memtime) at its start -> call clk_end with them at its end
+__device__ __forceinline__ void clk_begin(unsigned long long* ts_start, unsigned long long& w0, unsigned long long& c0) {
+    if (ts_start && blockIdx.x == 0 && threadIdx.x == 0) { w0 = wall_clock64(); c0 = __builtin_readcyclecounter(); }
+}
+__device__ __forceinline__ void clk_end(unsigned long long* ts_start, int st_index, unsigned long long w0, unsigned long long c0) {
+    if (ts_start && blockIdx.x == 0 && threadIdx.x == 0) {   // ts_start = set + st_index: the set's base is ts_start - st_index
+        unsigned long long* set = ts_start - st_index;
+        set[ST_CLK_WALL] = wall_clock64() - w0;
+        set[ST_CLK_CYC] = __builtin_readcyclecounter() - c0;
+    }
+}
 __device__ __forceinline__ void ts_first(unsigned long long* p) {   // the launch's first workgroup
     if (p && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) *p = wall_clock64();
 }

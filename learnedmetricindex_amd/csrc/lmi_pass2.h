@@ -659,8 +659,14 @@ struct Tile2 {
 // wrote).  A block takes 64 columns; thread (quarter qd, column c) keeps the ten best of lists 4 qd .. 4 qd + 3 (64 values; the
 // lists are column-minor: the 64 threads of a quarter read 64 neighbouring floats), the four partial lists of a column meet in
 // LDS.  Values only; fewer than 10 finite values: -inf (no bound).
-__global__ __launch_bounds__(256) void bound_merge2_kernel(const float* __restrict__ lists, long long ncols, float* __restrict__ bound1) {
+// (epoch_bump: nullable -- the tag word of route_kernel's granules, lmi_front.h: every consumer of this call's tag has finished by now)
+__device__ __forceinline__ void front_epoch_bump(unsigned* epoch_bump) {
+    if (epoch_bump && blockIdx.x == 0 && threadIdx.x == 0) { const unsigned e = *epoch_bump + 1u; *epoch_bump = e ? e : 1u; }
+}
+__global__ void front_epoch_bump_kernel(unsigned* epoch_bump) { front_epoch_bump(epoch_bump); }
+__global__ __launch_bounds__(256) void bound_merge2_kernel(const float* __restrict__ lists, long long ncols, float* __restrict__ bound1, unsigned* epoch_bump = nullptr) {
     __shared__ float part[4][KPB][64];
+    front_epoch_bump(epoch_bump);
     const int c = threadIdx.x & 63, qd = threadIdx.x >> 6;
     const long long col = (long long)blockIdx.x * 64 + c;
     float v[KPB];
@@ -862,6 +868,8 @@ __global__ __launch_bounds__(64 * P2_WAVES, 2) __attribute__((amdgpu_num_vgpr(LM
     __shared__ int s_prefix[P2_PREFIX_CAP_K];
     if (!SAMPLE && P.redo_count && *P.redo_count == 0u) return;  // the redo launch of a batch without overflowed columns
     ts_first(P.ts_start);
+    unsigned long long clk_w0 = 0, clk_c0 = 0;
+    if (!SAMPLE) clk_begin(P.ts_end_cell ? P.ts_start : nullptr, clk_w0, clk_c0);   // (pass 2 proper: the launch that carries an end cell)
     P2Queue<SAMPLE, false, 64 * P2_WAVES, P2_PREFIX_CAP_K> queue{P, s_item, s_prefix};
     queue.init();
     P2Item item;
@@ -875,6 +883,7 @@ __global__ __launch_bounds__(64 * P2_WAVES, 2) __attribute__((amdgpu_num_vgpr(LM
         }
 #undef P2_CASE
     }
+    if (!SAMPLE) clk_end(P.ts_end_cell ? P.ts_start : nullptr, ST_P2, clk_w0, clk_c0);
     ts_max(P.ts_end_cell);
 }
 

@@ -92,6 +92,8 @@ __global__ __launch_bounds__(64 * ps_waves(KG, WIDE), ps_blocks_per_cu(KG, WIDE)
     __shared__ int s_prefix[PS_PREFIX_CAP];
     if (!SAMPLE && P.redo_count && *P.redo_count == 0u) return;  // the redo launch of a batch without overflowed columns
     ts_first(P.ts_start);
+    unsigned long long clk_w0 = 0, clk_c0 = 0;
+    if (!SAMPLE) clk_begin(P.ts_end_cell ? P.ts_start : nullptr, clk_w0, clk_c0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, c = lane & 31;
@@ -405,6 +407,7 @@ __global__ __launch_bounds__(64 * ps_waves(KG, WIDE), ps_blocks_per_cu(KG, WIDE)
         for (int i = 0; i < 8; ++i) atomicAdd(g + i, st_acc[i]);
     }
 #endif
+    if (!SAMPLE) clk_end(P.ts_end_cell ? P.ts_start : nullptr, ST_P2, clk_w0, clk_c0);
     ts_max(P.ts_end_cell);
 }
 

@@ -54,9 +54,9 @@ class _Hasher:
 
     def __init__(self):
         try:
-            import xxhash
+            import xxhash   # optional (requirements.txt): ~10 GB/s; without it the zlib pair below, ~10x slower
             self._h, self._z = xxhash.xxh3_64(), None
-        except ImportError:  # pragma: no cover
+        except ImportError:
             self._h, self._z = None, [0, 1]
 
     def update(self, a) -> None:
@@ -64,7 +64,7 @@ class _Hasher:
         buf = memoryview(a.reshape(-1).view(np.uint8)) if a.size else b""
         if self._h is not None:
             self._h.update(buf)
-        else:  # pragma: no cover
+        else:
             import zlib
             self._z = [zlib.crc32(buf, self._z[0]), zlib.adler32(buf, self._z[1])]
 
@@ -136,6 +136,7 @@ class LearnedIndex(Logger):
         state["_engine_key"] = None
         state["_path_ids"] = None
         state["_entry_paths"] = None
+        state.pop("_fp_memo", None)
         return state
 
     def __setstate__(self, state):
@@ -160,7 +161,10 @@ class LearnedIndex(Logger):
         self._engine_key = None
 
     #: "auto": full-content fingerprint of the scan frame for frames up to _STRICT_BYTES, a row sample above; True: always full;
-    #: False: always the sample (an in-place edit of unsampled rows is then only caught by `invalidate()`)
+    #: False: always the sample (an in-place edit of unsampled rows is then only caught by `invalidate()`);
+    #: "memo": the full fingerprint once per (frame object, shape, address of its values), later calls with the same triple re-check a
+    #: 4 096-row sample only -- for callers that search the same frames again and again (the full hash costs ~0.1 s per GB and call,
+    #: 10-100x the GPU search itself); an in-place edit of unsampled rows of the SAME buffer is then only caught by `invalidate()`
     strict_cache = "auto"
     _STRICT_BYTES = 1 << 30
 
@@ -184,6 +188,19 @@ class LearnedIndex(Logger):
         full = self.strict_cache is True or (self.strict_cache == "auto" and _frame_bytes(data_search) <= self._STRICT_BYTES)
         if assume_unchanged and self._engine is not None:
             content = self._engine_key[0] if self._engine_key else None
+        elif self.strict_cache == "memo":
+            try:
+                addr = int(data_search._mgr.blocks[0].values.__array_interface__["data"][0])
+            except Exception:  # noqa: BLE001  (pandas internals: best effort)
+                addr = None
+            who = (id(data_search), tuple(data_search.shape), addr)
+            sample = _frame_fingerprint(data_search, False)
+            memo = getattr(self, "_fp_memo", None)
+            if addr is not None and memo is not None and memo[0] == who and memo[1] == sample:
+                content = memo[2]
+            else:
+                content = _frame_fingerprint(data_search, True)
+                self._fp_memo = (who, sample, content)
         else:
             content = _frame_fingerprint(data_search, full)
         w_h = _Hasher()

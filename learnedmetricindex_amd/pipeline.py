@@ -18,6 +18,12 @@ The 1 MB result download is a KERNEL on the compute stream that stores into the 
 stream) blocked the submitting host thread for 15-20 ms every few batches behind the queued search kernels
 (ROCm 7.2, seen by timing the calls) and cost up to 8 % of the throughput.
 
+`use_graph`: the whole batch -- upload, MLP, scan, download, three streams -- is captured ONCE per (slot, pinned source batch) as a
+hipGraph and replayed with one launch per batch: a 1 000-query search is ~0.18 ms of GPU work behind ~0.26 ms of Python and HIP API
+calls (a dozen launches and event operations), so small batches are host-bound without it.  Nothing in the captured work depends on a
+per-call kernel argument (the routing kernels' call tag is a device word, lmi_front.h); `capture()` pre-builds the graphs outside a timed
+region.  Pageable inputs go through the slot's pinned staging buffer (one graph per slot).
+
 Host buffers are pinned (hipHostMalloc through torch): `submit` copies a pageable numpy batch into the
 slot's pinned staging buffer (a CPU memcpy that overlaps the GPU's work), or takes a pinned torch tensor as
 it is.  PyTorch is used for pinned memory, streams and events only; the search is the C ABI's `lmi_search`.
@@ -32,7 +38,7 @@ import numpy as np
 class HostPipeline:
     def __init__(self, index, nq: int, d_nav: int, d_search: int, nb: int, k: int = 10, depth: int = 2,
                  device: Optional[int] = None, same_queries: bool = False, want_bucket_order: bool = False,
-                 search_fn=None, overlap_inference: bool = True, two_handles: bool = False, sharded=None):
+                 search_fn=None, overlap_inference: bool = True, two_handles: bool = False, sharded=None, use_graph: bool = False):
         """`search_fn(qn_dev, qs_dev) -> (dists_t, ids_t, bucket_order_t)`: optional replacement of the single-GPU
         `lmi_search` call, run on the compute stream (the bucket-sharded searcher of sharded.py, whose collectives
         then run on that stream too); its output tensors may be reused by its next call."""
@@ -71,12 +77,14 @@ class HostPipeline:
         f32, i32 = torch.float32, torch.int32
         mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)   # noqa: E731
         pin = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)   # noqa: E731
+        # hipGraph replay: single-GPU forms only (a collective inside a capture is RCCL's business, not rehearsed here)
+        self.use_graph = bool(use_graph) and search_fn is None and sharded is None and not self.two
         self.slots = []
         for _ in range(self.depth):
             s = dict(qn_h=pin((nq, d_nav), f32), qn_d=mk((nq, d_nav), f32),
                      d_d=mk((nq, self.kout), f32), i_d=mk((nq, self.kout), i32), bo_d=mk((nq, nb), i32),
                      d_h=pin((nq, self.kout), f32), i_h=pin((nq, self.kout), i32), bo_h=pin((nq, nb), i32),
-                     ev_in=torch.cuda.Event(), ev_nav=torch.cuda.Event(), ev_out=torch.cuda.Event(), busy=False)
+                     ev_in=torch.cuda.Event(), ev_nav=torch.cuda.Event(), ev_out=torch.cuda.Event(), busy=False, graphs={}, warm=False)
             if not self.same:
                 s["qs_h"], s["qs_d"] = pin((nq, d_search), f32), mk((nq, d_search), f32)
             if self.sh_overlap:
@@ -84,27 +92,16 @@ class HostPipeline:
             self.slots.append(s)
         self.t = 0
 
-    def submit(self, queries_nav, queries_search=None) -> int:
-        """Enqueues one batch (numpy arrays or pinned CPU torch tensors, [nq, d]); returns its ticket.
-        Blocks only if the slot's previous batch (`depth` submits ago) has not finished."""
+    def _enqueue(self, s, qn_src, qs_src, s_run, index, origin=None) -> None:
+        """The batch's GPU work on the three streams.  `origin`: the capturing stream (graph capture) -- the upload stream forks from it
+        and the compute stream joins back into it, so that everything is part of the capture."""
         import torch
 
-        s = self.slots[self.t % self.depth]
-        if s["busy"]:
-            s["ev_out"].synchronize()
-        s["busy"] = True
-
-        def stage(src, pinned):
-            if isinstance(src, torch.Tensor) and src.is_pinned():
-                return src                                   # already DMA-able: no staging copy
-            pinned.copy_(torch.from_numpy(np.ascontiguousarray(src, dtype=np.float32)) if isinstance(src, np.ndarray) else src)
-            return pinned
-
-        qn_src = stage(queries_nav, s["qn_h"])
         with torch.cuda.stream(self.s_in):
+            if origin is not None:
+                self.s_in.wait_stream(origin)
             s["qn_d"].copy_(qn_src, non_blocking=True)
             if not self.same:
-                qs_src = stage(queries_nav if queries_search is None else queries_search, s["qs_h"])
                 s["qs_d"].copy_(qs_src, non_blocking=True)
             s["ev_in"].record(self.s_in)
         if self.overlap:
@@ -121,7 +118,6 @@ class HostPipeline:
                 self.sharded.route_local(s["qn_d"], self.nb, s["bo_loc"])
                 s["ev_nav"].record(self.s_nav)
             self.index.set_stream(self.s_run.cuda_stream)
-        index, s_run = self.handles[self.t % len(self.handles)]
         with torch.cuda.stream(s_run):
             s_run.wait_event(s["ev_nav"] if (self.overlap or self.sh_overlap) else s["ev_in"])
             if self.sh_overlap:
@@ -141,7 +137,93 @@ class HostPipeline:
                 d_t, i_t, bo_t = self.search_fn(s["qn_d"], s["qn_d"] if self.same else s["qs_d"])
             # ONE kernel storing to the pinned buffers (see the module docstring; three launches were 25 us of a 0.6-ms search)
             index.copy_out_many([(s["d_h"], d_t), (s["i_h"], i_t)] + ([(s["bo_h"], bo_t)] if self.want_bo else []))
-            s["ev_out"].record(s_run)
+            if origin is not None:
+                origin.wait_stream(s_run)
+
+    def _stage(self, src, pinned):
+        import torch
+
+        if isinstance(src, torch.Tensor) and src.is_pinned():
+            return src                                   # already DMA-able: no staging copy
+        pinned.copy_(torch.from_numpy(np.ascontiguousarray(src, dtype=np.float32)) if isinstance(src, np.ndarray) else src)
+        return pinned
+
+    def _graph_for(self, s, qn_src, qs_src, s_run, index):
+        """The slot's captured batch for these pinned sources (built on first use: an eager batch first, so that the library has made
+        its allocations -- nothing may allocate or synchronise inside a capture).  With the MLP on the navigation stream the batch is
+        TWO graphs: (upload + MLP) replayed on the navigation stream and (scan + download) on the compute stream behind it -- graph
+        launches on one stream run strictly one after the other, so a single graph per batch would serialise the upload and the MLP
+        of batch i + 1 behind the scan of batch i (measured: 0.32 ms per 1 000-query batch instead of 0.20)."""
+        import torch
+
+        key = (qn_src.data_ptr(), 0 if qs_src is None else qs_src.data_ptr())
+        g = s["graphs"].get(key)
+        if g is None:
+            if not s["warm"]:
+                self._enqueue(s, qn_src, qs_src, s_run, index)
+                s["warm"] = True
+            torch.cuda.synchronize(self.dev)
+            if self.overlap:
+                ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga, stream=self.s_nav):
+                    s["qn_d"].copy_(qn_src, non_blocking=True)
+                    if not self.same:
+                        s["qs_d"].copy_(qs_src, non_blocking=True)
+                    self.index.set_stream(self.s_nav.cuda_stream)
+                    self.index.mlp_topk_device(s["qn_d"], self.nb, s["bo_d"])
+                self.index.set_stream(self.s_run.cuda_stream)
+                torch.cuda.synchronize(self.dev)
+                with torch.cuda.graph(gb, stream=self.s_run):
+                    self.index.scan_topk_device(s["qn_d"] if self.same else s["qs_d"], s["bo_d"], self.nb, self.k, s["d_d"], s["i_d"])
+                    self.index.copy_out_many([(s["d_h"], s["d_d"]), (s["i_h"], s["i_d"])] + ([(s["bo_h"], s["bo_d"])] if self.want_bo else []))
+                g = (ga, gb)
+            else:
+                g1 = torch.cuda.CUDAGraph()
+                cap = torch.cuda.Stream(self.dev)
+                with torch.cuda.graph(g1, stream=cap):
+                    self._enqueue(s, qn_src, qs_src, s_run, index, origin=cap)
+                g = (g1,)
+            s["graphs"][key] = g
+        return g
+
+    def capture(self, queries_nav, queries_search=None) -> None:
+        """Pre-builds the graphs of one pinned source batch for every slot (outside a timed region; `use_graph` only)."""
+        if not self.use_graph:
+            return
+        self.drain()
+        for n, s in enumerate(self.slots):
+            index, s_run = self.handles[n % len(self.handles)]
+            qn_src = self._stage(queries_nav, s["qn_h"])
+            qs_src = None if self.same else self._stage(queries_nav if queries_search is None else queries_search, s["qs_h"])
+            self._graph_for(s, qn_src, qs_src, s_run, index)
+
+    def submit(self, queries_nav, queries_search=None) -> int:
+        """Enqueues one batch (numpy arrays or pinned CPU torch tensors, [nq, d]); returns its ticket.
+        Blocks only if the slot's previous batch (`depth` submits ago) has not finished."""
+        import torch
+
+        s = self.slots[self.t % self.depth]
+        if s["busy"]:
+            s["ev_out"].synchronize()
+        s["busy"] = True
+        qn_src = self._stage(queries_nav, s["qn_h"])
+        qs_src = None if self.same else self._stage(queries_nav if queries_search is None else queries_search, s["qs_h"])
+        index, s_run = self.handles[self.t % len(self.handles)]
+        if self.use_graph:
+            g = self._graph_for(s, qn_src, qs_src, s_run, index)
+            if len(g) == 2:   # (upload + MLP) on the navigation stream, (scan + download) on the compute stream behind it
+                with torch.cuda.stream(self.s_nav):
+                    g[0].replay()
+                    s["ev_nav"].record(self.s_nav)
+            with torch.cuda.stream(s_run):
+                if len(g) == 2:
+                    s_run.wait_event(s["ev_nav"])
+                g[-1].replay()
+                s["ev_out"].record(s_run)
+        else:
+            self._enqueue(s, qn_src, qs_src, s_run, index)
+            with torch.cuda.stream(s_run):
+                s["ev_out"].record(s_run)
         self.t += 1
         return self.t - 1
 

@@ -137,6 +137,39 @@ class ShardedSearcher:
         self.calls_per_search = 2 if self.shard_inference else 1
         self._buf = None
         self._bo_loc = None
+        # time_collectives: every collective of a search is bracketed by two events on the current stream (device tensors) -- what a
+        # rank really WAITS for each exchange, the other ranks' lateness included; read with collective_ms() after a synchronize
+        self.time_collectives = False
+        self._coll = {"bucket_order_allgather": [], "result_allgather_merge": []}
+
+    def _timed(self, name, fn, on_cuda: bool):
+        if not self.time_collectives or self.world == 1:
+            return fn()
+        import time
+
+        import torch
+
+        if on_cuda:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = fn()
+            b.record()
+            self._coll[name].append((a, b))
+        else:
+            t0 = time.perf_counter()
+            out = fn()
+            self._coll[name].append((time.perf_counter() - t0) * 1e3)
+        return out
+
+    def collective_ms(self, reset: bool = True):
+        """{collective: mean exposed ms per search} since the last reset (call after torch.cuda.synchronize())."""
+        out = {}
+        for name, items in self._coll.items():
+            vals = [it if isinstance(it, float) else it[0].elapsed_time(it[1]) for it in items]
+            out[name] = round(float(np.mean(vals)), 4) if vals else None
+            if reset:
+                items.clear()
+        return out
 
     def _buffers(self, nq: int, nb: int, kout: int, dev):
         import torch
@@ -168,7 +201,7 @@ class ShardedSearcher:
         nq = qs_t.shape[0]
         kout = self.index.kout(nb, k)
         blk, out_d, out_i, _ = self._buffers(nq, nb, kout, qs_t.device)
-        bo = all_gather_rows(bo_loc, nq, self.world, self.group)
+        bo = self._timed("bucket_order_allgather", lambda: all_gather_rows(bo_loc, nq, self.world, self.group), bo_loc.is_cuda)
         self.index.scan_topk_device(qs_t, bo, nb, k, blk[0], blk[1], blk[2])
         return self._exchange(blk, out_d, out_i, bo, nq, kout)
 
@@ -178,12 +211,16 @@ class ShardedSearcher:
         if self.world == 1 and self.lib_comm is None:
             return blk[0].view(torch.float32), blk[1], bo
         if self.lib_comm is not None:
-            self.index.allgather_merge(self.lib_comm, self.rank, self.world, blk[0], blk[1], blk[2], out_d, out_i)
+            self._timed("result_allgather_merge",
+                        lambda: self.index.allgather_merge(self.lib_comm, self.rank, self.world, blk[0], blk[1], blk[2], out_d, out_i), blk.is_cuda)
             return out_d, out_i, bo
-        g = all_gather_blocks(blk, self.world, self.group)  # [world, 3, nq, kout]
-        plane = nq * kout
-        self.index.merge_gathered(g[0, 0], g[0, 1], g[0, 2], self.world, nq, kout, out_d, out_i,
-                                  world_stride=3 * plane)
+
+        def exchange():
+            g = all_gather_blocks(blk, self.world, self.group)  # [world, 3, nq, kout]
+            plane = nq * kout
+            self.index.merge_gathered(g[0, 0], g[0, 1], g[0, 2], self.world, nq, kout, out_d, out_i, world_stride=3 * plane)
+
+        self._timed("result_allgather_merge", exchange, blk.is_cuda)
         return out_d, out_i, bo
 
     def search(self, qn_t, qs_t, nb: int, k: int):

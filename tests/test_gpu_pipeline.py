@@ -56,3 +56,56 @@ def test_pipeline_equals_synchronous_search(oracle, name, depth, mode):
     np.testing.assert_array_equal(expect[0][1], io)
     np.testing.assert_array_equal(expect[0][0].astype(np.float64), do)
     idx.close()
+
+
+@pytest.mark.parametrize("name,mode", [("G3", "nav"), ("G6", "plain")])
+def test_pipeline_graph_replay_equals_eager(name, mode):
+    """use_graph: every batch is ONE hipGraph launch (upload, MLP, routing, scan, tail, download over three streams, captured once per
+    slot and pinned source).  Replays must return what the eager pipeline returns, batch after batch -- including the routing kernels'
+    call tag, which lives in device memory because a replay freezes kernel arguments (lmi_front.h)."""
+    from learnedmetricindex_amd import _capi
+    from learnedmetricindex_amd.pipeline import HostPipeline
+
+    g = load_golden(name)
+    Xn, Qn, Xs, Qs = inputs_for(name, g)
+    layers = layers_from(g)
+    nb, k = int(g["n_buckets"]), int(g["k"])
+    L = layers[-1][0].shape[0]
+    idx = _capi.Index(0)
+    idx.set_mlp(layers)
+    idx.set_buckets(Xs, g["data_prediction"][:, 0], L)
+    nq = 128
+    same = Xn.shape[1] == Xs.shape[1] and np.array_equal(Qn, Qs)
+    rs = np.random.RandomState(1)
+    sels = [np.sort(rs.choice(Qn.shape[0], nq, replace=False)) for _ in range(3)]
+    pinned = [(torch.from_numpy(np.ascontiguousarray(Qn[s_])).pin_memory(), torch.from_numpy(np.ascontiguousarray(Qs[s_])).pin_memory()) for s_ in sels]
+    out = {}
+    for use_graph in (False, True):
+        pipe = HostPipeline(idx, nq, Qn.shape[1], Qs.shape[1], nb, k, depth=2, same_queries=same, want_bucket_order=True,
+                            overlap_inference=mode == "nav", use_graph=use_graph)
+        assert pipe.use_graph == use_graph
+        for qn, qs in pinned:
+            pipe.capture(qn, qs)
+        got = []
+        for rep in range(9):   # every (slot, batch) pair several times: replays of the same graph with other batches in between
+            qn, qs = pinned[rep % 3]
+            t = pipe.submit(qn, qs)
+            d, i = pipe.result(t)
+            got.append((d.copy(), i.copy(), pipe.bucket_order(t).copy()))
+        # a pageable batch goes through the slot's staging buffer (its own graph)
+        t = pipe.submit(np.ascontiguousarray(Qn[sels[1]]), np.ascontiguousarray(Qs[sels[1]]))
+        d, i = pipe.result(t)
+        got.append((d.copy(), i.copy(), pipe.bucket_order(t).copy()))
+        pipe.drain()
+        out[use_graph] = got
+        if use_graph:
+            assert sum(len(s_["graphs"]) for s_ in pipe.slots) >= 6
+    for (d0, i0, b0), (d1, i1, b1) in zip(out[False], out[True]):
+        np.testing.assert_array_equal(i0, i1)
+        np.testing.assert_array_equal(d0, d1)
+        np.testing.assert_array_equal(b0, b1)
+    idx.set_stream(0)
+    d_ref, i_ref, _ = idx.search(np.ascontiguousarray(Qn[sels[1]]), np.ascontiguousarray(Qs[sels[1]]), nb, k)
+    np.testing.assert_array_equal(out[True][-1][1], i_ref)
+    np.testing.assert_array_equal(out[True][-1][0], d_ref)
+    idx.close()
