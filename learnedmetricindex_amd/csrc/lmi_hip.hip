@@ -283,8 +283,7 @@ extern "C" LMI_API int lmi_create(int device, lmi_index** out) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
 #define LMI_TL_ATTR(GV) \
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<GV>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_big_kernel<GV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<GV>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     LMI_TL_ATTR(1) LMI_TL_ATTR(2) LMI_TL_ATTR(3) LMI_TL_ATTR(4)
 #undef LMI_TL_ATTR
     *out = h;
@@ -1466,12 +1465,8 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
             Q.merge_pending = T.pending; Q.m_kout = kout; Q.m_out_d = d_dists; Q.m_out_id = d_ids; Q.m_out_key = d_keys;
             if (Q.ts) (void)tsp(h, ST_END);
             const int lds_s = RC_WAVES * tail_wave_lds(h->dp, G, true);
-            int wb = RC_WAVES;
-            while (wb > 1 && wb * tail_wave_lds(h->dp, G, false) > 160 * 1024 - 512) wb >>= 1;
-            const int lds_b = wb * tail_wave_lds(h->dp, G, false);
-            const int blocks = cdiv(nq, RC_WAVES), blocks_b = std::min(cdiv(nq, wb), h->num_cus);
-#define LMI_TL_LAUNCH(GV) { tail_kernel<GV><<<blocks, 64 * RC_WAVES, lds_s, h->stream>>>(Q, O, T); \
-                            tail_big_kernel<GV><<<blocks_b, 64 * wb, lds_b, h->stream>>>(Q, O, T); }
+            const int blocks = cdiv(nq, RC_WAVES);
+#define LMI_TL_LAUNCH(GV) { tail_kernel<GV><<<blocks, 64 * RC_WAVES, lds_s, h->stream>>>(Q, O, T); }
             if (G == 4) LMI_TL_LAUNCH(4) else if (G == 3) LMI_TL_LAUNCH(3) else if (G == 2) LMI_TL_LAUNCH(2) else LMI_TL_LAUNCH(1)
 #undef LMI_TL_LAUNCH
             HIPCHK(hipGetLastError());

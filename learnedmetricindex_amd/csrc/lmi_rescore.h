@@ -217,25 +217,15 @@ struct RcWave {
     }
 };
 
-// The re-rank proper, shared by rescore_kernel and tail_kernel (lmi_tail.h): the wave's survivors krow[0, off[G]) (absolute slab rows, slot after
-// slot) and its query are in LDS; rows streamed, canonical chains, then every slot's rank list.  LCOPY: the lists also go to the
-// wave's LDS copy rl_d / rl_i [G][KPB] (the caller merges them in the wave).  colv / fbv: the slots' columns and fallback flags.
-template <int G, bool SMALL, bool LCOPY>
-__device__ __forceinline__ void rescore_core(const RescoreParams& P, const RcWave<G, SMALL>& W, const int (&off)[G + 1], int p0, int lane,
-                                             const int (&colv)[G], const int (&fbv)[G], float* rl_d, unsigned* rl_i) {
-    constexpr int RINGB = RcWave<G, SMALL>::RINGB;
-    const int d = P.dp;   // the rows' pitch: the chain runs over the zero padding too (+0 * +0 added to the sum changes nothing)
-    unsigned char* mine = W.mine;
-    unsigned* krow = W.krow;
-    float* ksc = W.ksc;
-    const float FMAXV = 3.402823466e+38f;
-    const int total = off[G];
+// One batch of <= RC_ROWS chains: rows krow[base ..] (absolute slab rows, in LDS) streamed through the wave's chunk ring `mine`, lane r runs the
+// canonical chain of row base + r against the query at LDS byte address `qaddr`; scores -> ksc[base ..].  NP = LDS-DMA pieces per chunk that
+// hold rows of THIS batch (a wave re-scores ~13 rows since the bound is per query: 2 pieces instead of the 9 that cover 64 rows -- issuing the
+// unused ones was most of the kernel's time).  RINGB: bytes of the ring.
+template <int NP, int RINGB>
+__device__ __forceinline__ void rc_run_batch(const RescoreParams& P, unsigned char* mine, const unsigned* krow, float* ksc, unsigned qaddr,
+                                             int base, int total, int lane) {
+    const int d = P.dp;
     const int nchunks = (d + RC_CHUNK - 1) / RC_CHUNK;
-    const unsigned qaddr = (unsigned)reinterpret_cast<uintptr_t>(W.qs);
-    // One batch of <= RC_ROWS chains.  NP = LDS-DMA pieces per chunk that hold rows of THIS batch (a wave re-scores ~13 rows since
-    // the bound is per query: 2 pieces instead of the 9 that cover 64 rows -- issuing the unused ones was most of the kernel's time).
-    auto run_batch = [&](auto np_c, int base) {
-        constexpr int NP = decltype(np_c)::value;
         // the wave's RC_DEPTH x RC_BUF bytes of chunk buffers, cut into buffers of NP pieces: fewer rows -> MORE chunks in flight
         // (13 instead of 3 at NP = 2).  A wave of ~13 rows waited 24 x for a 2-deep pipeline of 128-byte row segments: latency,
         // not bandwidth (profiles/r03_pass2_experiments.txt, section 12).
@@ -256,11 +246,7 @@ __device__ __forceinline__ void rescore_core(const RescoreParams& P, const RcWav
             const int r = o / RC_PITCH;
             const int cb = o - r * RC_PITCH;
             const bool okl = r < nrows && cb < RC_CHUNK * 4;
-            int sl = 0;
             const int i = base + (okl ? r : 0);
-#pragma unroll
-            for (int t = 1; t < G; ++t) sl += i >= off[t] ? 1 : 0;
-            (void)sl;
             src[pc] = P.rows + (size_t)krow[i] * d + (okl ? cb / 4 : 0);
             colb[pc] = okl ? (unsigned)cb : 0u;
         }
@@ -318,13 +304,31 @@ __device__ __forceinline__ void rescore_core(const RescoreParams& P, const RcWav
             }
         }
         if (lane < nrows) ksc[base + lane] = acc;
-    };
-    for (int base = 0; base < total; base += RC_ROWS) {
-        const int np = (min(RC_ROWS, total - base) * RC_PITCH + 1023) / 1024;   // wave-uniform
-        if (np <= 2) run_batch(std::integral_constant<int, 2>{}, base);
-        else if (SMALL || (np <= 4 && RC_PIECES > 4)) run_batch(std::integral_constant<int, (RC_PIECES > 4 ? 4 : RC_PIECES)>{}, base);
-        else { if constexpr (!SMALL) run_batch(std::integral_constant<int, RC_PIECES>{}, base); }
-    }
+}
+// the batch at `base`, with as few pieces per chunk as its rows need (wave-uniform choice)
+template <bool SMALL>
+__device__ __forceinline__ void rc_stream_batch(const RescoreParams& P, unsigned char* mine, const unsigned* krow, float* ksc, unsigned qaddr,
+                                                int base, int total, int lane) {
+    constexpr int RINGB = SMALL ? RC_SMALL_RING : RC_DEPTH * RC_BUF;
+    const int np = (min(RC_ROWS, total - base) * RC_PITCH + 1023) / 1024;   // wave-uniform
+    if (np <= 2) rc_run_batch<2, RINGB>(P, mine, krow, ksc, qaddr, base, total, lane);
+    else if (SMALL || (np <= 4 && RC_PIECES > 4)) rc_run_batch<(RC_PIECES > 4 ? 4 : RC_PIECES), RINGB>(P, mine, krow, ksc, qaddr, base, total, lane);
+    else { if constexpr (!SMALL) rc_run_batch<RC_PIECES, RINGB>(P, mine, krow, ksc, qaddr, base, total, lane); }
+}
+
+// The re-rank proper, shared by rescore_kernel and tail_kernel (lmi_tail.h): the wave's survivors krow[0, off[G]) (absolute slab rows, slot after
+// slot) and its query are in LDS; rows streamed, canonical chains, then every slot's rank list.  LCOPY: the lists also go to the
+// wave's LDS copy rl_d / rl_i [G][KPB] (the caller merges them in the wave).  colv / fbv: the slots' columns and fallback flags.
+template <int G, bool SMALL, bool LCOPY>
+__device__ __forceinline__ void rescore_core(const RescoreParams& P, const RcWave<G, SMALL>& W, const int (&off)[G + 1], int p0, int lane,
+                                             const int (&colv)[G], const int (&fbv)[G], float* rl_d, unsigned* rl_i) {
+    unsigned char* mine = W.mine;   // (rows of pitch P.dp: the chain runs over the zero padding too -- +0 * +0 added to the sum changes nothing)
+    unsigned* krow = W.krow;
+    float* ksc = W.ksc;
+    const float FMAXV = 3.402823466e+38f;
+    const int total = off[G];
+    const unsigned qaddr = (unsigned)reinterpret_cast<uintptr_t>(W.qs);
+    for (int base = 0; base < total; base += RC_ROWS) rc_stream_batch<SMALL>(P, mine, krow, ksc, qaddr, base, total, lane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // rank lists: a survivor's position = the number of survivors of ITS slot that beat it by (score desc, row asc)

@@ -10,8 +10,8 @@
 //                       memory), rows streamed through the wave's LDS ring and re-scored by the canonical chain (rescore_core,
 //                       lmi_rescore.h), the slots' rank lists -> global memory AND the wave's LDS, merged there by (distance, rank,
 //                       position) = the reference's hstack + stable argsort (LearnedIndex.py:125-146) -> the caller's output rows.
-//   tail_big_kernel<G>  the queries with more survivors than the small ring holds (a list; none on most batches): the big-ring
-//                       re-rank of round 4, then the same merge in the wave.
+//                       A query with more survivors than the ring holds at once re-scores them in batches and folds each batch
+//                       into its slots' running ten best (no second launch).
 //   fallback_kernel     (lmi_prefilter.h) the flagged slots; the LAST flagged slot of a query to finish merges the query from the
 //                       rank lists in global memory (a per-query counter set by tail_kernel; agent-scope release / acquire around it).
 // Same arithmetic, same selection rule, same tie order: results are bit-identical to the five-launch form (LMI_TAIL=0 in the
@@ -30,7 +30,8 @@ struct TailParams {
 };
 
 // the wave's LDS behind the small / big re-rank layout: the rank lists' copy [G][KPB] distances, then ids
-__host__ __device__ inline int tail_wave_lds(int d, int G, bool small_form) { return (rc_wave_lds(d, G, small_form) + 15) / 16 * 16 + 2 * G * KPB * 4; }
+// (+ the running best lists of the many-survivor path: [G][KPB] scores, then rows)
+__host__ __device__ inline int tail_wave_lds(int d, int G, bool small_form) { return (rc_wave_lds(d, G, small_form) + 15) / 16 * 16 + 4 * G * KPB * 4; }
 
 // That + survivors of ONE slot (select_tail's arithmetic, lmi_rescore.h); survivors -> out_g[k] (global, k < RC_KEEP) and krow_l[k]
 // (LDS, k < cap_l) as absolute slab rows.  Returns the survivor count (wave-uniform; may exceed RC_KEEP: the caller flags the slot).
@@ -163,72 +164,96 @@ __global__ __launch_bounds__(64 * RC_WAVES, 3) void tail_kernel(RescoreParams P,
     }
     if (lane == 0) T.pending[q] = nflag;
     const int total = off[G];
-    if (total > RC_SMALL_ROWS) {   // more survivors than the small ring holds: tail_big_kernel takes the query (its lists are in global memory)
-        if (lane == 0) O.big[1 + atomicAdd(&O.big[0], 1)] = q;
-        return;
-    }
     if (total > 0) W.stage_query(P, q, lane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    rescore_core<G, true, true>(P, W, off, p0, lane, colv, fbv, rl_d, rl_i);
+    if (total <= RC_SMALL_ROWS) {
+        rescore_core<G, true, true>(P, W, off, p0, lane, colv, fbv, rl_d, rl_i);
+    } else {
+        // More survivors than the small ring holds at once (a few per cent of the queries at C2, none at most shapes; round 4 and the
+        // first form of this file passed them on to a second launch with a big ring -- 16-35 us per search, most of it the launch's
+        // own turn-around): batches of RC_SMALL_ROWS rows, re-read from the slots' survivor lists in global memory (written above by
+        // this wave; nobody else touches those lines), each batch's scores folded into the slots' running ten best.
+        float* best_s = reinterpret_cast<float*>(rl_i + G * KPB);
+        unsigned* best_r = reinterpret_cast<unsigned*>(best_s + G * KPB);
+        int nbest[G];
+#pragma unroll
+        for (int sl = 0; sl < G; ++sl) nbest[sl] = 0;
+        const unsigned qaddr = (unsigned)reinterpret_cast<uintptr_t>(W.qs);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the survivor stores above have left
+        for (int base = 0; base < total; base += RC_SMALL_ROWS) {
+            const int nrows = min(RC_SMALL_ROWS, total - base);
+            if (lane < nrows) {
+                const int e = base + lane;
+                int sl = 0;
+#pragma unroll
+                for (int t = 1; t < G; ++t) sl += e >= off[t] ? 1 : 0;
+                int lo = off[0];
+#pragma unroll
+                for (int t = 1; t < G; ++t) lo = sl == t ? off[t] : lo;
+                W.krow[lane] = __builtin_nontemporal_load(O.surv_row + (size_t)(p0 + sl) * RC_KEEP + (e - lo));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            rc_stream_batch<true>(P, W.mine, W.krow, W.ksc, qaddr, 0, nrows, lane);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // fold: per slot, its old best (<= 10) and its rows of this batch (<= 28) ranked by (score desc, row asc); the ten best stay
+#pragma unroll
+            for (int sl = 0; sl < G; ++sl) {
+                const int b_lo = max(off[sl], base) - base, b_hi = min(off[sl + 1], base + nrows) - base;   // the slot's rows of the batch
+                const int nbat = max(0, b_hi - b_lo), nold = nbest[sl], n = nold + nbat;                        // wave-uniform
+                if (nbat > 0) {
+                    float sc = -INFINITY;
+                    unsigned row = NOROW;
+                    if (lane < nold) { sc = best_s[sl * KPB + lane]; row = best_r[sl * KPB + lane]; }
+                    else if (lane < n) { sc = W.ksc[b_lo + lane - nold]; row = W.krow[b_lo + lane - nold]; }
+                    int pos = 0;
+                    for (int o = 0; o < n; ++o) {
+                        const float os = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc), o));
+                        const unsigned orr = (unsigned)__builtin_amdgcn_readlane((int)row, o);
+                        pos += better(os, orr, sc, row) ? 1 : 0;
+                    }
+                    if (lane < n && pos < KPB) { best_s[sl * KPB + pos] = sc; best_r[sl * KPB + pos] = row; }
+                    nbest[sl] = min(n, KPB);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        // the slots' rank lists from their ten best (rescore_core's last step)
+        if (lane < KPB) {
+#pragma unroll
+            for (int sl = 0; sl < G; ++sl) {
+                const int p = p0 + sl;
+                if (colv[sl] < 0 || fbv[sl]) continue;   // written above / recomputed by fallback_kernel
+                const int b = P.bucket_order[p];
+                const int rb0 = P.rb_start[b], n_b = P.nb_rows[b];
+                const int nreal = min(nbest[sl], n_b);
+                float dv;
+                unsigned iv;
+                if (lane < nreal) {
+                    const float sc = best_s[sl * KPB + lane];
+                    const unsigned row = best_r[sl * KPB + lane];
+                    dv = P.raw ? sc : sim_to_dist(sc, P.qn2, q);
+                    iv = P.raw ? row - (unsigned)rb0 * 32u : P.ids_slab[row];
+                } else {   // faiss padding (Q4)
+                    dv = P.raw ? -FMAXV : pad_dist(P.qn2);
+                    iv = P.raw ? NOROW : P.ids_slab[(size_t)rb0 * 32 + (n_b - 1)];
+                }
+                P.rank_d[(size_t)p * KPB + lane] = dv;
+                P.rank_id[(size_t)p * KPB + lane] = iv;
+                rl_d[sl * KPB + lane] = dv;
+                rl_i[sl * KPB + lane] = iv;
+            }
+        }
+    }
     if (nflag) return;   // fallback_kernel re-scores the flagged slot(s) and merges the query
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const float dv = lane < G * KPB ? rl_d[lane] : 0.0f;
     const unsigned iv = lane < G * KPB ? rl_i[lane] : 0u;
     merge_entries<G>(dv, iv, lane, P.raw, T.kout, (size_t)q, T.out_d, T.out_id, T.out_key);
-}
-
-// the queries tail_kernel passed on: big-ring re-rank (round 4's rescore_kernel<G, false>), then the merge in the wave
-template <int G>
-__global__ __launch_bounds__(64 * RC_WAVES, 1) void tail_big_kernel(RescoreParams P, SelectOut O, TailParams T) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char tl_smem[];
-    const int nbig = __builtin_amdgcn_readfirstlane(O.big[0]);
-    if (nbig == 0) return;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int nwv = (int)(blockDim.x >> 6);
-    const int dp = P.dp;
-    const float FMAXV = 3.402823466e+38f;
-    unsigned char* base = tl_smem + (size_t)wv * tail_wave_lds(dp, G, false);
-    const RcWave<G, false> W(base, dp);
-    float* rl_d = reinterpret_cast<float*>(base + (rc_wave_lds(dp, G, false) + 15) / 16 * 16);
-    unsigned* rl_i = reinterpret_cast<unsigned*>(rl_d + G * KPB);
-    for (int i = blockIdx.x * nwv + wv; i < nbig; i += (int)gridDim.x * nwv) {
-        const int q = O.big[1 + i], p0 = q * G;
-        int off[G + 1];
-        off[0] = 0;
-        int colv[G], fbv[G], nkv[G];
-#pragma unroll
-        for (int sl = 0; sl < G; ++sl) { colv[sl] = P.slot_col[p0 + sl]; fbv[sl] = P.fallback[p0 + sl]; nkv[sl] = P.nkeep[p0 + sl]; }
-        int nflag = 0;
-#pragma unroll
-        for (int sl = 0; sl < G; ++sl) {
-            off[sl + 1] = off[sl] + ((colv[sl] >= 0 && !fbv[sl]) ? nkv[sl] : 0);   // wave-uniform
-            nflag += fbv[sl];
-            if (colv[sl] < 0 && lane < KPB) {   // an unvisited slot's list (tail_kernel wrote the global copy)
-                rl_d[sl * KPB + lane] = P.raw ? -FMAXV : INFINITY;
-                rl_i[sl * KPB + lane] = P.raw ? NOROW : 0u;
-            }
-        }
-#pragma unroll
-        for (int sl = 0; sl < G; ++sl) {
-            const int nk = off[sl + 1] - off[sl];
-            for (int e = lane; e < nk; e += 64) W.krow[off[sl] + e] = O.surv_row[(size_t)(p0 + sl) * RC_KEEP + e];
-        }
-        W.stage_query(P, q, lane);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        rescore_core<G, false, true>(P, W, off, p0, lane, colv, fbv, rl_d, rl_i);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (!nflag) {
-            const float dv = lane < G * KPB ? rl_d[lane] : 0.0f;
-            const unsigned iv = lane < G * KPB ? rl_i[lane] : 0u;
-            merge_entries<G>(dv, iv, lane, P.raw, T.kout, (size_t)q, T.out_d, T.out_id, T.out_key);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the wave's LDS lists are rewritten by its next query
-        __builtin_amdgcn_wave_barrier();
-    }
 }
 
 }  // namespace lmi
