@@ -212,7 +212,8 @@ class Workload:
         pipe = HostPipeline(eng, nq, d, d, nb, k, depth=int(os.environ.get("LMI_PIPE_DEPTH", "2")), same_queries=True, want_bucket_order=True,
                             overlap_inference=(ov == "1") if world == 1 else os.environ.get("LMI_PIPE_OVERLAP_SHARDED", "0") == "1",
                             two_handles=ov == "2", sharded=searcher if world > 1 else None,
-                            use_graph=world == 1 and os.environ.get("LMI_PIPE_GRAPH", "0") == "1")
+                            use_graph=world == 1 and os.environ.get("LMI_PIPE_GRAPH", "0") == "1",
+                            direct_out=world == 1 and os.environ.get("LMI_PIPE_DIRECT", "1") == "1")   # (dists, ids) stored straight into the pinned host buffers
         for qh in q_hosts:   # LMI_PIPE_GRAPH=1: hipGraph replay (opt-in: measured SLOWER than eager submission on ROCm 7.2 -- C1 0.27 against 0.22 ms
             pipe.capture(qh)  # per batch: two graph launches cost more than the dozen eager ones); the graphs are built here, untimed
         # (world > 1: the rank's MLP slice of batch i+1 beside the scan of batch i is opt-in -- it could only be rehearsed with

@@ -38,7 +38,8 @@ import numpy as np
 class HostPipeline:
     def __init__(self, index, nq: int, d_nav: int, d_search: int, nb: int, k: int = 10, depth: int = 2,
                  device: Optional[int] = None, same_queries: bool = False, want_bucket_order: bool = False,
-                 search_fn=None, overlap_inference: bool = True, two_handles: bool = False, sharded=None, use_graph: bool = False):
+                 search_fn=None, overlap_inference: bool = True, two_handles: bool = False, sharded=None, use_graph: bool = False,
+                 direct_out: bool = False):
         """`search_fn(qn_dev, qs_dev) -> (dists_t, ids_t, bucket_order_t)`: optional replacement of the single-GPU
         `lmi_search` call, run on the compute stream (the bucket-sharded searcher of sharded.py, whose collectives
         then run on that stream too); its output tensors may be reused by its next call."""
@@ -77,6 +78,9 @@ class HostPipeline:
         f32, i32 = torch.float32, torch.int32
         mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)   # noqa: E731
         pin = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)   # noqa: E731
+        # direct_out: the search's last kernels store (dists, ids) straight into the pinned host buffers (device-accessible memory) -- no
+        # download kernel behind the search (1 MB over PCIe: 18 us of a 0.56-ms search at 10M x 45); single-GPU forms only
+        self.direct_out = bool(direct_out) and search_fn is None and sharded is None
         # hipGraph replay: single-GPU forms only (a collective inside a capture is RCCL's business, not rehearsed here)
         self.use_graph = bool(use_graph) and search_fn is None and sharded is None and not self.two
         self.slots = []
@@ -118,25 +122,28 @@ class HostPipeline:
                 self.sharded.route_local(s["qn_d"], self.nb, s["bo_loc"])
                 s["ev_nav"].record(self.s_nav)
             self.index.set_stream(self.s_run.cuda_stream)
+        od, oi = ("d_h", "i_h") if self.direct_out else ("d_d", "i_d")   # the search's output rows: pinned host buffers or device buffers
         with torch.cuda.stream(s_run):
             s_run.wait_event(s["ev_nav"] if (self.overlap or self.sh_overlap) else s["ev_in"])
             if self.sh_overlap:
                 d_t, i_t, bo_t = self.sharded.search_routed(s["qn_d"] if self.same else s["qs_d"], s["bo_loc"], self.nb, self.k)
             elif self.two:
                 index.search_device(s["qn_d"], s["qn_d"] if self.same else s["qs_d"], self.nb, self.k,
-                                    s["d_d"], s["i_d"], None, s["bo_d"])
-                d_t, i_t, bo_t = s["d_d"], s["i_d"], s["bo_d"]
+                                    s[od], s[oi], None, s["bo_d"])
+                d_t, i_t, bo_t = s[od], s[oi], s["bo_d"]
             elif self.overlap:
-                self.index.scan_topk_device(s["qn_d"] if self.same else s["qs_d"], s["bo_d"], self.nb, self.k, s["d_d"], s["i_d"])
-                d_t, i_t, bo_t = s["d_d"], s["i_d"], s["bo_d"]
+                self.index.scan_topk_device(s["qn_d"] if self.same else s["qs_d"], s["bo_d"], self.nb, self.k, s[od], s[oi])
+                d_t, i_t, bo_t = s[od], s[oi], s["bo_d"]
             elif self.search_fn is None:
                 self.index.search_device(s["qn_d"], s["qn_d"] if self.same else s["qs_d"], self.nb, self.k,
-                                         s["d_d"], s["i_d"], None, s["bo_d"])
-                d_t, i_t, bo_t = s["d_d"], s["i_d"], s["bo_d"]
+                                         s[od], s[oi], None, s["bo_d"])
+                d_t, i_t, bo_t = s[od], s[oi], s["bo_d"]
             else:
                 d_t, i_t, bo_t = self.search_fn(s["qn_d"], s["qn_d"] if self.same else s["qs_d"])
             # ONE kernel storing to the pinned buffers (see the module docstring; three launches were 25 us of a 0.6-ms search)
-            index.copy_out_many([(s["d_h"], d_t), (s["i_h"], i_t)] + ([(s["bo_h"], bo_t)] if self.want_bo else []))
+            pairs = ([] if self.direct_out else [(s["d_h"], d_t), (s["i_h"], i_t)]) + ([(s["bo_h"], bo_t)] if self.want_bo else [])
+            if pairs:
+                index.copy_out_many(pairs)
             if origin is not None:
                 origin.wait_stream(s_run)
 

@@ -10,10 +10,14 @@ from helpers import inputs_for, layers_from, load_golden
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name,depth,mode", [("G3", 2, "nav"), ("G6", 3, "nav"), ("G4", 1, "nav"), ("G3", 2, "plain"), ("G6", 2, "twin")])
+@pytest.mark.parametrize("name,depth,mode", [("G3", 2, "nav"), ("G6", 3, "nav"), ("G4", 1, "nav"), ("G3", 2, "plain"), ("G6", 2, "twin"),
+                                             ("G3", 2, "nav+direct"), ("G4", 2, "plain+direct")])
 def test_pipeline_equals_synchronous_search(oracle, name, depth, mode):
     """mode: "nav" (default) -- the next batch's MLP on a navigation stream beside the current scan; "plain" -- one lmi_search
-    per batch; "twin" -- batches alternate between the handle and a clone of it (lmi_clone_view: same index memory)."""
+    per batch; "twin" -- batches alternate between the handle and a clone of it (lmi_clone_view: same index memory);
+    "+direct" -- the search's last kernels store (dists, ids) straight into the pinned host buffers (no download kernel)."""
+    direct = mode.endswith("+direct")
+    mode = mode.split("+")[0]
     from learnedmetricindex_amd import _capi
     from learnedmetricindex_amd.pipeline import HostPipeline
 
@@ -28,7 +32,8 @@ def test_pipeline_equals_synchronous_search(oracle, name, depth, mode):
     nq = 96
     same = Xn.shape[1] == Xs.shape[1] and np.array_equal(Qn, Qs)
     pipe = HostPipeline(idx, nq, Qn.shape[1], Qs.shape[1], nb, k, depth=depth, same_queries=same, want_bucket_order=True,
-                        overlap_inference=mode == "nav", two_handles=mode == "twin")
+                        overlap_inference=mode == "nav", two_handles=mode == "twin", direct_out=direct)
+    assert pipe.direct_out == direct
     assert pipe.calls_per_batch == (2 if mode == "nav" else 1) and len(pipe.handles) == (2 if mode == "twin" else 1)
     rs = np.random.RandomState(0)
     batches = [np.sort(rs.choice(Qn.shape[0], nq, replace=False)) for _ in range(7)]
