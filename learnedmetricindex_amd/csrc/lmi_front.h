@@ -9,8 +9,9 @@
 //                      ITS bucket, primary and other (RouteArrays) -- ballots, no atomics; publishes the count as a tagged 8-byte granule
 //                      and sums the granules of the LOWER buckets (they are dispatched first and wait for nobody) into the bucket's
 //                      first col-block -- the one grid-wide quantity routing needs, without a launch boundary, a contended atomic or
-//                      anything to reset; walks again and hands every slot of the bucket its column in a FIXED order (wave's query
-//                      range, step, rank, lane): slot_col[], colmap[]; writes m[b], m0[b], cb_start[b].
+//                      anything to reset; then hands every slot of the bucket its column in a FIXED order (wave's query range, step,
+//                      rank, lane; from the waves' LDS lists of the slots found, or by a second walk when a list ran over):
+//                      slot_col[], colmap[]; writes m[b], m0[b], cb_start[b].
 //   pack_kernel<..>    a block per col-block (32 columns): each column's query row is read ONCE, coalesced (8..64 lanes per row, all of
 //                      a wave's rows in flight together): max |q| -> the query's power-of-two scale -> fp16 image -> ||q'||, ||q^ - q'||
 //                      -> eps' of the slot (the arithmetic of query_norm_kernel / slot_bound_kernel, lmi_prefilter.h); the fp16 values go
@@ -34,6 +35,7 @@ constexpr int FR_MAX_L = 512;            // buckets: one 1 024-thread block per 
                                          // (2 000 leaves: the separate kernels' 115 us are faster)
 constexpr int FR_MAX_SLOTS = 1 << 17;    // slots per batch: every block of route_kernel walks all of them twice
 constexpr int FR_SLICE_G = 48;           // k16-groups of a col-block staged at a time (48 KiB: d <= 768 in one slice)
+constexpr int FR_LIST = 512;             // slots of its bucket a wave of route_kernel keeps in LDS (more: the bucket's block walks a second time)
 constexpr int FP_THREADS = 512, FP_WAVES = FP_THREADS / 64;    // pack_kernel
 constexpr int FR_MAX_D = 64 * 4 * 8;     // a row's chunks fit a wave's registers (4 per lane)
 static_assert(FR_SLICE_G % 2 == 0, "the 16 x 32 fragment shape pairs k16-groups");
@@ -129,15 +131,26 @@ struct FrChunk {
 // One walk over the whole batch's bucket_order by the block of bucket b, in the FIXED order (wave's query range, 64-query step, rank,
 // lane).  COUNT: the wave's primary / other slots of the bucket -> own0 / own1.  !COUNT: every slot of the bucket gets its column
 // (c0 / c1: the wave's first primary / other position; n0: the bucket's primary slots) -> slot_col[], colmap[].
+// COUNT also records the bucket's slots in discovery order into the wave's LDS list `wl` (slot | other << 31; n_list counts them, past
+// `cap` too): the caller then places them from the list and needs no second walk unless a wave's list ran over.
 template <int NB, bool COUNT>
-__device__ __forceinline__ void fr_walk(const FrontParams& P, const int* nbr, int b, int nbv, int lane, int q0w, int q1w, int& c0, int& c1, int n0, int col_base) {
+__device__ __forceinline__ void fr_walk(const FrontParams& P, const int* nbr, int b, int nbv, int lane, int q0w, int q1w, int& c0, int& c1, int n0, int col_base,
+                                        unsigned* wl = nullptr, int cap = 0, int* n_list = nullptr) {
     const int L = P.L;
     const bool use_primary = P.R.primary_nb > 0;
     const unsigned long long lt = (1ull << lane) - 1ull;
+    int nl = 0;
     auto slot = [&](int q, int r, int br, int rows, bool big) __attribute__((always_inline)) {
         const bool other = use_primary && big;
         const bool mine = rows > 0 && br == b;
         const unsigned long long bal0 = __ballot(mine && !other), bal1 = __ballot(mine && other);
+        if (COUNT && wl) {
+            if (mine) {
+                const int e = nl + (int)__popcll((bal0 | bal1) & lt);
+                if (e < cap) wl[e] = (unsigned)(q * nbv + r) | (other ? 0x80000000u : 0u);
+            }
+            nl += (int)__popcll(bal0 | bal1);
+        }
         if (!COUNT && mine) {
             const int cpos = other ? n0 + c1 + (int)__popcll(bal1 & lt) : c0 + (int)__popcll(bal0 & lt);
             P.slot_col[(size_t)q * nbv + r] = col_base + cpos;
@@ -175,6 +188,7 @@ __device__ __forceinline__ void fr_walk(const FrontParams& P, const int* nbr, in
             }
         }
     }
+    if (COUNT && n_list) *n_list = nl;
 }
 
 // ---- launch 1: a block per bucket -- which slots go to the bucket, in which columns --------------------------------------------
@@ -182,6 +196,8 @@ template <int NB>
 __global__ __launch_bounds__(FR_THREADS) void route_kernel(FrontParams P) {
     extern __shared__ __attribute__((aligned(16))) char fr_smem[];
     __shared__ int misc[2 * FR_WAVES + 2];
+    __shared__ unsigned wlist[FR_WAVES][FR_LIST];   // a wave's slots of the bucket, in discovery order
+    __shared__ int over_s;
     const int L = P.L, nq = P.nq, nb = NB > 0 ? NB : P.nb;
     const unsigned epoch_v = *P.epoch_dev;
     int* nbr = reinterpret_cast<int*>(fr_smem);
@@ -201,10 +217,12 @@ __global__ __launch_bounds__(FR_THREADS) void route_kernel(FrontParams P) {
     __syncthreads();
     const int Qw = (((nq + FR_WAVES - 1) / FR_WAVES) + 63) / 64 * 64;
     const int q0w = w * Qw, q1w = min(nq, q0w + Qw);
-    int own0 = 0, own1 = 0;   // wave-uniform
-    fr_walk<NB, true>(P, nbr, b, nb, lane, q0w, q1w, own0, own1, 0, 0);
+    int own0 = 0, own1 = 0, n_mine = 0;   // wave-uniform
+    if (tid == 0) over_s = 0;
+    fr_walk<NB, true>(P, nbr, b, nb, lane, q0w, q1w, own0, own1, 0, 0, wlist[w], FR_LIST, &n_mine);
     if (lane == 0) { misc[w] = own0; misc[FR_WAVES + w] = own1; }
     __syncthreads();
+    if (lane == 0 && n_mine > FR_LIST) over_s = 1;   // (after the barrier that orders thread 0's reset; read behind the next one)
     FR_DBG(dbg_base, 1);
     int base0 = 0, base1 = 0, n0 = 0, n1 = 0;
     for (int i = 0; i < FR_WAVES; ++i) {
@@ -249,7 +267,25 @@ __global__ __launch_bounds__(FR_THREADS) void route_kernel(FrontParams P) {
     for (int i = tid; i < ncb; i += FR_THREADS) P.cb_bucket[cbs + i] = b;
     for (int i = m_b + tid; i < ncb * 32; i += FR_THREADS) P.colmap[cbs * 32 + i] = -1;   // the idle columns of the last col-block
     int c0 = base0, c1 = base1;
-    fr_walk<NB, false>(P, nbr, b, nb, lane, q0w, q1w, c0, c1, n0, cbs * 32);
+    if (over_s) {   // a wave found more slots than its list holds (a skewed batch): the placing walk
+        fr_walk<NB, false>(P, nbr, b, nb, lane, q0w, q1w, c0, c1, n0, cbs * 32);
+    } else {        // from the lists: the same order, hence the same columns, as the placing walk
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        for (int e0 = 0; e0 < n_mine; e0 += 64) {
+            const int e = e0 + lane;
+            const unsigned ent = e < n_mine ? wlist[w][e] : 0u;
+            const bool live = e < n_mine, other = (ent >> 31) != 0u;
+            const unsigned long long bal0 = __ballot(live && !other), bal1 = __ballot(live && other);
+            if (live) {
+                const int p = (int)(ent & 0x7fffffffu);
+                const int cpos = other ? n0 + c1 + (int)__popcll(bal1 & lt) : c0 + (int)__popcll(bal0 & lt);
+                P.slot_col[p] = cbs * 32 + cpos;
+                P.colmap[cbs * 32 + cpos] = p / nb;
+            }
+            c0 += (int)__popcll(bal0);
+            c1 += (int)__popcll(bal1);
+        }
+    }
     FR_DBG(dbg_base, 2);
 }
 

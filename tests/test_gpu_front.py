@@ -70,6 +70,7 @@ SHAPES = [
     (7, 9_000, 33, 40, 257, 8, 15, dict(unit=False, invalid_frac=0.02)),
     (8, 5_000, 128, 5, 64, 1, 10, {}),              # a single rank: returned unmerged
     (9, 15_000, 96, 300, 900, 5, 10, dict(empty=(0, 299))),
+    (10, 30_000, 32, 2, 12_000, 2, 10, {}),         # 12 000 slots per bucket: a wave's LDS list of its bucket's slots runs over -> the placing walk
 ]
 
 
