@@ -185,6 +185,8 @@ struct lmi_index {
     double wall_khz = 100000.0;
     DevBuf fr_dbg;                // LMI_FR_DEBUG=1: route_kernel's / pack_kernel's phase stamps (lmi_debug_peek "fr_dbg")
     DevBuf cb_alloc, cb_bucket;   // lmi_front.h: the call-tagged granules of route_kernel (zero at allocation) and the col-blocks' buckets
+    unsigned* h_oflag = nullptr;  // a word of pinned host memory (device-visible): "the last batch used the overflow log" (RescoreParams::host_oflag)
+    int overflow_armed = 0;       // calls for which overflow_rebound_kernel + pass 2's redo launch stay in the sequence (re-armed by h_oflag)
     bool fr_bump_pending = false; // route_kernel was launched and the launch that bumps the granules' tag (bound_merge2_kernel) not yet: a call that
                                   // failed in between is repaired by a bump launch of its own at the next call
     bool use_tail = true;         // tail_kernel (lmi_tail.h): selection + re-rank + rank merge in one wave per query (LMI_TAIL=0: the five launches of round 4)
@@ -308,6 +310,7 @@ extern "C" LMI_API int lmi_destroy(lmi_index* h) {
                       &h->slot_col, &h->colmap, &h->qfrag, &h->grp, &h->col_thr, &h->slab16, &h->rowmajor, &h->xscale, &h->xmaxbits, &h->bnorm, &h->bdelta, &h->qdelta, &h->qnorm, &h->qscale, &h->qfrag16, &h->eps2, &h->cand_cnt, &h->cand_row, &h->cand_s, &h->fallback, &h->pf_bound, &h->nkeep, &h->redo, &h->part_score, &h->part_row, &h->rank_d,
                       &h->rank_id, &h->out_d, &h->out_id, &h->out_key, &h->x_log, &h->x_ext, &h->x_off, &h->fb_list, &h->grp_scratch, &h->ts_ring, &h->fr_dbg, &h->cb_alloc, &h->cb_bucket};
     for (DevBuf* b : bufs) b->release();
+    if (h->h_oflag) (void)hipHostFree(h->h_oflag);
     for (auto& m : h->node_models) { for (auto& b : m.Wf) b.release(); for (auto& b : m.bias) b.release(); }
     DevBuf* nav[] = {&h->d_models, &h->d_child_offset, &h->d_child_model, &h->d_child_bucket, &h->pq_prob, &h->pq_ent, &h->pq_len, &h->surv_row, &h->rs_flag, &h->rs_active, &h->gather_send, &h->gather_recv, &h->aug_rows, &h->q_aug, &h->qn2,
                      &h->nav_len, &h->nav_slab, &h->nav_ent, &h->nav_count, &h->nav_colq, &h->nav_active};
@@ -350,6 +353,8 @@ extern "C" LMI_API int lmi_clone_view(lmi_index* h, lmi_index** out) {
     for (DevBuf* b : own) b->forget();
     c->ts_set = nullptr;
     memset(c->ts_mask, 0, sizeof(c->ts_mask));
+    c->h_oflag = nullptr;
+    c->overflow_armed = 0;
     c->x_cap = 0;
     memset(c->ev_ring, 0, sizeof(c->ev_ring));
     memset(c->valid_ring, 0, sizeof(c->valid_ring));
@@ -1391,7 +1396,20 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         F.ts_start = nullptr;
         F.ts_end_cell = nullptr;
         CHK(record(h, 6));
-        if (h->pf_redo && !h->debug_emit_all) {
+        // the fused tail (lmi_tail.h): a wave per query selects, re-ranks and merges -- n_buckets <= 4 (one wave holds the query's slots)
+        use_tail = rescore_is_streamed(h) && h->use_tail && nb <= 4 && RC_WAVES * tail_wave_lds(h->dp, nb, true) <= 64 * 1024;
+        // The overflow machinery (overflow_rebound_kernel + pass 2's redo launch: two launches that return at once on ordinary batches,
+        // 11 us of a 0.2-0.5 ms search) stays OUT of the fused-tail sequence until a batch needs it: fallback_kernel then picks a flagged
+        // column's entries out of the unsorted log (or, log full, scans the bucket: always correct) and raises a flag in pinned host memory;
+        // the next 1 000 calls run with the machinery in.  The five-launch tail keeps it always.
+        if (use_tail && !h->h_oflag) {
+            HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->h_oflag), 64, hipHostMallocMapped));
+            *h->h_oflag = 0u;
+        }
+        if (use_tail && *reinterpret_cast<volatile unsigned*>(h->h_oflag) != 0u) { h->overflow_armed = 1000; *h->h_oflag = 0u; }
+        const bool overflow_sorted = h->pf_redo && !h->debug_emit_all && (!use_tail || h->overflow_armed > 0);
+        if (use_tail && h->overflow_armed > 0) --h->overflow_armed;
+        if (overflow_sorted) {
             // columns whose candidate buffer overflowed get the 10th best stored score as their bound and one more run of pass 2
             // over their buckets (a launch that returns at once when there is none: ~15 us per batch; lmi_prefilter.h)
             unsigned* rc = h->redo.as<unsigned>();
@@ -1432,7 +1450,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         Q.nkeep = h->nkeep.as<int>();
         Q.fb_count = reinterpret_cast<int*>(fbw);
         Q.fb_list = reinterpret_cast<int*>(fbw + 8);
-        const bool sorted_overflow = h->pf_redo && !h->debug_emit_all;   // (overflow_rebound_kernel hands out the ranges)
+        const bool sorted_overflow = overflow_sorted;   // (overflow_rebound_kernel hands out the ranges)
         Q.x_fail = fbw + 1;
         Q.x_off = sorted_overflow ? h->x_off.as<unsigned>() : nullptr;
         Q.x_ext = h->x_ext.as<uint2>();
@@ -1444,8 +1462,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         Q.p2_end = p2_end_cell;
         if (Q.ts) { (void)tsp(h, ST_TAIL); (void)tsp(h, ST_P2END); (void)tsp(h, ST_FB); }
         Q.merge_pending = nullptr; Q.m_kout = 0; Q.m_out_d = nullptr; Q.m_out_id = nullptr; Q.m_out_key = nullptr;
-        // the fused tail (lmi_tail.h): a wave per query selects, re-ranks and merges -- n_buckets <= 4 (one wave holds the query's slots)
-        use_tail = rescore_is_streamed(h) && h->use_tail && nb <= 4 && RC_WAVES * tail_wave_lds(h->dp, nb, true) <= 64 * 1024;
+        Q.host_oflag = use_tail ? h->h_oflag : nullptr;
 #ifndef LMI_ABL_NOEMIT  // timing-only ablation builds emit nothing: no re-rank, no fallback
         if (use_tail) {
             const int G = nb, groups = nq;

@@ -418,6 +418,9 @@ struct RescoreParams {
     unsigned long long* ts;               // nullable: the call's stamp set (lmi_kernels.h)
     const unsigned long long* p2_end;     // pass 2's end cell: the selection kernel copies it to ST_P2END
     // the fused tail (lmi_tail.h; all null / 0 on the five-launch route): fallback_kernel merges a query once its last flagged slot is re-scored
+    unsigned* host_oflag;                 // nullable: a word of PINNED HOST memory fallback_kernel sets when this batch put candidates into the overflow log
+                                          // (or filled it): the host then arms the sort-by-column machinery (overflow_rebound_kernel + pass 2's redo
+                                          // launch) for its next calls -- two launches every batch would otherwise pay for (lmi_hip.hip, scan_enqueue)
     int* merge_pending;                   // [nq] flagged slots of the query not yet re-scored (tail_kernel writes it for every query)
     int m_kout;
     float* m_out_d;                       // [nq][kout]
@@ -764,6 +767,7 @@ __global__ __launch_bounds__(256) void fallback_kernel(RescoreParams P) {
     __shared__ unsigned fr[256 * KPB];
     const int tid = threadIdx.x, lane = tid & 63;
     if (P.ts) ts_first(P.ts + ST_FB);
+    if (P.host_oflag && blockIdx.x == 0 && tid == 0 && (*P.x_head > 0u || P.x_fail[0] != 0u)) *P.host_oflag = 1u;
     // the flagged slots are on a list (select_kernel / the re-rank append): the blocks stride over it -- one block per slot at a
     // time, every block of the grid busy when thousands of slots are flagged (duplicate-heavy data); an empty list costs one
     // round of blocks reading the count
@@ -785,6 +789,9 @@ __global__ __launch_bounds__(256) void fallback_kernel(RescoreParams P) {
     const unsigned ccnt = ccol >= 0 ? P.cand_cnt[ccol] : 0xffffffffu;
     const int launch = (P.redo_col && ccol >= 0 && P.redo_col[ccol]) ? 1 : 0;   // which pass-2 launch filled the column last
     const bool in_table = ccol >= 0 && ccnt > (unsigned)PF_CAP && P.x_off != nullptr && launch == 0 && P.x_fail[0] == 0u;
+    // The log was NOT sorted by column this batch (the machinery is armed only after a batch that needed it: host_oflag): the column's
+    // entries are picked out of the log as it lies -- complete as long as the log did not run full; every flagged slot reads the whole log.
+    const bool in_log = ccol >= 0 && ccnt > (unsigned)PF_CAP && P.x_off == nullptr && P.x_log != nullptr && P.x_cap != 0u && P.x_fail[0] == 0u;
     auto consider = [&](unsigned row) {
         const float s = exact_score(P.rows, (size_t)rb0 * 32 + row, qv, P.d, P.dp);
         if (better(s, row, v[KPB - 1], id[KPB - 1])) {  // candidates come in no order: ties by row here
@@ -798,12 +805,18 @@ __global__ __launch_bounds__(256) void fallback_kernel(RescoreParams P) {
             if (better(s, row, v[0], id[0])) { v[0] = s; id[0] = row; }
         }
     };
-    if (ccnt <= (unsigned)PF_CAP || in_table) {
+    if (ccnt <= (unsigned)PF_CAP || in_table || in_log) {
         const unsigned* cr = P.cand_row + (size_t)ccol * PF_CAP;
         for (unsigned it = tid; it < min(ccnt, (unsigned)PF_CAP); it += 256) consider(cr[it]);
         if (in_table) {
             const uint2* ext = P.x_ext + P.x_off[ccol];
             for (unsigned e = tid; e < ccnt - (unsigned)PF_CAP; e += 256) consider(ext[e].x);
+        } else if (in_log) {
+            const unsigned n_log = min(*P.x_head, P.x_cap);
+            for (unsigned e = tid; e < n_log; e += 256) {
+                const uint4 en = P.x_log[e];
+                if (en.x == (unsigned)ccol) consider(en.z);
+            }
         }
     } else {
     if (tid == 0) atomicAdd(P.fb_count + 5, 1);   // (statistics: slots that scan their whole bucket)

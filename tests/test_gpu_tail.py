@@ -122,3 +122,27 @@ def test_tail_l2_and_raw_knn(capi, oracle):
     Do, Io = oracle.knn_ip(Q[:64], X[:5000], 10)
     np.testing.assert_array_equal(I, Io)
     np.testing.assert_array_equal(D, Do)
+
+
+def test_overflow_machinery_arms_itself_after_a_batch_that_needed_it(capi):
+    """The sort-by-column machinery of the overflow log (overflow_rebound_kernel + pass 2's redo launch) is NOT in the fused tail's launch
+    sequence until a batch has put candidates into the log: that batch's flagged slots pick their entries out of the unsorted log, a flag in
+    pinned host memory arms the machinery, and the next calls on the handle run with it.  Every call must return the all-f32 answer."""
+    X, lab, L, Q, order = dup_data(9, 64, 1500, 3, 0.0)          # 1 500 exact copies near three queries: far past a column's 1 024 buffer entries
+    Xn, labn, Qn, ordern = make(41, 20_000, 64, L, 300, 4)         # an ordinary batch on the same handle afterwards
+    idx = capi.Index(0, chunk_rows=2048)
+    idx.set_buckets(X, lab, L)
+    ref = capi.Index(0, chunk_rows=2048, prefilter=False)
+    ref.set_buckets(X, lab, L)
+    d_ref, i_ref = ref.scan_topk(Q, order, 10)
+    seen = []
+    for call in range(3):                                           # call 0: unsorted log; calls 1, 2: the armed machinery (sorted log)
+        d, i = idx.scan_topk(Q, order, 10)
+        st = idx.debug_peek("pf_fallback", 32).view(np.uint32)
+        np.testing.assert_array_equal(i, i_ref)
+        np.testing.assert_array_equal(d, d_ref)
+        assert st[1] == 0 and st[5] == 0 and st[3] > 0, st         # log not full, nobody scanned a whole bucket, entries were logged
+        seen.append(int(st[4]))                                     # entries sorted by column: 0 on the unarmed call
+    assert seen[0] == 0 and seen[1] > 0 and seen[2] > 0, seen
+    ref.close()
+    idx.close()
