@@ -1001,8 +1001,8 @@ def main():
             torch.cuda.empty_cache()
             ocfg = dict(CONFIGS[cname])
             wo = Workload(args, ocfg, dev, rank, world, local_rank, tag=cname)
-            osteps = max(10, args.steps)
-            ro = wo.run(osteps, 3, measure_resident=False)
+            osteps = max(60, 3 * args.steps)   # (a step is 0.2-0.6 ms: 20 steps are 5-10 ms of wall clock, too few to average the host's jitter)
+            ro = wo.run(osteps, 8, measure_resident=False)
             oroof, _, _ = dominant_roofline(args, ocfg, ro, wo.sizes, wo.owner, rank, _capi)
             pmc_replay(oroof, os.path.join(ROOT, "profiles", f"scan_pmc_{cname}.json"), "bench.py --config " + cname)
             others[cname] = {"workload": f"{ocfg['n']}x{ocfg['d']}, {ocfg['leaves']} leaves, top-{ocfg['nb']}, {ocfg['nq']}-query batch",
