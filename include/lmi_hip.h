@@ -184,6 +184,16 @@ LMI_API int lmi_merge_gathered(lmi_index *h, const float *gathered_dists, const 
 LMI_API int lmi_copy_out(lmi_index *h, void *dst, const void *src, int64_t bytes);
 /* Up to 4 such copies as ONE launch (dists, ids and the bucket order of a batch: three launches were 25 us of a 0.6-ms search). */
 LMI_API int lmi_copy_out_many(lmi_index *h, int n, void *const *dst, const void *const *src, const int64_t *bytes);
+/* One batch of a host-in -> host-out pipeline as ONE call (learnedmetricindex_amd/pipeline.py: a dozen Python-level stream / event / ctypes
+ * operations per batch are 0.2-0.3 ms of host time -- more than the GPU's 0.17 ms for a 1 000-query search).  Streams and events are the caller's
+ * (hipStream_t / hipEvent_t as void*): upload of the pinned host queries on s_in -> ev_in; overlap_nav != 0: lmi_mlp_topk on s_nav behind ev_in
+ * -> ev_nav, lmi_scan_topk on s_run behind ev_nav; else lmi_search on s_run behind ev_in; (dists, ids) are stored where dists_out / ids_out point
+ * (device memory, or pinned host memory: then no download is needed); the bucket order goes to bo_dev and, bo_host != NULL, by one copy
+ * kernel to pinned bo_host; ev_out is recorded on s_run behind everything.  qs_host == NULL: navigation and scan vectors are the same array.
+ * The handle's stream is s_run on return.  Replaces the body of LearnedIndex.search for one batch (LearnedIndex.py:85-159) like lmi_search. */
+LMI_API int lmi_pipeline_submit(lmi_index *h, void *s_in, void *s_nav, void *s_run, void *ev_in, void *ev_nav, void *ev_out,
+                                const float *qn_host, const float *qs_host, float *qn_dev, float *qs_dev, int nq, int nb, int k,
+                                float *dists_out, uint32_t *ids_out, int32_t *bo_dev, int32_t *bo_host, int overlap_nav);
 
 /* The same exchange through RCCL inside the library (no reference counterpart; SURVEY 8b `lmi_allgather_merge(h,
  * ncclComm_t, ...)`): a C/C++ caller runs the bucket-sharded mode without torch.distributed.

@@ -62,6 +62,7 @@ SIGNATURES = {
     "lmi_bucket_read": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp]),
     "lmi_copy_out": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64]),
     "lmi_copy_out_many": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp]),
+    "lmi_pipeline_submit": (ctypes.c_int, [_vp] * 7 + [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_int]),
     "lmi_knn_ip": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int64, _vp, ctypes.c_int64, ctypes.c_int,
                                   ctypes.c_int, _vp, _vp]),
     "lmi_timings": (ctypes.c_int, [_vp, _vp]),
@@ -386,6 +387,12 @@ class Index:
             assert d_t.is_pinned() and d_t.numel() * d_t.element_size() == nbytes and s_t.is_contiguous() and d_t.is_contiguous()
             dst[i], src[i], nby[i] = d_t.data_ptr(), s_t.data_ptr(), nbytes
         _check(lib().lmi_copy_out_many(self._h, n, dst, src, nby))
+
+    def pipeline_submit(self, s_in, s_nav, s_run, ev_in, ev_nav, ev_out, qn_h, qs_h, qn_d, qs_d, nb: int, k: int, d_out, i_out, bo_d, bo_h,
+                        overlap_nav: bool) -> None:
+        """One batch of a host-in -> host-out pipeline as ONE C call (lmi_pipeline_submit): raw stream / event handles, torch tensors."""
+        _check(lib().lmi_pipeline_submit(self._h, s_in, s_nav, s_run, ev_in, ev_nav, ev_out, _ptr(qn_h), _ptr(qs_h), _ptr(qn_d), _ptr(qs_d),
+                                         int(qn_d.shape[0]), int(nb), int(k), _ptr(d_out), _ptr(i_out), _ptr(bo_d), _ptr(bo_h), 1 if overlap_nav else 0))
 
     # ---- RCCL inside the library (the sharded exchange without torch.distributed) ----------------------------
     @staticmethod

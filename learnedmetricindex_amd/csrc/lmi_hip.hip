@@ -2006,6 +2006,40 @@ extern "C" LMI_API int lmi_copy_out_many(lmi_index* h, int n, void* const* dst, 
     return 0;
 }
 
+extern "C" LMI_API int lmi_pipeline_submit(lmi_index* h, void* s_in_, void* s_nav_, void* s_run_, void* ev_in_, void* ev_nav_, void* ev_out_,
+                                          const float* qn_host, const float* qs_host, float* qn_dev, float* qs_dev, int nq, int nb, int k,
+                                          float* dists_out, uint32_t* ids_out, int32_t* bo_dev, int32_t* bo_host, int overlap_nav) {
+    if (!h) return fail("lmi_pipeline_submit: NULL handle");
+    if (!s_in_ || !s_run_ || !ev_in_ || !ev_out_ || !qn_host || !qn_dev || !dists_out || !ids_out || !bo_dev) return fail("lmi_pipeline_submit: NULL argument");
+    if (overlap_nav && (!s_nav_ || !ev_nav_)) return fail("lmi_pipeline_submit: overlap_nav needs a navigation stream and event");
+    if ((qs_host == nullptr) != (qs_dev == nullptr)) return fail("lmi_pipeline_submit: qs_host and qs_dev go together");
+    if (nq < 1 || h->n_layers == 0 || !h->built) return fail("lmi_pipeline_submit: empty batch, no MLP or no bucket index");
+    CHK(set_dev(h));
+    hipStream_t s_in = static_cast<hipStream_t>(s_in_), s_nav = static_cast<hipStream_t>(s_nav_), s_run = static_cast<hipStream_t>(s_run_);
+    hipEvent_t ev_in = static_cast<hipEvent_t>(ev_in_), ev_nav = static_cast<hipEvent_t>(ev_nav_), ev_out = static_cast<hipEvent_t>(ev_out_);
+    HIPCHK(hipMemcpyAsync(qn_dev, qn_host, (size_t)nq * h->dims[0] * 4, hipMemcpyHostToDevice, s_in));
+    if (qs_host) HIPCHK(hipMemcpyAsync(qs_dev, qs_host, (size_t)nq * h->d_user * 4, hipMemcpyHostToDevice, s_in));
+    HIPCHK(hipEventRecord(ev_in, s_in));
+    const float* q_scan = qs_dev ? qs_dev : qn_dev;
+    if (overlap_nav) {
+        HIPCHK(hipStreamWaitEvent(s_nav, ev_in, 0));
+        h->stream = s_nav;
+        int rc = lmi_mlp_topk(h, qn_dev, nq, nb, bo_dev, nullptr, 1);
+        h->stream = s_run;
+        CHK(rc);
+        HIPCHK(hipEventRecord(ev_nav, s_nav));
+        HIPCHK(hipStreamWaitEvent(s_run, ev_nav, 0));
+        CHK(lmi_scan_topk(h, q_scan, nq, bo_dev, nb, k, dists_out, ids_out, nullptr, 1));
+    } else {
+        h->stream = s_run;
+        HIPCHK(hipStreamWaitEvent(s_run, ev_in, 0));
+        CHK(lmi_search(h, qn_dev, q_scan, nq, nb, k, dists_out, ids_out, nullptr, bo_dev, 1));
+    }
+    if (bo_host) CHK(lmi_copy_out(h, bo_host, bo_dev, (int64_t)nq * nb * 4));
+    HIPCHK(hipEventRecord(ev_out, s_run));
+    return 0;
+}
+
 // Multi-level navigation on the device: LearnedIndex._precompute_bucket_order for len(n_categories) > 1
 // (LearnedIndex.py:216-252) -- the batched priority-queue walk.  slab_ids[nq][nb] <- slab bucket id of the
 // j-th visited bucket (-1: listed bucket without objects or queue exhausted), entries[nq][nb] <- its flat child

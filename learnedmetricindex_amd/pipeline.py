@@ -39,7 +39,7 @@ class HostPipeline:
     def __init__(self, index, nq: int, d_nav: int, d_search: int, nb: int, k: int = 10, depth: int = 2,
                  device: Optional[int] = None, same_queries: bool = False, want_bucket_order: bool = False,
                  search_fn=None, overlap_inference: bool = True, two_handles: bool = False, sharded=None, use_graph: bool = False,
-                 direct_out: bool = False):
+                 direct_out: bool = False, native_submit: bool = True):
         """`search_fn(qn_dev, qs_dev) -> (dists_t, ids_t, bucket_order_t)`: optional replacement of the single-GPU
         `lmi_search` call, run on the compute stream (the bucket-sharded searcher of sharded.py, whose collectives
         then run on that stream too); its output tensors may be reused by its next call."""
@@ -81,6 +81,9 @@ class HostPipeline:
         # direct_out: the search's last kernels store (dists, ids) straight into the pinned host buffers (device-accessible memory) -- no
         # download kernel behind the search (1 MB over PCIe: 18 us of a 0.56-ms search at 10M x 45); single-GPU forms only
         self.direct_out = bool(direct_out) and search_fn is None and sharded is None
+        # native_submit: a batch's stream / event / launch sequence as ONE C call (lmi_pipeline_submit) instead of a dozen Python-level
+        # operations (0.2-0.3 ms of host time per batch: more than the GPU needs for a 1 000-query search); single-handle, single-GPU forms
+        self.native = bool(native_submit) and search_fn is None and sharded is None and not self.two
         # hipGraph replay: single-GPU forms only (a collective inside a capture is RCCL's business, not rehearsed here)
         self.use_graph = bool(use_graph) and search_fn is None and sharded is None and not self.two
         self.slots = []
@@ -216,7 +219,20 @@ class HostPipeline:
         qn_src = self._stage(queries_nav, s["qn_h"])
         qs_src = None if self.same else self._stage(queries_nav if queries_search is None else queries_search, s["qs_h"])
         index, s_run = self.handles[self.t % len(self.handles)]
-        if self.use_graph:
+        if self.native and not self.use_graph:
+            if not s["warm"]:   # torch creates an event's handle with its first record
+                for e_ in ("ev_in", "ev_nav", "ev_out"):
+                    s[e_].record(self.s_in)
+                s["warm"] = True
+            od, oi = ("d_h", "i_h") if self.direct_out else ("d_d", "i_d")
+            self.index.pipeline_submit(self.s_in.cuda_stream, self.s_nav.cuda_stream, s_run.cuda_stream, s["ev_in"].cuda_event, s["ev_nav"].cuda_event,
+                                       s["ev_out"].cuda_event, qn_src, qs_src, s["qn_d"], None if self.same else s["qs_d"], self.nb, self.k,
+                                       s[od], s[oi], s["bo_d"], s["bo_h"] if self.want_bo else None, self.overlap)
+            if not self.direct_out:
+                with torch.cuda.stream(s_run):
+                    index.copy_out_many([(s["d_h"], s["d_d"]), (s["i_h"], s["i_d"])])
+                    s["ev_out"].record(s_run)
+        elif self.use_graph:
             g = self._graph_for(s, qn_src, qs_src, s_run, index)
             if len(g) == 2:   # (upload + MLP) on the navigation stream, (scan + download) on the compute stream behind it
                 with torch.cuda.stream(self.s_nav):
