@@ -1085,7 +1085,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     // partial-list bound (exact mode only; the prefilter path writes rank lists, not chunk partials): a row of
     // bucket_order is caller data and may repeat a bucket, so a query owns at most nb x the largest chunk count
     const bool fast = h->prefilter && h->have16;
-    bool use_tail = false;   // (set where the prefilter path picks its tail)
+    bool use_tail = false, tail_merges = false;   // (set where the prefilter path picks its tail)
     int max_nch = 0;
     for (int b = 0; b < L; ++b) max_nch = std::max(max_nch, h->h_nch[b]);
     const long long part_lists = fast ? 1 : std::max<long long>(1, (long long)nb * max_nch * nq);
@@ -1397,7 +1397,8 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         F.ts_end_cell = nullptr;
         CHK(record(h, 6));
         // the fused tail (lmi_tail.h): a wave per query selects, re-ranks and merges -- n_buckets <= 4 (one wave holds the query's slots)
-        use_tail = rescore_is_streamed(h) && h->use_tail && nb <= 4 && RC_WAVES * tail_wave_lds(h->dp, nb, true) <= 64 * 1024;
+        use_tail = rescore_is_streamed(h) && h->use_tail && RC_WAVES * tail_wave_lds(h->dp, rescore_group_size(nb), true) <= 64 * 1024;
+        tail_merges = use_tail && rescore_group_size(nb) == nb;   // (a query's slots in ONE wave: n_buckets <= 4)
         // The overflow machinery (overflow_rebound_kernel + pass 2's redo launch: two launches that return at once on ordinary batches,
         // 11 us of a 0.2-0.5 ms search) stays OUT of the fused-tail sequence until a batch needs it: fallback_kernel then picks a flagged
         // column's entries out of the unsorted log (or, log full, scans the bucket: always correct) and raises a flag in pinned host memory;
@@ -1465,7 +1466,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         Q.host_oflag = use_tail ? h->h_oflag : nullptr;
 #ifndef LMI_ABL_NOEMIT  // timing-only ablation builds emit nothing: no re-rank, no fallback
         if (use_tail) {
-            const int G = nb, groups = nq;
+            const int G = rescore_group_size(nb), groups = nslots / G;
             CHK(h->surv_row.reserve((size_t)nslots * RC_KEEP * 4));
             const int sub_cap = cdiv(groups, RC_SUB);
             SelectOut O;
@@ -1476,13 +1477,15 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
             O.sub_cap = sub_cap;
             O.big = O.active + RC_SUB + RC_SUB * sub_cap;
             TailParams T;
-            T.nq = nq; T.kout = kout;
+            T.ngroups = groups; T.merge = tail_merges ? 1 : 0; T.kout = kout;
             T.out_d = d_dists; T.out_id = d_ids; T.out_key = d_keys;
-            T.pending = h->rs_flag.as<int>();   // [groups = nq]
-            Q.merge_pending = T.pending; Q.m_kout = kout; Q.m_out_d = d_dists; Q.m_out_id = d_ids; Q.m_out_key = d_keys;
-            if (Q.ts) (void)tsp(h, ST_END);
+            T.pending = h->rs_flag.as<int>();   // [groups] (used as [nq] when the tail merges: then groups == nq)
+            if (tail_merges) {
+                Q.merge_pending = T.pending; Q.m_kout = kout; Q.m_out_d = d_dists; Q.m_out_id = d_ids; Q.m_out_key = d_keys;
+                if (Q.ts) (void)tsp(h, ST_END);
+            }
             const int lds_s = RC_WAVES * tail_wave_lds(h->dp, G, true);
-            const int blocks = cdiv(nq, RC_WAVES);
+            const int blocks = cdiv(groups, RC_WAVES);
 #define LMI_TL_LAUNCH(GV) { tail_kernel<GV><<<blocks, 64 * RC_WAVES, lds_s, h->stream>>>(Q, O, T); }
             if (G == 4) LMI_TL_LAUNCH(4) else if (G == 3) LMI_TL_LAUNCH(3) else if (G == 2) LMI_TL_LAUNCH(2) else LMI_TL_LAUNCH(1)
 #undef LMI_TL_LAUNCH
@@ -1547,11 +1550,11 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     M.rank_id = h->rank_id.as<unsigned>();
     M.ts = h->ts_set;
     M.scan_end = (!fast && h->ts_set) ? scan_end_cell : nullptr;
-    if (M.ts && !use_tail) { (void)tsp(h, ST_MERGE); (void)tsp(h, ST_END); }
+    if (M.ts && !tail_merges) { (void)tsp(h, ST_MERGE); (void)tsp(h, ST_END); }
     M.out_d = d_dists;
     M.out_id = d_ids;
     M.out_key = d_keys;
-    if (use_tail) { /* merged by tail_kernel / tail_big_kernel / fallback_kernel */ }
+    if (tail_merges) { /* merged by tail_kernel / fallback_kernel */ }
     else if (M.skip_a && nb <= 16) merge_ranks_kernel<<<cdiv(nq, 64), 64, 0, h->stream>>>(M);  // rank lists exist: a thread per query
     else merge_kernel<<<nq, 64, 0, h->stream>>>(M);
     HIPCHK(hipGetLastError());

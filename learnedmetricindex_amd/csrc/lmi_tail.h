@@ -22,7 +22,10 @@
 namespace lmi {
 
 struct TailParams {
-    int nq, kout;
+    int ngroups;         // waves of work: groups of G slots of one query (G = n_buckets: a query per wave, merged in the wave; G a proper divisor of
+                         // n_buckets -- 8 buckets: two groups of 4 -- the groups' rank lists go to global memory and merge_ranks_kernel merges)
+    int merge;           // G == n_buckets
+    int kout;
     float* out_d;        // [nq][kout]
     unsigned* out_id;
     unsigned* out_key;   // nullable
@@ -91,14 +94,15 @@ __global__ __launch_bounds__(64 * RC_WAVES, 3) void tail_kernel(RescoreParams P,
     extern __shared__ __attribute__((aligned(16))) unsigned char tl_smem[];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int nwv = (int)(blockDim.x >> 6);
-    const int q = blockIdx.x * nwv + wv;
-    if (q >= T.nq) return;
+    const int grp = blockIdx.x * nwv + wv;
+    if (grp >= T.ngroups) return;
+    const int q = (grp * G) / P.nb;   // the group's query
     const int dp = P.dp;
     unsigned char* base = tl_smem + (size_t)wv * tail_wave_lds(dp, G, true);
     const RcWave<G, true> W(base, dp);
     float* rl_d = reinterpret_cast<float*>(base + (rc_wave_lds(dp, G, true) + 15) / 16 * 16);
     unsigned* rl_i = reinterpret_cast<unsigned*>(rl_d + G * KPB);
-    const int p0 = q * G;
+    const int p0 = grp * G;
     const float FMAXV = 3.402823466e+38f;
     constexpr int SPEC = 4;
     constexpr int PER = PF_CAP / 64;
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(64 * RC_WAVES, 3) void tail_kernel(RescoreParams P,
         }
         nflag += fbv[sl];
     }
-    if (lane == 0) T.pending[q] = nflag;
+    if (lane == 0 && T.merge) T.pending[q] = nflag;
     const int total = off[G];
     if (total > 0) W.stage_query(P, q, lane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(64 * RC_WAVES, 3) void tail_kernel(RescoreParams P,
             }
         }
     }
-    if (nflag) return;   // fallback_kernel re-scores the flagged slot(s) and merges the query
+    if (nflag || !T.merge) return;   // fallback_kernel re-scores the flagged slot(s) and merges the query / merge_ranks_kernel merges the groups
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const float dv = lane < G * KPB ? rl_d[lane] : 0.0f;

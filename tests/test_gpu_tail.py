@@ -1,5 +1,6 @@
 """GPU (`-m gpu`): the fused tail (lmi_tail.h: selection + exact re-rank + rank merge in one wave per query, LMI_TAIL=1, the default)
-against the five launches it replaces (LMI_TAIL=0) and the all-f32 scan, bit for bit -- every group size (n_buckets 1..4), the
+against the five launches it replaces (LMI_TAIL=0) and the all-f32 scan, bit for bit -- every group size (n_buckets 1..4: a query per wave, merged
+in the wave; 5 / 6 / 8 / 10: groups of 1 / 3 / 4 / 2 slots per wave + merge_ranks_kernel), the
 hand-overs (queries with more survivors than the small ring holds -> tail_big_kernel; slots whose candidates overflow or with
 hundreds of survivors -> fallback_kernel, which then merges the query), unvisited and repeated slots, k != 10, the L2 metric."""
 import os
@@ -40,7 +41,7 @@ def run(capi, X, labels, L, Q, order, k, tail, prefilter=True, metric="ip", chun
     return out, st
 
 
-@pytest.mark.parametrize("nb,k", [(1, 10), (2, 10), (3, 7), (4, 10), (4, 15), (4, 1)])
+@pytest.mark.parametrize("nb,k", [(1, 10), (2, 10), (3, 7), (4, 10), (4, 15), (4, 1), (5, 10), (6, 12), (8, 10), (10, 20)])
 def test_tail_equals_five_launches_every_group_size(capi, nb, k):
     X, lab, Q, order = make(20 + nb, 40_000, 96, 20, 1500, nb, invalid_frac=0.03, repeat_frac=0.1 if nb > 1 else 0.0, empty=(3,))
     (d1, i1, k1), st1 = run(capi, X, lab, 20, Q, order, k, tail=True, want_keys=True)
