@@ -189,7 +189,8 @@ struct lmi_index {
     int overflow_armed = 0;       // calls for which overflow_rebound_kernel + pass 2's redo launch stay in the sequence (re-armed by h_oflag)
     bool fr_bump_pending = false; // route_kernel was launched and the launch that bumps the granules' tag (bound_merge2_kernel) not yet: a call that
                                   // failed in between is repaired by a bump launch of its own at the next call
-    bool use_tail = true;         // tail_kernel (lmi_tail.h): selection + re-rank + rank merge in one wave per query (LMI_TAIL=0: the five launches of round 4)
+    int use_tail = 1;             // tail_kernel (lmi_tail.h): selection + re-rank + rank merge in one wave per query (LMI_TAIL=0: the five launches of round 4;
+                                  // 2: also group-wise for n_buckets > 4)
     bool use_front = true;        // route_kernel + pack_kernel (lmi_front.h) instead of the eight preparation launches (LMI_FRONT=0 in the environment: off)
 };
 
@@ -258,7 +259,7 @@ extern "C" LMI_API int lmi_create(int device, lmi_index** out) {
     if (const char* e = getenv("LMI_PF_PRIMARY")) h->pf_primary = e[0] && e[0] != '0';
     if (const char* e = getenv("LMI_PS_WIDE")) h->ps_force_wide = e[0] == '1' ? 1 : e[0] == '0' ? 0 : -1;
     if (const char* e = getenv("LMI_FRONT")) h->use_front = !(e[0] == '0');
-    if (const char* e = getenv("LMI_TAIL")) h->use_tail = !(e[0] == '0');
+    if (const char* e = getenv("LMI_TAIL")) h->use_tail = e[0] == '0' ? 0 : e[0] == '2' ? 2 : 1;
     if (const char* e = getenv("LMI_FR_DEBUG")) { if (e[0] == '1') { CHK(h->fr_dbg.reserve(256)); HIPCHK(hipMemset(h->fr_dbg.p, 0, 256)); } }
     {
         int khz = 0;
@@ -1397,8 +1398,12 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         F.ts_end_cell = nullptr;
         CHK(record(h, 6));
         // the fused tail (lmi_tail.h): a wave per query selects, re-ranks and merges -- n_buckets <= 4 (one wave holds the query's slots)
-        use_tail = rescore_is_streamed(h) && h->use_tail && RC_WAVES * tail_wave_lds(h->dp, rescore_group_size(nb), true) <= 64 * 1024;
-        tail_merges = use_tail && rescore_group_size(nb) == nb;   // (a query's slots in ONE wave: n_buckets <= 4)
+        // n_buckets <= 4 (a query's slots in ONE wave).  tail_kernel also runs group-wise (8 buckets: two waves of 4 + merge_ranks_kernel; LMI_TAIL=2),
+        // but there the five launches are faster -- 4M x 768, 16 buckets: re-rank 0.39 against 0.25 ms; 4M x 45, 2 000 leaves, 8 buckets: 0.23 against
+        // 0.18: most of the 160 000+ slots have nothing to re-rank, which select_kernel's compacted lists skip and a wave per group does not
+        use_tail = rescore_is_streamed(h) && h->use_tail && (rescore_group_size(nb) == nb || h->use_tail == 2) &&
+                   RC_WAVES * tail_wave_lds(h->dp, rescore_group_size(nb), true) <= 64 * 1024;
+        tail_merges = use_tail && rescore_group_size(nb) == nb;
         // The overflow machinery (overflow_rebound_kernel + pass 2's redo launch: two launches that return at once on ordinary batches,
         // 11 us of a 0.2-0.5 ms search) stays OUT of the fused-tail sequence until a batch needs it: fallback_kernel then picks a flagged
         // column's entries out of the unsorted log (or, log full, scans the bucket: always correct) and raises a flag in pinned host memory;

@@ -23,7 +23,7 @@ def capi():
 
 def run(capi, X, labels, L, Q, order, k, tail, prefilter=True, metric="ip", chunk_rows=256, want_keys=False):
     old = os.environ.get("LMI_TAIL")
-    os.environ["LMI_TAIL"] = "1" if tail else "0"
+    os.environ["LMI_TAIL"] = "2" if tail else "0"   # 2: the fused tail also group-wise for n_buckets > 4 (off by default there: slower)
     try:
         idx = capi.Index(0, chunk_rows=chunk_rows, prefilter=prefilter, metric=metric)
     finally:
