@@ -884,7 +884,7 @@ def main():
         args.no_cpu_baseline = args.no_recall = args.no_hard_leg = args.no_other_configs = args.no_exact_leg = True
         wl = Workload(args, cfg, dev, rank, world, local_rank, sigma=args.hard_sigma, zipf=args.hard_zipf, centre_scale=args.hard_centre_scale, tag="hard")
     else:
-        wl = Workload(args, cfg, dev, rank, world, local_rank)
+        wl = Workload(args, cfg, dev, rank, world, local_rank, tag=os.environ.get("LMI_BENCH_TAG", "main"))   # (developer aid: another data seed)
     res = wl.run(args.steps, args.warmup, shard_inference=True)
     elapsed, phases, out_d, out_i, bo = res["elapsed"], res["phases"], res["out_d"], res["out_i"], res["bo"]
     flops, pairs, items = res["scan_stats"]

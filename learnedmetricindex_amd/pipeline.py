@@ -34,12 +34,14 @@ from typing import Optional, Tuple
 
 import numpy as np
 
+_STREAMS: dict = {}   # device index -> the four streams every pipeline of this process uses there
+
 
 class HostPipeline:
     def __init__(self, index, nq: int, d_nav: int, d_search: int, nb: int, k: int = 10, depth: int = 2,
                  device: Optional[int] = None, same_queries: bool = False, want_bucket_order: bool = False,
                  search_fn=None, overlap_inference: bool = True, two_handles: bool = False, sharded=None, use_graph: bool = False,
-                 direct_out: bool = False, native_submit: bool = True):
+                 direct_out: bool = False, native_submit: bool = True, share_streams: bool = True):
         """`search_fn(qn_dev, qs_dev) -> (dists_t, ids_t, bucket_order_t)`: optional replacement of the single-GPU
         `lmi_search` call, run on the compute stream (the bucket-sharded searcher of sharded.py, whose collectives
         then run on that stream too); its output tensors may be reused by its next call."""
@@ -67,12 +69,22 @@ class HostPipeline:
         self.calls_per_batch = 2 if self.overlap else 1
         dev = torch.device("cuda", index.device if device is None else device)
         self.dev = dev
-        self.s_in, self.s_run, self.s_nav = (torch.cuda.Stream(dev) for _ in range(3))
+        # the pipelines of a process share one set of streams per device: every new HIP stream is bound to one of the runtime's few
+        # hardware queues (GPU_MAX_HW_QUEUES, 4 by default) by creation order, and the pipeline built sixth in a process measured
+        # 15 % slower at 10M x 45 than the same pipeline built first (profiles/r05_stream_queues.txt) -- its three streams no longer
+        # overlapped the way the first three do
+        key = (dev.index if dev.index is not None else torch.cuda.current_device())
+        if share_streams:
+            pool = _STREAMS.setdefault(key, [])
+            while len(pool) < 4:
+                pool.append(torch.cuda.Stream(dev))
+            self.s_in, self.s_run, self.s_nav, s2 = pool
+        else:
+            self.s_in, self.s_run, self.s_nav, s2 = (torch.cuda.Stream(dev) for _ in range(4))
         index.set_stream(self.s_run.cuda_stream)
         self.handles = [(index, self.s_run)]
         if self.two:
             twin = index.clone_view()
-            s2 = torch.cuda.Stream(dev)
             twin.set_stream(s2.cuda_stream)
             self.handles.append((twin, s2))
         f32, i32 = torch.float32, torch.int32

@@ -114,3 +114,35 @@ def test_pipeline_graph_replay_equals_eager(name, mode):
     np.testing.assert_array_equal(out[True][-1][1], i_ref)
     np.testing.assert_array_equal(out[True][-1][0], d_ref)
     idx.close()
+
+
+def test_pipelines_share_streams():
+    """Every pipeline of a process runs on the same streams of its device unless asked otherwise (profiles/r05_stream_queues.txt)."""
+    from learnedmetricindex_amd import _capi
+    from learnedmetricindex_amd.pipeline import HostPipeline
+
+    g = load_golden("G6")
+    Xn, Qn, Xs, Qs = inputs_for("G6", g)
+    layers = layers_from(g)
+    nb, k = int(g["n_buckets"]), int(g["k"])
+    idx = _capi.Index(0)
+    idx.set_mlp(layers)
+    idx.set_buckets(Xs, g["data_prediction"][:, 0], layers[-1][0].shape[0])
+    nq = 64
+    mk = lambda **kw: HostPipeline(idx, nq, Qn.shape[1], Qs.shape[1], nb, k, depth=2, **kw)   # noqa: E731
+    a, b, c = mk(), mk(), mk(share_streams=False)
+    for f in ("s_in", "s_run", "s_nav"):
+        assert getattr(a, f).cuda_stream == getattr(b, f).cuda_stream
+        assert getattr(c, f).cuda_stream != getattr(a, f).cuda_stream
+    assert len({a.s_in.cuda_stream, a.s_run.cuda_stream, a.s_nav.cuda_stream}) == 3
+    qn, qs = np.ascontiguousarray(Qn[:nq]), np.ascontiguousarray(Qs[:nq])
+    got = []
+    for pipe in (a, c, b):
+        t = pipe.submit(qn, qs)
+        d, i = pipe.result(t)
+        got.append((d.copy(), i.copy()))
+        pipe.drain()
+    for d, i in got[1:]:
+        np.testing.assert_array_equal(i, got[0][1])
+        np.testing.assert_array_equal(d, got[0][0])
+    idx.close()
