@@ -290,6 +290,14 @@ class Workload:
             res["pf_redo_columns"] = int(eng.debug_peek("pf_redo", 4).view(np.uint32)[0]) if not self.exact else 0
         except Exception:  # noqa: BLE001
             res["pf_redo_columns"] = None
+        if os.environ.get("LMI_P2_ENDS") and not self.exact:   # -DLMI_P2_ENDS builds: the ragged end of pass 2 (100 MHz ticks)
+            raw = eng.debug_peek("pf_stamps", 8 * (192 + 256)).view(np.uint64).astype(np.int64)
+            t0, ends = int(raw[191]), np.sort(raw[192:][raw[192:] > 0])
+            if len(ends):
+                rel = (ends - t0) / 100.0
+                sys.stderr.write("[p2 ends %s] blocks %d: first %.1f us, median %.1f, last %.1f; mean idle before the last %.1f us (%.2f %% of the launch)\n"
+                                 % (self.tag, len(ends), rel[0], float(np.median(rel)), rel[-1], float((rel[-1] - rel).mean()),
+                                    100.0 * float((rel[-1] - rel).mean()) / rel[-1]))
         return res
 
     def recall(self, out_i, nr):

@@ -191,6 +191,9 @@ struct lmi_index {
                                   // failed in between is repaired by a bump launch of its own at the next call
     int use_tail = 1;             // tail_kernel (lmi_tail.h): selection + re-rank + rank merge in one wave per query (LMI_TAIL=0: the five launches of round 4;
                                   // 2: also group-wise for n_buckets > 4)
+    bool graded_chunks = true;    // pass 2's items: chunk length per bucket and call (LMI_P2_GRADED=0: the index's static chunk everywhere)
+    int chunk_lvl_rows[3] = {0, 0, 0};   // LMI_P2_CHUNKS=a,b,c (rows; 0 = 1, 1/2, 1/4 of the static chunk)
+    float chunk_frac[2] = {0.16f, 0.05f};   // LMI_P2_CHUNK_FRAC=f0,f1: the last f0 of the work in chunks of b rows, the last f1 in chunks of c
     bool use_front = true;        // route_kernel + pack_kernel (lmi_front.h) instead of the eight preparation launches (LMI_FRONT=0 in the environment: off)
 };
 
@@ -259,6 +262,9 @@ extern "C" LMI_API int lmi_create(int device, lmi_index** out) {
     if (const char* e = getenv("LMI_PF_PRIMARY")) h->pf_primary = e[0] && e[0] != '0';
     if (const char* e = getenv("LMI_PS_WIDE")) h->ps_force_wide = e[0] == '1' ? 1 : e[0] == '0' ? 0 : -1;
     if (const char* e = getenv("LMI_FRONT")) h->use_front = !(e[0] == '0');
+    if (const char* e = getenv("LMI_P2_GRADED")) h->graded_chunks = !(e[0] == '0');
+    if (const char* e = getenv("LMI_P2_CHUNKS")) (void)sscanf(e, "%d,%d,%d", &h->chunk_lvl_rows[0], &h->chunk_lvl_rows[1], &h->chunk_lvl_rows[2]);
+    if (const char* e = getenv("LMI_P2_CHUNK_FRAC")) (void)sscanf(e, "%f,%f", &h->chunk_frac[0], &h->chunk_frac[1]);
     if (const char* e = getenv("LMI_TAIL")) h->use_tail = e[0] == '0' ? 0 : e[0] == '2' ? 2 : 1;
     if (const char* e = getenv("LMI_FR_DEBUG")) { if (e[0] == '1') { CHK(h->fr_dbg.reserve(256)); HIPCHK(hipMemset(h->fr_dbg.p, 0, 256)); } }
     {
@@ -1097,7 +1103,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     CHK(h->part_base.reserve((L + 1) * 8));
     CHK(h->stats.reserve(32));
     CHK(h->head.reserve(256));   // [0, 32): queue heads | [32, 36): the end-of-launch cells of the device stamps (pass 2, scan_kernel)
-    const size_t grp_ints = (size_t)NGRP * L + 2 * (size_t)NGRP * (L + 1) + 3 * NGRP;
+    const size_t grp_ints = (size_t)NGRP * L + 2 * (size_t)NGRP * (L + 1) + 3 * NGRP + (size_t)L;   // (+ the call's chunk length per bucket)
     CHK(h->grp.reserve(grp_ints * 4));
     CHK(h->slot_local.reserve((size_t)nslots * 4));
     CHK(h->slot_col.reserve((size_t)nslots * 4));
@@ -1126,6 +1132,20 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     R.grp_total1 = R.grp_base1 + (size_t)NGRP * (L + 1);
     R.dbg = nullptr;
     const bool v2 = h->prefilter && h->have16;   // the prefilter's kernels: lmi_pass2.h (tiles of up to 12 col-blocks)
+    // graded pass-2 items (lmi_kernels.h RouteArrays): long chunks for the buckets a queue serves first, short ones for the last
+    R.chunk_rb = h->chunk_rows / 32;
+    R.chunk_rb_b = (v2 && h->graded_chunks) ? R.grp_total1 + NGRP : nullptr;
+    {
+        const int base = h->chunk_rows;
+        int rows[3] = {base, base / 2, base / 4};   // (longer than the static chunk: no gain at C2, and a 4 096-row chunk of 768-d rows no longer fits an L2 beside a second query tile: hard leg +3.5 %)
+        for (int i = 0; i < 3; ++i) {
+            if (h->chunk_lvl_rows[i] > 0) rows[i] = h->chunk_lvl_rows[i];
+            rows[i] = std::max(P2_TILE_ROWS, rows[i] / P2_TILE_ROWS * P2_TILE_ROWS);
+            R.chunk_lvl[i] = rows[i] / 32;
+        }
+        R.chunk_frac[0] = h->chunk_frac[0];
+        R.chunk_frac[1] = h->chunk_frac[1];
+    }
     // low-dimensional kernels: the wide form (one 8-wave block per CU, 12-col-block tiles) when the visited buckets receive more
     // queries than the narrow form's tile holds -- decided from the call's shape alone (no device round trip)
     h->ps_wide = false;
@@ -1334,6 +1354,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         F.KG16 = h->KG16;
         F.L = L;
         F.chunk_rb = S.chunk_rb;
+        F.chunk_rb_b = R.chunk_rb_b;
         F.tile_cb = R.tile_cb;
         F.sample_max = R.sample_max;
         F.rb_start = S.rb_start;

@@ -364,7 +364,17 @@ struct RouteArrays {
     int sample_items;     // 1: also build the pass-1 queues of lmi_pass2.h (grp_base1 / grp_total1: query tiles x SAMPLED tiles)
     int sample_max;       // pass 1's largest sampling stride (PF_SAMPLE; PF_SAMPLE_LOWD at K <= 64)
     unsigned long long* dbg;  // nullable developer aid: route_group_body stamps the clock after its key pass [2] and its sort [3]
+    // Graded pass-2 items (round 5; prefilter only, <= 1 024 buckets): a bucket's rows are handed out in chunks of chunk_rb_b[b] row-blocks,
+    // chosen per CALL from where the bucket sits in the work-sorted order: the buckets a queue serves last get short chunks, the others
+    // long ones -- few item starts over most of the launch, a fine-grained end (C2: workgroups idle 4 % of the launch at 2 048 rows per
+    // item everywhere, 1 % at 512 with 9 % more time spent on item starts)
+    int* chunk_rb_b;          // nullable [L] out: row-blocks per chunk of bucket b (null: nch / the index's static chunk)
+    int chunk_rb;             // the index's static chunk (= nch): thousands of buckets keep it
+    int chunk_lvl[3];         // row-blocks per chunk: buckets ahead of the last chunk_frac[0] of the work, the next ones, the last chunk_frac[1]
+    float chunk_frac[2];
 };
+// chunks of a bucket of nrb row-blocks at crb row-blocks per chunk
+__device__ __forceinline__ int chunks_of(int n_rows, int crb) { return (((n_rows + 31) >> 5) + crb - 1) / crb; }
 
 // ---- prefilter pass 1: which tiles of a bucket are sampled (shared by the routing kernels and lmi_prefilter.h / lmi_pass2.h) ----
 #ifndef LMI_PF_SAMPLE_ROWS
@@ -583,14 +593,32 @@ __device__ __forceinline__ void route_group_body(int L, const RouteArrays& R, ch
             if (i < P) {
                 const unsigned long long mine = key_s[i];
                 int r = 0;
+                long long w_all = 0, w_tail = 0;   // work of all buckets / of those ranked at or behind this one (graded chunks)
 #pragma unroll 8
-                for (int o = 0; o < P; ++o) r += key_s[o] < mine ? 1 : 0;
+                for (int o = 0; o < P; ++o) {
+                    const unsigned long long ko = key_s[o];
+                    r += ko < mine ? 1 : 0;
+                    if (R.chunk_rb_b) {
+                        const long long wo = ko == ~0ull ? 0ll : (1ll << 43) - 1 - (long long)(ko >> ROUTE_ID_BITS);
+                        w_all += wo;
+                        w_tail += ko >= mine ? wo : 0ll;
+                    }
+                }
                 my_rank[u] = r;
                 my_id[u] = (int)(mine & ((1ull << ROUTE_ID_BITS) - 1));
+                if (R.chunk_rb_b && mine != ~0ull) {
+                    const float f = w_all > 0 ? (float)((double)w_tail / (double)w_all) : 0.0f;
+                    const int crb = f > R.chunk_frac[0] ? R.chunk_lvl[0] : f > R.chunk_frac[1] ? R.chunk_lvl[1] : R.chunk_lvl[2];
+                    const int b = my_id[u];
+                    R.chunk_rb_b[b] = crb;
+                    items_s[b] = query_tiles(R.m[b], R.tile_cb) * chunks_of(R.nb_rows[b], crb);   // (items_s lies behind the keys: no overlap)
+                }
             }
         }
         __syncthreads();   // every key is read: the ids may go over them
-    } else
+    } else {
+    if (R.chunk_rb_b)   // thousands of buckets: items are short and many anyway -- the index's static chunk
+        for (int b = t; b < L; b += NT) R.chunk_rb_b[b] = R.chunk_rb;
     for (int k = 2; k <= P; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = t; i < P; i += NT) {
@@ -603,6 +631,7 @@ __device__ __forceinline__ void route_group_body(int L, const RouteArrays& R, ch
             }
             __syncthreads();
         }
+    }
     }
     if (R.dbg && t == 0) R.dbg[3] = wall_clock64();
     if (ranked) {

@@ -517,7 +517,8 @@ struct Tile2 {
 
     // The tile = col-blocks [cbt0, cbt0 + NCB) of bucket b.  !SAMPLE: `ch` = chunk of the bucket, every tile of it;
     // SAMPLE: `ch` = sampled tile j of the bucket (tile j * stride), one tile.
-    __device__ __forceinline__ void run(int b_, int cbt0_, int ch_, int m_use_, int nt_) {
+    template <typename Q>
+    __device__ __forceinline__ void run(int b_, int cbt0_, int ch_, int m_use_, int nt_, Q& queue) {
         // the item came through LDS (s_item): tell the compiler it is wave-uniform, so that every address derived from it is
         // scalar (the vector loads take their base as an "s" operand)
         const int b = __builtin_amdgcn_readfirstlane(b_), cbt0 = __builtin_amdgcn_readfirstlane(cbt0_);
@@ -535,8 +536,9 @@ struct Tile2 {
         const int n_b = P.nb_rows[b];
         const int nrb_b = (n_b + 31) >> 5;
         const int stride = SAMPLE ? sample_stride(n_b, P.sample_max) : 1;
-        const int rb0 = SAMPLE ? ch * stride * P2_TILE_RB : ch * P.chunk_rb;
-        const int nrb_all = SAMPLE ? P2_TILE_RB : min(P.chunk_rb, nrb_b - rb0);
+        const int crb = (!SAMPLE && P.chunk_rb_b) ? P.chunk_rb_b[b] : P.chunk_rb;
+        const int rb0 = SAMPLE ? ch * stride * P2_TILE_RB : ch * crb;
+        const int nrb_all = SAMPLE ? P2_TILE_RB : min(crb, nrb_b - rb0);
         // block tiles of P2_WAVES row-blocks.  pass 1: the item's nt sampled tiles, each VPT block tiles, 2 stride tiles apart (row-blocks
         // past the bucket's end are clamped re-reads, masked in the epilogue)
         constexpr int VPT = P2_TILE_RB / P2_WAVES;
@@ -552,13 +554,6 @@ struct Tile2 {
         const bool loader = is_loader();
         const int lw = w & 3;
         const uint4* bbase0 = P.qfrag16 + ((size_t)cb_tile * KG) * 64;
-        if (!SAMPLE) {
-            // thresholds of the tile's columns -> LDS (the caller's barrier made sThr free; the first stage's barrier publishes it)
-            for (int i = tid; i < NCB * 32; i += 64 * P2_WAVES) {
-                const bool wanted = i < m_left && (!P.redo_col || P.redo_col[col0 + i]);
-                sThr[i] = wanted ? P.bound1[col0 + i] - P.eps2[col0 + i] : INFINITY;
-            }
-        }
         pend_pos = 0xffffffffu;
         int vt_n = 0, t_n = 0;
         Stream S;
@@ -618,6 +613,14 @@ struct Tile2 {
             load_a<1>(S);
             P2_ADVANCE
         }
+        if (!SAMPLE) {
+            // thresholds of the tile's columns -> LDS (the caller's barrier made sThr free; the first stage's barrier publishes it).  BEHIND
+            // the first two stages' requests (round 5): their wait covers both round trips instead of one after the other
+            for (int i = tid; i < NCB * 32; i += 64 * P2_WAVES) {
+                const bool wanted = i < m_left && (!P.redo_col || P.redo_col[col0 + i]);
+                sThr[i] = wanted ? P.bound1[col0 + i] - P.eps2[col0 + i] : INFINITY;
+            }
+        }
         for (int vt = 0; vt < nvt; ++vt) {
             bool pend = false;
             for (int t = 0; t < NSR; t += P2_RING) {
@@ -636,6 +639,7 @@ struct Tile2 {
             P2_STAMP(3)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the look-ahead before the LDS is reused
+        queue.prefetch();   // the next ticket: its round trip beside the barrier and the flush below
         __syncthreads();
         P2_STAMP(5)
 #ifdef LMI_P2_STAMPS
@@ -798,11 +802,15 @@ __device__ __forceinline__ bool p2_pop_item(const PrefilterParams& P, int& grp, 
 // Once the own group is used up the block falls back to p2_pop_item's walk over the other groups (the tail of the launch).
 constexpr int P2_PREFIX_CAP = 1025;   // buckets + 1 of a group held in LDS (more: the global prefix is searched)
 constexpr int P2_PREFIX_CAP_K = P2_WAVES == 4 ? 116 : P2_PREFIX_CAP;   // pass2_kernel at two blocks per CU: 80 KiB of LDS per block, to the byte
-template <bool SAMPLE, bool PREFETCH, int NTHREADS, int PREFIX_CAP = P2_PREFIX_CAP>
+// PREFETCH 2 (pass2_kernel, round 5): the ticket is taken by prefetch(), which the tile loop calls once the item's look-ahead is drained --
+// the atomic's round trip runs beside the item's last barrier and candidate flush, and no register is live across the K loop; with the
+// group's bucket ids in LDS too (s_gb) the pop makes no global round trip of its own.
+template <bool SAMPLE, int PREFETCH, int NTHREADS, int PREFIX_CAP = P2_PREFIX_CAP>
 struct P2Queue {
     const PrefilterParams& P;
     int* s_item;     // [2] LDS
     int* s_prefix;   // [PREFIX_CAP] LDS
+    int* s_gb;       // nullable [PREFIX_CAP] LDS: the group's bucket ids
     int grp, own, own_tot, own_n, ticket;
     const int* own_base;
     unsigned* own_head;
@@ -816,17 +824,23 @@ struct P2Queue {
         own_base = (SAMPLE ? P.grp_base1 : P.grp_base) + own * (P.L + 1);
         prefix_lds = own_n + 1 <= PREFIX_CAP;
         if (prefix_lds)
-            for (int i = threadIdx.x; i <= own_n; i += NTHREADS) s_prefix[i] = own_base[i];
+            for (int i = threadIdx.x; i <= own_n; i += NTHREADS) {
+                s_prefix[i] = own_base[i];
+                if (s_gb && i < own_n) s_gb[i] = P.grp_bucket[own * P.L + i];
+            }
         own_live = own_tot > 0 && !(!SAMPLE && P.redo_bucket);   // (the redo launch skips buckets: it keeps to the plain pop)
         ticket = -1;
-        if (PREFETCH && own_live && threadIdx.x == 0) ticket = (int)atomicAdd(own_head, 1u);
+        if (PREFETCH == 1 && own_live && threadIdx.x == 0) ticket = (int)atomicAdd(own_head, 1u);
         __syncthreads();
+    }
+    __device__ __forceinline__ void prefetch() {
+        if (PREFETCH == 2 && own_live && threadIdx.x == 0) ticket = (int)atomicAdd(own_head, 1u);
     }
     __device__ __forceinline__ bool next(P2Item& it) {
         if (own_live) {
             if (threadIdx.x == 0) {
                 int b = -1, local = 0;
-                if (!PREFETCH) ticket = (int)atomicAdd(own_head, 1u);
+                if (PREFETCH == 0 || (PREFETCH == 2 && ticket < 0)) ticket = (int)atomicAdd(own_head, 1u);
                 if (ticket < own_tot) {
                     int lo = 0, hi = own_n;
                     if (prefix_lds) {
@@ -836,9 +850,10 @@ struct P2Queue {
                         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (own_base[mid] <= ticket) lo = mid; else hi = mid; }
                         local = ticket - own_base[lo];
                     }
-                    b = P.grp_bucket[own * P.L + lo];
-                    if (PREFETCH) ticket = (int)atomicAdd(own_head, 1u);   // the next one: consumed when this item is done
+                    b = (s_gb && prefix_lds) ? s_gb[lo] : P.grp_bucket[own * P.L + lo];
+                    if (PREFETCH == 1) ticket = (int)atomicAdd(own_head, 1u);   // the next one: consumed when this item is done
                 }
+                if (PREFETCH == 2) ticket = -1;   // consumed
                 s_item[0] = b;
                 s_item[1] = local;
             }
@@ -866,24 +881,31 @@ __global__ __launch_bounds__(64 * P2_WAVES, 2) __attribute__((amdgpu_num_vgpr(LM
     __shared__ __attribute__((aligned(16))) uint4 sPend[SAMPLE ? 1 : P2_WAVES * 64];
     __shared__ int s_item[2];
     __shared__ int s_prefix[P2_PREFIX_CAP_K];
+    __shared__ int s_gb[P2_PREFIX_CAP_K];
     if (!SAMPLE && P.redo_count && *P.redo_count == 0u) return;  // the redo launch of a batch without overflowed columns
     ts_first(P.ts_start);
     unsigned long long clk_w0 = 0, clk_c0 = 0;
     if (!SAMPLE) clk_begin(P.ts_end_cell ? P.ts_start : nullptr, clk_w0, clk_c0);   // (pass 2 proper: the launch that carries an end cell)
-    P2Queue<SAMPLE, false, 64 * P2_WAVES, P2_PREFIX_CAP_K> queue{P, s_item, s_prefix};
+    P2Queue<SAMPLE, 2, 64 * P2_WAVES, P2_PREFIX_CAP_K> queue{P, s_item, s_prefix, s_gb};
     queue.init();
     P2Item item;
     while (queue.next(item)) {
         const int b = item.b, cbt0 = item.cbt0, ch = item.ch, m_use = item.m_use, nt = item.nt;
-#define P2_CASE(N) case N: { Tile2<N, SAMPLE> it{P, (unsigned)reinterpret_cast<uintptr_t>(ring), ring, sList, sThr, sPend}; it.run(b, cbt0, ch, m_use, nt); break; }
+#define P2_CASE(N) case N: { Tile2<N, SAMPLE> it{P, (unsigned)reinterpret_cast<uintptr_t>(ring), ring, sList, sThr, sPend}; it.run(b, cbt0, ch, m_use, nt, queue); break; }
         switch (item.ncb_tile) {
             P2_CASE(1) P2_CASE(2) P2_CASE(3) P2_CASE(4) P2_CASE(5) P2_CASE(6)
             P2_CASE(7) P2_CASE(8) P2_CASE(9) P2_CASE(10) P2_CASE(11)
-            default: { Tile2<12, SAMPLE> it{P, (unsigned)reinterpret_cast<uintptr_t>(ring), ring, sList, sThr, sPend}; it.run(b, cbt0, ch, m_use, nt); break; }
+            default: { Tile2<12, SAMPLE> it{P, (unsigned)reinterpret_cast<uintptr_t>(ring), ring, sList, sThr, sPend}; it.run(b, cbt0, ch, m_use, nt, queue); break; }
         }
 #undef P2_CASE
     }
     if (!SAMPLE) clk_end(P.ts_end_cell ? P.ts_start : nullptr, ST_P2, clk_w0, clk_c0);
+#ifdef LMI_P2_ENDS   // developer builds (bench.py LMI_P2_ENDS=1): when each workgroup of pass 2 ran out of items -- the launch's ragged end
+    if (!SAMPLE && P.ts_end_cell && threadIdx.x == 0 && blockIdx.x < 256) {
+        P.stamps[192 + blockIdx.x] = wall_clock64();
+        if (blockIdx.x == 0) P.stamps[191] = clk_w0;
+    }
+#endif
     ts_max(P.ts_end_cell);
 }
 

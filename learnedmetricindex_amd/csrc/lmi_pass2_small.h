@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64 * ps_waves(KG, WIDE), ps_blocks_per_cu(KG, WIDE)
 #define PS_STAMP(PH)
 #endif
     // an item is a few microseconds of work: the queue takes the next ticket ahead (P2Queue, lmi_pass2.h)
-    P2Queue<SAMPLE, true, 64 * WV, PS_PREFIX_CAP> queue{P, s_item, s_prefix};
+    P2Queue<SAMPLE, 1, 64 * WV, PS_PREFIX_CAP> queue{P, s_item, s_prefix, nullptr};
     queue.init();
     P2Item item;
     while (queue.next(item)) {
@@ -129,8 +129,9 @@ __global__ __launch_bounds__(64 * ps_waves(KG, WIDE), ps_blocks_per_cu(KG, WIDE)
         const int n_b = P.nb_rows[b];
         const int nrb_b = (n_b + 31) >> 5, rb_last = nrb_b - 1;
         const int stride = SAMPLE ? sample_stride(n_b, P.sample_max) : 1;
-        const int rb0 = SAMPLE ? item_ch * stride * P2_TILE_RB : item_ch * P.chunk_rb;
-        const int nrb = SAMPLE ? P2_TILE_RB : min(P.chunk_rb, nrb_b - rb0);
+        const int crb = (!SAMPLE && P.chunk_rb_b) ? P.chunk_rb_b[b] : P.chunk_rb;
+        const int rb0 = SAMPLE ? item_ch * stride * P2_TILE_RB : item_ch * crb;
+        const int nrb = SAMPLE ? P2_TILE_RB : min(crb, nrb_b - rb0);
         // pass 1: the item's units run through its item_nt sampled tiles (UPT units each, tiles 2 stride apart; units past the bucket's end are skipped)
         constexpr int UPT = P2_TILE_RB / (PAIR ? 2 : 1);
         const int tile_step = 2 * stride * P2_TILE_RB;

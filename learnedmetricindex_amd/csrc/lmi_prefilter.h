@@ -333,6 +333,7 @@ struct PrefilterParams {
     int KG16;  // k16-groups per row-block (d > 128: a multiple of 2, a stage of pass2_kernel holds two)
     int L;
     int chunk_rb;
+    const int* chunk_rb_b;  // nullable [L]: the call's row-blocks per chunk of each bucket (lmi_kernels.h: graded pass-2 items); null: chunk_rb
     int sample_max;  // pass 1's largest sampling stride (lmi_kernels.h: sample_stride)
     int tile_cb;  // col-blocks per query tile (12; the low-dimensional kernels at K = 65..96: 8, lmi_pass2_small.h)
     const int* rb_start;
