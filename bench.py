@@ -649,7 +649,7 @@ def notebook_leg(args, dev):
                          f"{N} x {d} frame on {nthr} threads; bucket order from the device walk (navigation not timed)"}
     li.close()
     return {"workload": f"{N}x{d} scan vectors, {d_nav}-d navigation vectors (random projection), 2-level [10,10] MLP(128) index, "
-                        f"{nb} buckets, {nq}-query batch, k={k}; li.LearnedIndex.search_resident (lmi_nav_order + lmi_scan_topk), host in -> host out",
+                        f"{nb} buckets, {nq}-query batch, k={k}; li.LearnedIndex.search_resident (lmi_search_tree: the walk + the scan of its buckets in one call), host in -> host out",
             "value": round(nq * steps / elapsed, 2), "unit": "queries/s", "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 4),
             "published_reference_qps": 1290, "published_reference_note": "01-Introduction.ipynb cell 24: 10 000 queries in 7.75 s on LAION-100K (other hardware, real data)",
             "recall_at_10": round(recall, 5), "buckets": int(n_buckets), "build_s": round(build_s, 2),

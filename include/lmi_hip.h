@@ -113,6 +113,14 @@ LMI_API int lmi_nav_set_tree(lmi_index *h, int n_models, const int32_t *child_of
 LMI_API int lmi_nav_order(lmi_index *h, const float *queries_nav, int nq, int nb, int32_t *slab_ids,
                   int32_t *entries, int on_device);
 
+/* LearnedIndex.search for a multi-level index in ONE call (reference: search/li/LearnedIndex.py:41-83 the entry point, :216-325 the walk,
+ * :328-373 the bucket scans): lmi_nav_order followed by lmi_scan_topk on the walk's buckets, without the host in between.  Arguments as
+ * lmi_search (queries_nav [nq][model inputs], queries_search [nq][d]; dists / ids / keys [nq][kout]); slab_ids / entries: nullable
+ * [nq][nb] outputs of the walk (as lmi_nav_order).  With host buffers the scan vectors are uploaded on a library-owned stream while the
+ * walk runs.  Trees of up to 16 models run without any host round trip inside the call. */
+LMI_API int lmi_search_tree(lmi_index *h, const float *queries_nav, const float *queries_search, int nq, int nb, int k,
+                    float *dists, uint32_t *ids, uint32_t *keys, int32_t *slab_ids, int32_t *entries, int on_device);
+
 /* Metric of the bucket scan (call before lmi_buckets_begin; default LMI_METRIC_IP).  The reference scans with
  * faiss.METRIC_INNER_PRODUCT only (LearnedIndex.py:364); LMI_METRIC_L2 is what faiss.knn(..., METRIC_L2) would be in
  * its place: squared Euclidean distances, ascending.  Canonical arithmetic (oracle/lmi_oracle.c:lmi_oracle_knn_l2):

@@ -41,6 +41,7 @@ SIGNATURES = {
     "lmi_nav_set_model": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _i32p, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     "lmi_nav_set_tree": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp]),
     "lmi_nav_order": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int]),
+    "lmi_search_tree": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, ctypes.c_int]),
     "lmi_buckets_begin": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
     "lmi_buckets_add_rows": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int]),
     "lmi_buckets_add_owned_rows": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int]),
@@ -259,6 +260,26 @@ class Index:
         ent = np.empty((q.shape[0], nb), dtype=np.int32)
         _check(lib().lmi_nav_order(self._h, _ptr(q), q.shape[0], int(nb), _ptr(slab), _ptr(ent), 0))
         return slab, ent
+
+    def search_tree(self, queries_nav, queries_search, nb: int, k: int = 10, want_keys: bool = False, want_order: bool = False):
+        """The multi-level walk + the scan of its buckets in one call (lmi_search_tree): (dists f32[nq,kout], ids u32[nq,kout]
+        [, keys] [, slab bucket ids i32[nq,nb], flat child indices i32[nq,nb]])."""
+        qn = _np(queries_nav, np.float32)
+        qs = qn if queries_search is queries_nav else _np(queries_search, np.float32)
+        nq = qn.shape[0]
+        ko = self.kout(nb, k)
+        d = np.empty((nq, ko), dtype=np.float32)
+        i = np.empty((nq, ko), dtype=np.uint32)
+        keys = np.empty((nq, ko), dtype=np.uint32) if want_keys else None
+        slab = np.empty((nq, nb), dtype=np.int32) if want_order else None
+        ent = np.empty((nq, nb), dtype=np.int32) if want_order else None
+        _check(lib().lmi_search_tree(self._h, _ptr(qn), _ptr(qs), nq, int(nb), int(k), _ptr(d), _ptr(i), _ptr(keys), _ptr(slab), _ptr(ent), 0))
+        out = (d, i) + ((keys,) if want_keys else ()) + ((slab, ent) if want_order else ())
+        return out
+
+    def search_tree_device(self, qn_t, qs_t, nb: int, k: int, d_t, i_t, keys_t=None, slab_t=None, ent_t=None) -> None:
+        _check(lib().lmi_search_tree(self._h, _ptr(qn_t), _ptr(qs_t), int(qn_t.shape[0]), int(nb), int(k), _ptr(d_t), _ptr(i_t),
+                                     _ptr(keys_t), _ptr(slab_t), _ptr(ent_t), 1))
 
     # ---- buckets ---------------------------------------------------------------------------
     def buckets_begin(self, labels, d: int, L: int, ids=None, owned=None) -> None:

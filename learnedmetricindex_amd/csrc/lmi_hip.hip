@@ -616,6 +616,11 @@ extern "C" LMI_API int lmi_buckets_begin(lmi_index* h, int64_t N, int d, int L, 
             // 1024 / 2048 / 4096 / 8192 rows per item: 0.590 / 0.441 / 0.385 / 0.412 ms): up to 4096
             if (h->pf_small && cdiv(d, 16) <= PS_MAXKG)
                 h->chunk_rows = (int)std::min<long long>(4096, std::max<long long>(P2_TILE_ROWS, rup(owned_rows / 1024, P2_TILE_ROWS)));
+            // all-f32 scan (scan_kernel: 128-query tiles, so a bucket's chunk is read by several items): the chunk's 4 d-byte rows should
+            // stay in an XCD's 4-MiB L2 until the bucket's last query tile has come by -- 10M x 768: 2 048-row chunks (6 MB) 35.28 ms,
+            // 1 024-row chunks 34.76 (profiles/r05_exact_chunks.txt)
+            if (!h->prefilter)
+                h->chunk_rows = (int)std::max<long long>(P2_TILE_ROWS, std::min<long long>(h->chunk_rows, (3ll << 20) / (4ll * d) / P2_TILE_ROWS * P2_TILE_ROWS));
         }
         const int need = (int)rup(cdiv(max_rows, 1024), 256);
         if (need > h->chunk_rows) h->chunk_rows = need;
@@ -859,12 +864,16 @@ static int input_ptr(lmi_index* h, const void* src, size_t bytes, int on_device,
 // MLP forward + class ranking (+ softmax when d_probs: then nb == L and d_order receives the full class order)
 // Side stream (library-owned): work that does not depend on what the handle's stream runs next is forked onto it and
 // joined before its results are needed.  side_fork: the side stream waits for everything enqueued on h->stream so far.
-static int side_fork(lmi_index* h) {
+static int side_ensure(lmi_index* h) {
     if (!h->side) {
         HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&h->side_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->side_join, hipEventDisableTiming));
     }
+    return 0;
+}
+static int side_fork(lmi_index* h) {
+    CHK(side_ensure(h));
     HIPCHK(hipEventRecord(h->side_fork, h->stream));
     HIPCHK(hipStreamWaitEvent(h->side, h->side_fork, 0));
     return 0;
@@ -1620,6 +1629,7 @@ extern "C" LMI_API int lmi_workspace_bytes(lmi_index* h, int nq, int nb, int64_t
     } else {
         t += std::max<long long>(1, (long long)nb * max_nch * nq) * KPB * 8;   // chunk partial lists of the exact scan
     }
+    t += L * (3 * NGRP + 16) * 4;                                // per-bucket routing arrays, the work queues, the call's chunk lengths
     if (h->metric == LMI_METRIC_L2) t += (long long)nq * (h->d + 1) * 4;
     *bytes = t;
     return 0;
@@ -2073,34 +2083,32 @@ extern "C" LMI_API int lmi_pipeline_submit(lmi_index* h, void* s_in_, void* s_na
 // (LearnedIndex.py:216-252) -- the batched priority-queue walk.  slab_ids[nq][nb] <- slab bucket id of the
 // j-th visited bucket (-1: listed bucket without objects or queue exhausted), entries[nq][nb] <- its flat child
 // index (child_offset[parent model] + class; -1: none) from which the caller rebuilds the path.
-extern "C" LMI_API int lmi_nav_order(lmi_index* h, const float* queries_nav, int nq, int nb, int32_t* slab_ids, int32_t* entries,
-                             int on_device) {
-    if (!h) return fail("lmi_nav_order: NULL handle");
-    if (nq < 0 || nb < 1) return fail("lmi_nav_order: bad nq/n_buckets");
-    if (nq == 0) return 0;
-    if (!h->tree_set) return fail("lmi_nav_order: no tree (lmi_nav_set_model / lmi_nav_set_tree)");
+// The multi-level walk of one batch, enqueued on h->stream: d_slab / d_ent [nq][nb] receive the visited buckets in visiting order.
+// Trees of up to NAV_ENQUEUE_ALL models: EVERY possible step is enqueued up front and a step whose predecessor left no query waiting
+// returns at once (nav_pop_kernel: prev_active) -- no host round trip inside the walk, the call is asynchronous like every other
+// enqueue.  Larger trees: steps in batches of 4 with the count read back after each (one small synchronisation).
+constexpr int NAV_ENQUEUE_ALL = 16;
+static int nav_check(lmi_index* h, int nq, int nb, const char* who) {
+    if (!h->tree_set) return fail("%s: no tree (lmi_nav_set_model / lmi_nav_set_tree)", who);
     CHK(set_dev(h));
     CHK(build_descs(h));
     if (!h->fm_ok || !h->fm_logits_lds)
-        return fail("lmi_nav_order: a model of the tree does not fit the fused kernel (layer outputs <= %d, LDS plan %d bytes)", FM_MAXH, h->fm_lds);
+        return fail("%s: a model of the tree does not fit the fused kernel (layer outputs <= %d, LDS plan %d bytes)", who, FM_MAXH, h->fm_lds);
     const int nm = 1 + (int)h->node_models.size();
     const int cap = h->h_child_offset[nm];
-    if ((long long)nq * cap >= (1ll << 31) || (long long)nq * nb >= (1ll << 31)) return fail("lmi_nav_order: nq too large for this tree");
-    if (cap == 0) return fail("lmi_nav_order: empty tree");
-    const void* d_q = nullptr;
-    CHK(input_ptr(h, queries_nav, (size_t)nq * h->dims[0] * 4, on_device, h->q_nav, &d_q));
+    if ((long long)nq * cap >= (1ll << 31) || (long long)nq * nb >= (1ll << 31)) return fail("%s: nq too large for this tree", who);
+    if (cap == 0) return fail("%s: empty tree", who);
+    return 0;
+}
+static int nav_enqueue(lmi_index* h, const float* d_q, int nq, int nb, int* d_slab, int* d_ent) {
+    const int nm = 1 + (int)h->node_models.size();
+    const int cap = h->h_child_offset[nm];
     CHK(h->pq_prob.reserve((size_t)nq * cap * 4));
     CHK(h->pq_ent.reserve((size_t)nq * cap * 4));
     CHK(h->pq_len.reserve((size_t)nq * 4));
     CHK(h->nav_len.reserve((size_t)nq * 4));
-    CHK(h->nav_slab.reserve((size_t)nq * nb * 4));
-    CHK(h->nav_ent.reserve((size_t)nq * nb * 4));
     CHK(h->nav_count.reserve((size_t)2 * (nm + 1) * 4));  // [2][nm + 1]: per-model counters + the step's active-query count
     CHK(h->nav_colq.reserve((size_t)nm * nq * 4));
-    int* d_slab = on_device ? slab_ids : h->nav_slab.as<int>();
-    int* d_ent = on_device ? entries : h->nav_ent.as<int>();
-    begin_call(h);
-    CHK(record(h, 0));
     FillRanges Z;
     Z.count = 0;
     bool fill_ok = true;
@@ -2115,7 +2123,7 @@ extern "C" LMI_API int lmi_nav_order(lmi_index* h, const float* queries_nav, int
     fill_ranges_kernel<<<h->num_cus * 2, 256, 0, h->stream>>>(Z);
     HIPCHK(hipGetLastError());
     FusedParams P;
-    fused_base(h, static_cast<const float*>(d_q), nq, P);
+    fused_base(h, d_q, nq, P);
     P.pq_prob = h->pq_prob.as<float>();
     P.pq_ent = h->pq_ent.as<int>();
     P.pq_len = h->pq_len.as<int>();
@@ -2137,17 +2145,20 @@ extern "C" LMI_API int lmi_nav_order(lmi_index* h, const float* queries_nav, int
     N.col_query = h->nav_colq.as<int>();
     int* counts = h->nav_count.as<int>();
     // A step pops entries until the query hits an internal node; a query expands each node at most once, so there are
-    // at most (models) steps.  They are enqueued in batches of 4 and the number of queries still waiting for an
-    // expansion is read back after each batch (one small synchronisation).
+    // at most (models) steps.
     const int max_steps = nm + 1;
+    const bool all = nm <= NAV_ENQUEUE_ALL;
+    const bool pop_lds = cap <= NAV_LDS_CAP;
     int h_active = 1;
     for (int it = 0; it < max_steps && h_active > 0;) {
         int last_par = 0;
-        for (int k4 = 0; k4 < 4 && it < max_steps; ++k4, ++it) {
+        for (int k4 = 0; (all || k4 < 4) && it < max_steps; ++k4, ++it) {
             const int par = it & 1;
             N.node_count = counts + par * (nm + 1);
             N.active = counts + par * (nm + 1) + nm;
-            nav_pop_kernel<<<cdiv(nq, 256), 256, 0, h->stream>>>(N);
+            N.prev_active = (all && it > 0) ? counts + (1 - par) * (nm + 1) + nm : nullptr;
+            if (pop_lds) nav_pop_lds_kernel<<<cdiv(nq, 64), 64, (size_t)cap * 64 * 8, h->stream>>>(N);
+            else nav_pop_kernel<<<cdiv(nq, 256), 256, 0, h->stream>>>(N);
             HIPCHK(hipGetLastError());
             P.node_count = N.node_count;
             P.zero_counts = counts + (1 - par) * (nm + 1);
@@ -2156,14 +2167,88 @@ extern "C" LMI_API int lmi_nav_order(lmi_index* h, const float* queries_nav, int
             HIPCHK(hipGetLastError());
             last_par = par;
         }
+        if (all) break;
         HIPCHK(hipMemcpyAsync(&h_active, counts + last_par * (nm + 1) + nm, 4, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
+    return 0;
+}
+
+extern "C" LMI_API int lmi_nav_order(lmi_index* h, const float* queries_nav, int nq, int nb, int32_t* slab_ids, int32_t* entries,
+                             int on_device) {
+    if (!h) return fail("lmi_nav_order: NULL handle");
+    if (nq < 0 || nb < 1) return fail("lmi_nav_order: bad nq/n_buckets");
+    if (nq == 0) return 0;
+    CHK(nav_check(h, nq, nb, "lmi_nav_order"));
+    const void* d_q = nullptr;
+    CHK(input_ptr(h, queries_nav, (size_t)nq * h->dims[0] * 4, on_device, h->q_nav, &d_q));
+    CHK(h->nav_slab.reserve((size_t)nq * nb * 4));
+    CHK(h->nav_ent.reserve((size_t)nq * nb * 4));
+    int* d_slab = on_device ? slab_ids : h->nav_slab.as<int>();
+    int* d_ent = on_device ? entries : h->nav_ent.as<int>();
+    begin_call(h);
+    CHK(record(h, 0));
+    CHK(nav_enqueue(h, static_cast<const float*>(d_q), nq, nb, d_slab, d_ent));
     CHK(record(h, 1));
     CHK(stamp_end(h, ST_MLP1));
     if (!on_device) {
         HIPCHK(hipMemcpyAsync(slab_ids, d_slab, (size_t)nq * nb * 4, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(entries, d_ent, (size_t)nq * nb * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return 0;
+}
+
+// LearnedIndex.search for a multi-level index in ONE call (LearnedIndex.py:216-325 the walk, :328-373 the bucket scans): lmi_nav_order +
+// lmi_scan_topk without the host in between.  Host buffers: the scan vectors' upload (30 MB at 10 000 x 768: 1.2 ms from pageable memory)
+// goes over the library's side stream WHILE the walk runs (0.4-1 ms); the walk's bucket order never leaves the device unless asked for.
+extern "C" LMI_API int lmi_search_tree(lmi_index* h, const float* queries_nav, const float* queries_search, int nq, int nb, int k,
+                               float* dists, uint32_t* ids, uint32_t* keys, int32_t* slab_ids, int32_t* entries, int on_device) {
+    if (!h) return fail("lmi_search_tree: NULL handle");
+    int kout = 0;
+    CHK(check_scan_args(h, nq, nb, k, &kout));
+    if (nq == 0) return 0;
+    CHK(nav_check(h, nq, nb, "lmi_search_tree"));
+    const void* d_qn = nullptr;
+    const void* d_qs = queries_search;
+    CHK(input_ptr(h, queries_nav, (size_t)nq * h->dims[0] * 4, on_device, h->q_nav, &d_qn));
+    const bool same = queries_search == queries_nav && h->dims[0] == h->d_user;
+    if (same) d_qs = d_qn;
+    CHK(h->nav_slab.reserve((size_t)nq * nb * 4));
+    CHK(h->nav_ent.reserve((size_t)nq * nb * 4));
+    int* d_slab = (on_device && slab_ids) ? slab_ids : h->nav_slab.as<int>();
+    int* d_ent = (on_device && entries) ? entries : h->nav_ent.as<int>();
+    float* d_d = dists;
+    uint32_t* d_i = ids;
+    uint32_t* d_k = keys;
+    if (!on_device) {
+        CHK(h->out_d.reserve((size_t)nq * kout * 4));
+        CHK(h->out_id.reserve((size_t)nq * kout * 4));
+        d_d = h->out_d.as<float>();
+        d_i = h->out_id.as<uint32_t>();
+        if (keys) { CHK(h->out_key.reserve((size_t)nq * kout * 4)); d_k = h->out_key.as<uint32_t>(); }
+        if (!same) CHK(h->q_srch.reserve((size_t)nq * h->d_user * 4));
+    }
+    begin_call(h);
+    CHK(record(h, 0));
+    CHK(nav_enqueue(h, static_cast<const float*>(d_qn), nq, nb, d_slab, d_ent));
+    CHK(record(h, 1));
+    CHK(stamp_end(h, ST_MLP1));
+    if (!on_device && !same) {
+        // the scan vectors: uploaded beside the walk (the copy's host side returns when the bytes are staged; the stream waits for its event)
+        CHK(side_ensure(h));   // (no fork: the buffer's last reader was the previous call's scan, and a host-buffer call ends synchronised)
+        HIPCHK(hipMemcpyAsync(h->q_srch.p, queries_search, (size_t)nq * h->d_user * 4, hipMemcpyHostToDevice, h->side));
+        HIPCHK(hipEventRecord(h->side_join, h->side));
+        HIPCHK(hipStreamWaitEvent(h->stream, h->side_join, 0));
+        d_qs = h->q_srch.p;
+    }
+    CHK(scan_enqueue(h, static_cast<const float*>(d_qs), nq, d_slab, nb, kout, 0, d_d, d_i, d_k));
+    if (!on_device) {
+        HIPCHK(hipMemcpyAsync(dists, d_d, (size_t)nq * kout * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(ids, d_i, (size_t)nq * kout * 4, hipMemcpyDeviceToHost, h->stream));
+        if (keys) HIPCHK(hipMemcpyAsync(keys, d_k, (size_t)nq * kout * 4, hipMemcpyDeviceToHost, h->stream));
+        if (slab_ids) HIPCHK(hipMemcpyAsync(slab_ids, d_slab, (size_t)nq * nb * 4, hipMemcpyDeviceToHost, h->stream));
+        if (entries) HIPCHK(hipMemcpyAsync(entries, d_ent, (size_t)nq * nb * 4, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     return 0;

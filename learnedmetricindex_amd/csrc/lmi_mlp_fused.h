@@ -345,20 +345,46 @@ struct NavParams {
     int* node_count;          // [n_models] this step's counters (zeroed by the previous step)
     int* col_query;           // [n_models][nq]
     int* active;              // queries waiting for an expansion after this step
+    const int* prev_active;   // nullable: the same count of the step before -- 0: the walk is over, this launch returns (the host then
+                              // enqueues every possible step up front instead of reading the count back)
 };
 
+// The queries of a wave that stopped at an internal node queue up for its model: ONE counter atomic per (wave, model) and one for the
+// step's count of waiting queries (round 5: 2 atomics per query on 1 + n_models addresses were most of the step -- 10 000 queries: 40-100 us).
+// my_cm: the lane's model, -1: none.  Every lane of the wave must call (no early returns in front).
+__device__ __forceinline__ void nav_push(const NavParams& P, int q, int my_cm) {
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    unsigned long long todo = __ballot(my_cm >= 0);
+    const int total = (int)__popcll(todo);
+    if (total == 0) return;
+    const int first = __ffsll((long long)todo) - 1;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int cm = __shfl(my_cm, leader, 64);
+        const unsigned long long same = __ballot(my_cm == cm);
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(same >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)same, 0u));
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&P.node_count[cm], (int)__popcll(same));
+        base = __shfl(base, leader, 64);
+        if (my_cm == cm) P.col_query[(size_t)cm * P.nq + base + rank] = q;
+        todo &= ~same;
+    }
+    if (lane == first) atomicAdd(P.active, total);
+}
+
 __global__ __launch_bounds__(256) void nav_pop_kernel(NavParams P) {
+    if (P.prev_active && *P.prev_active == 0) return;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= P.nq) return;
-    int have = P.out_len[q];
-    if (have >= P.nb) return;
-    const float* pp = P.pq_prob + q;   // entry i at [i * nq]
-    int* pe = P.pq_ent + q;
-    const int len = P.pq_len[q];
+    const bool live = q < P.nq;
+    int have = live ? P.out_len[q] : P.nb;
+    const float* pp = P.pq_prob + (live ? q : 0);   // entry i at [i * nq]
+    int* pe = P.pq_ent + (live ? q : 0);
+    const int len = (live && have < P.nb) ? P.pq_len[q] : 0;
     // Bucket pops change nothing but the queue, so they continue within this step; the walk pauses at the first
     // internal node (its children's probabilities come from this step's grouped MLP launch) -- the same sequence
     // of pops as the reference's one-pop-per-iteration loop, in fewer launches.
-    for (;;) {
+    int my_cm = -1;
+    while (len > 0) {
         float best = 0.0f;
         int bi = -1;
         for (int i = 0; i < len; ++i) {
@@ -366,23 +392,75 @@ __global__ __launch_bounds__(256) void nav_pop_kernel(NavParams P) {
             const float v = pp[(size_t)i * P.nq];
             if (bi < 0 || v >= best) { best = v; bi = i; }  // >=: the later entry wins a tie
         }
-        if (bi < 0) return;  // queue exhausted: the remaining slots stay EMPTY (the reference would fail here)
+        if (bi < 0) break;  // queue exhausted: the remaining slots stay EMPTY (the reference would fail here)
         const int ent = pe[(size_t)bi * P.nq];
         pe[(size_t)bi * P.nq] = -1;
         const int cm = P.child_model[ent], cb = P.child_bucket[ent];
-        if (cm >= 0) {
-            const int pos = atomicAdd(&P.node_count[cm], 1);
-            P.col_query[(size_t)cm * P.nq + pos] = q;
-            atomicAdd(P.active, 1);
-            return;
-        }
+        if (cm >= 0) { my_cm = cm; break; }
         if (cb >= -1) {
             P.out_slab[(size_t)q * P.nb + have] = cb;
             P.out_ent[(size_t)q * P.nb + have] = ent;
             P.out_len[q] = ++have;
-            if (have >= P.nb) return;
+            if (have >= P.nb) break;
         }
     }
+    nav_push(P, q, my_cm);
+}
+
+// The same step for trees whose queues fit LDS (cap <= NAV_LDS_CAP entries: [10, 10] has 110): a wave per 64 queries reads their queues
+// ONCE (entry-major: a 256-byte row per entry) and every pop scans LDS instead of global memory -- a step's ~10 pops x up to 110
+// entries per query took 43-101 us of a 0.96-ms walk at 10 000 queries (round 5 trace, profiles/r05_nav.txt); same pops, same order.
+constexpr int NAV_LDS_CAP = 128;
+__global__ __launch_bounds__(64) void nav_pop_lds_kernel(NavParams P) {
+    extern __shared__ __attribute__((aligned(16))) char nav_smem[];
+    if (P.prev_active && *P.prev_active == 0) return;
+    float* sp = reinterpret_cast<float*>(nav_smem) + threadIdx.x;      // [cap][64]: this lane's column
+    int* se = reinterpret_cast<int*>(nav_smem) + P.cap * 64 + threadIdx.x;
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    const bool live = q < P.nq;
+    int have = live ? P.out_len[q] : P.nb;
+    const int len = (live && have < P.nb) ? P.pq_len[q] : 0;
+    const float* pp = P.pq_prob + (live ? q : 0);
+    int* pe = P.pq_ent + (live ? q : 0);
+    int mx = len;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+    for (int i0 = 0; i0 < mx; i0 += 16) {   // 32 loads in flight per lane, then their LDS stores (clamped addresses: no branch per load)
+        float v[16];
+        int e[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const size_t o = (size_t)min(i0 + j, max(len - 1, 0)) * P.nq;
+            v[j] = pp[o];
+            e[j] = pe[o];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (i0 + j < len) { sp[(i0 + j) * 64] = v[j]; se[(i0 + j) * 64] = e[j]; }
+    }
+    int my_cm = -1;
+    while (len > 0) {
+        float best = 0.0f;
+        int bi = -1;
+        for (int i = 0; i < len; ++i) {
+            const int e = se[i * 64];
+            const float v = sp[i * 64];
+            if (e >= 0 && (bi < 0 || v >= best)) { best = v; bi = i; }  // >=: the later entry wins a tie
+        }
+        if (bi < 0) break;
+        const int ent = se[bi * 64];
+        se[bi * 64] = -1;
+        pe[(size_t)bi * P.nq] = -1;
+        const int cm = P.child_model[ent], cb = P.child_bucket[ent];
+        if (cm >= 0) { my_cm = cm; break; }
+        if (cb >= -1) {
+            P.out_slab[(size_t)q * P.nb + have] = cb;
+            P.out_ent[(size_t)q * P.nb + have] = ent;
+            P.out_len[q] = ++have;
+            if (have >= P.nb) break;
+        }
+    }
+    nav_push(P, q, my_cm);
 }
 
 }  // namespace lmi

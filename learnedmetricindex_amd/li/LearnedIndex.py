@@ -309,10 +309,11 @@ class LearnedIndex(Logger):
                 t = eng.timings() * 1e-3
                 measured_time["inference"] += float(t[_capi.T_INFERENCE])
             else:
-                ids, _ = eng.nav_order(qn_c, n_buckets)        # the priority-queue walk, on the device
-                measured_time["inference"] += float(eng.timings()[_capi.T_INFERENCE]) * 1e-3
-                d32, nn = eng.scan_topk(qs_c, ids, k)
+                # the priority-queue walk on the device, then the scan of its buckets: one call (lmi_search_tree), the scan vectors
+                # uploaded while the walk runs
+                d32, nn = eng.search_tree(qn_c, qs_c, n_buckets, k)
                 t = eng.timings() * 1e-3
+                measured_time["inference"] += float(t[_capi.T_INFERENCE])
             measured_time["search_within_buckets"] += float(t[_capi.T_ROUTE] + t[_capi.T_SCAN] + t[_capi.T_MERGE])
             measured_time["seq_search"] += float(t[_capi.T_SCAN])
             measured_time["sort"] += float(t[_capi.T_MERGE])

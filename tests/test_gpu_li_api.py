@@ -177,6 +177,28 @@ def test_multi_level_index(oracle, name):
     assert same.all()   # pinned: 0 rows differ on G2, G7, G8 (tests/test_oracle_multilevel.py::PINNED_ORDER_DIFFS)
     compare_modulo_near_ties(g["ref_dists"], g["ref_nns"], dists, nns)
     assert mt["inference"] > 0 and mt["seq_search"] > 0
+    # lmi_search_tree (one call, scan vectors uploaded beside the walk) against lmi_nav_order + lmi_scan_topk, host and device buffers
+    eng = li._engine
+    slab, ent = eng.nav_order(Qn, nb)
+    d_a, i_a = eng.scan_topk(Qs, slab, k)
+    d_b, i_b, slab_b, ent_b = eng.search_tree(Qn, Qs, nb, k, want_order=True)
+    for a, b in ((d_a, d_b), (i_a, i_b), (slab, slab_b), (ent, ent_b)):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(i_b, nns)
+    dev = torch.device("cuda", 0)
+    qn_t, qs_t = torch.from_numpy(np.ascontiguousarray(Qn)).to(dev), torch.from_numpy(np.ascontiguousarray(Qs)).to(dev)
+    ko = eng.kout(nb, k)
+    d_t = torch.empty((Qn.shape[0], ko), dtype=torch.float32, device=dev)
+    i_t = torch.empty((Qn.shape[0], ko), dtype=torch.int32, device=dev)
+    slab_t = torch.empty((Qn.shape[0], nb), dtype=torch.int32, device=dev)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    for _ in range(2):   # (twice: the walk's per-call state is re-initialised by the call itself)
+        eng.search_tree_device(qn_t, qs_t, nb, k, d_t, i_t, None, slab_t, None)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(i_t.cpu().numpy().view(np.uint32), i_b)
+    np.testing.assert_array_equal(d_t.cpu().numpy(), d_b)
+    np.testing.assert_array_equal(slab_t.cpu().numpy(), slab)
+    eng.set_stream(0)
     if name == "G7":   # the walk in query chunks (a tree whose queues would not fit lmi_nav_order's limit)
         li._NAV_QUEUE_BYTES = 8 * 110 * 37
         d2, n2, _ = li.search(nav, Qn, srch, Qs, dp, ncat, nb, k)
@@ -184,6 +206,46 @@ def test_multi_level_index(oracle, name):
         np.testing.assert_array_equal(bo2, bo)
         np.testing.assert_array_equal(n2, nns)
         np.testing.assert_array_equal(d2, dists)
+    li.close()
+
+
+@pytest.mark.parametrize("ncat,what", [([20, 3], "21 models: steps in batches with the count read back; queues in LDS"),
+                                       ([12, 12], "13 models: every step enqueued up front; 156-entry queues stay in global memory"),
+                                       ([5, 4], "small: everything up front, queues in LDS")])
+def test_walk_forms_against_the_oracle(oracle, ncat, what):
+    """The walk's launch forms (lmi_hip.hip nav_enqueue: NAV_ENQUEUE_ALL, NAV_LDS_CAP) on synthetic two-level trees with random models:
+    bucket order and results equal the oracle's restatement of LearnedIndex.py:216-325."""
+    from learnedmetricindex_amd.li.LearnedIndex import LearnedIndex
+    from learnedmetricindex_amd.li.model import NeuralNetwork
+
+    rs = np.random.RandomState(sum(ncat))
+    d_nav, d_s, N, nq, nb, k = 16, 24, 4000, 300, 7, 10
+
+    def layers_of(net):   # whatever hidden width the li model has: take the oracle's layers from the module itself
+        return [(m.weight.detach().cpu().numpy().copy(), m.bias.detach().cpu().numpy().copy()) for m in net.model.layers if isinstance(m, torch.nn.Linear)]
+
+    root = NeuralNetwork(input_dim=d_nav, output_dim=ncat[0], model_type="MLP")
+    nets = {(i, -1): NeuralNetwork(input_dim=d_nav, output_dim=ncat[1], model_type="MLP") for i in range(ncat[0])}
+    for net in [root] + list(nets.values()):
+        with torch.no_grad():
+            for m in net.model.layers:
+                if isinstance(m, torch.nn.Linear):
+                    m.weight.copy_(torch.from_numpy((rs.randn(*m.weight.shape) * 0.5).astype(np.float32)))
+                    m.bias.copy_(torch.from_numpy((rs.randn(*m.bias.shape) * 0.1).astype(np.float32)))
+    bucket_paths = [(i, j) for i in range(ncat[0]) for j in range(ncat[1])]
+    dp = np.stack([rs.randint(0, ncat[0], N), rs.randint(0, ncat[1], N)], axis=1).astype(np.int64)
+    dp[dp[:, 0] == 1] = (1, 0)   # node 1: one bucket with rows, its other children listed and empty
+    Xn, Xs = rs.randn(N, d_nav).astype(np.float32), rs.randn(N, d_s).astype(np.float32)
+    Qn, Qs = rs.randn(nq, d_nav).astype(np.float32), rs.randn(nq, d_s).astype(np.float32)
+    li = LearnedIndex(root, nets, bucket_paths)
+    dists, nns, _ = li.search(frame(Xn), Qn, frame(Xs), Qs, dp, ncat, nb, k)
+    bo, _ = li._precompute_bucket_order(Qn, nb, ncat)
+    internal = [(p, layers_of(n)) for p, n in nets.items()]
+    bo_o = oracle.precompute_bucket_order_multilevel(layers_of(root), internal, bucket_paths, Qn, nb, ncat)
+    np.testing.assert_array_equal(bo, bo_o)
+    do, no, _ = oracle.search(layers_of(root), Qn, Xs, Qs, dp, nb, k, bucket_order=bo_o)
+    np.testing.assert_array_equal(nns, no)
+    np.testing.assert_array_equal(dists, do)
     li.close()
 
 
