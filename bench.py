@@ -1171,6 +1171,8 @@ def main():
             out.update(extra)
             return out
         legs = {"c2": leg(result["value"], result["ms_per_step"], roof, cpu is not None, recall=result["recall_at_10"])}
+        if isinstance(result.get("resident"), dict):   # inputs and results in HBM (no PCIe): `value` is the host -> host rate, the lower of the two
+            legs["c2"]["hbm_resident_qps"] = round(result["resident"]["value"])
         if hard:
             legs["hard"] = leg(hard["value"], hard["ms_per_step"], hard.get("roofline"), hard.get("oracle_check"), recall=hard["recall_at_10"])
         if exact_leg:
