@@ -1147,6 +1147,9 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
     {
         const int base = h->chunk_rows;
         int rows[3] = {base, base / 2, base / 4};   // (longer than the static chunk: no gain at C2, and a 4 096-row chunk of 768-d rows no longer fits an L2 beside a second query tile: hard leg +3.5 %)
+        // d <= 128 (lmi_pass2_small.h): an item's start and end are a fifth of its time there and the rows are short -- twice the static chunk for the
+        // buckets served first (10M x 45: pass 2 0.270 -> 0.256-0.262 ms; four times: 0.38, too few items for 512 workgroups)
+        if (h->pf_small && h->KG16 <= PS_MAXKG) rows[0] = 2 * base;
         for (int i = 0; i < 3; ++i) {
             if (h->chunk_lvl_rows[i] > 0) rows[i] = h->chunk_lvl_rows[i];
             rows[i] = std::max(P2_TILE_ROWS, rows[i] / P2_TILE_ROWS * P2_TILE_ROWS);
