@@ -284,15 +284,15 @@ extern "C" LMI_API int lmi_create(int device, lmi_index** out) {
     LMI_PS_ATTR(1) LMI_PS_ATTR(2) LMI_PS_ATTR(3) LMI_PS_ATTR(4) LMI_PS_ATTR(5) LMI_PS_ATTR(6) LMI_PS_ATTR(7) LMI_PS_ATTR(8)
 #undef LMI_PS_ATTR
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, RC_SMALL_LDS_CAP));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, RC_SMALL_LDS_CAP));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, RC_SMALL_LDS_CAP));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rescore_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, RC_SMALL_LDS_CAP));
 #define LMI_TL_ATTR(GV) \
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<GV>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<GV>), hipFuncAttributeMaxDynamicSharedMemorySize, RC_SMALL_LDS_CAP));
     LMI_TL_ATTR(1) LMI_TL_ATTR(2) LMI_TL_ATTR(3) LMI_TL_ATTR(4)
 #undef LMI_TL_ATTR
     *out = h;
@@ -1056,7 +1056,7 @@ extern "C" LMI_API int lmi_mlp_proba(lmi_index* h, const float* queries_nav, int
 
 // the exact re-rank runs in its streamed form (select_kernel + rescore_kernel, lmi_rescore.h) for these shapes
 static bool rescore_is_streamed(const lmi_index* h) {
-    return h->rescore_streamed && rc_waves_for(h->dp, 4) > 0 && rc_wave_lds(h->dp, 4, true) <= 64 * 1024;
+    return h->rescore_streamed && rc_waves_for(h->dp, 4) > 0 && rc_wave_lds(h->dp, 4, true) <= RC_SMALL_LDS_CAP;
 }
 static int rescore_group_size(int nb) { return nb % 4 == 0 ? 4 : nb % 3 == 0 ? 3 : nb % 2 == 0 ? 2 : 1; }
 
@@ -1435,7 +1435,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
         // but there the five launches are faster -- 4M x 768, 16 buckets: re-rank 0.39 against 0.25 ms; 4M x 45, 2 000 leaves, 8 buckets: 0.23 against
         // 0.18: most of the 160 000+ slots have nothing to re-rank, which select_kernel's compacted lists skip and a wave per group does not
         use_tail = rescore_is_streamed(h) && h->use_tail && (rescore_group_size(nb) == nb || h->use_tail == 2) &&
-                   RC_WAVES * tail_wave_lds(h->dp, rescore_group_size(nb), true) <= 64 * 1024;
+                   RC_WAVES * tail_wave_lds(h->dp, rescore_group_size(nb), true) <= RC_SMALL_LDS_CAP;
         tail_merges = use_tail && rescore_group_size(nb) == nb;
         // The overflow machinery (overflow_rebound_kernel + pass 2's redo launch: two launches that return at once on ordinary batches,
         // 11 us of a 0.2-0.5 ms search) stays OUT of the fused-tail sequence until a batch needs it: fallback_kernel then picks a flagged
@@ -1545,7 +1545,7 @@ static int scan_enqueue(lmi_index* h, const float* d_qs, int nq, const int* d_or
             HIPCHK(hipGetLastError());
             // (wide rows: fewer waves per block in the big form, whose per-wave buffers hold the query and 256 survivors per slot; the small
             // form keeps four waves as long as a block stays under 64 KiB)
-            const int wb = rc_waves_for(h->dp, G), ws = RC_WAVES * rc_wave_lds(h->dp, G, true) <= 64 * 1024 ? RC_WAVES : 1;
+            const int wb = rc_waves_for(h->dp, G), ws = RC_WAVES * rc_wave_lds(h->dp, G, true) <= RC_SMALL_LDS_CAP ? RC_WAVES : 1;
             const int blocks = cdiv(groups, ws);
             const int lds = wb * rc_wave_lds(h->dp, G), lds_s = ws * rc_wave_lds(h->dp, G, true);
             // first every group in the small-LDS form (three blocks per CU), then the groups it passed on (more survivors than it holds)

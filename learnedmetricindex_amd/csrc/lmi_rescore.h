@@ -181,7 +181,11 @@ __global__ __launch_bounds__(256) void select_kernel(RescoreParams P, SelectOut 
 // occupancy, so more waves in flight is what it needs; a group with more survivors goes onto the `big` list and the second launch
 // (!SMALL: one wave per SIMD, room for G x RC_KEEP survivors) takes those.
 constexpr int RC_SMALL_ROWS = 28;                 // 4 LDS-DMA pieces of 7 rows
-constexpr int RC_SMALL_RING = 8 * 1024;           // chunk buffers of the small form (4 x 2 pieces or 2 x 4 pieces)
+#ifndef LMI_RC_SMALL_RING
+#define LMI_RC_SMALL_RING (8 * 1024)
+#endif
+constexpr int RC_SMALL_LDS_CAP = 64 * 1024 + RC_WAVES * (LMI_RC_SMALL_RING - 8 * 1024);   // dynamic LDS a block of the small-form kernels may ask for
+constexpr int RC_SMALL_RING = LMI_RC_SMALL_RING;  // chunk buffers of the small form (4 x 2 pieces or 2 x 4 pieces)
 // dynamic LDS per wave: chunk buffers | q [d] | rows [KEEPW] | scores [KEEPW]
 __host__ __device__ inline int rc_wave_lds(int d, int G, bool small_form = false) {
     return small_form ? RC_SMALL_RING + d * 4 + 32 * 8 : RC_DEPTH * RC_BUF + d * 4 + G * RC_KEEP * 8;
