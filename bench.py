@@ -1168,6 +1168,8 @@ def main():
             out = {"qps": None if v is None else round(v), "ms": None if ms is None else round(ms, 4),
                    "frac": None if not roofv else roofv.get("frac"), "kernel_ms": None if not roofv else roofv.get("avg_launch_ms"),
                    "oracle_ok": bool(checked)}
+            if roofv and roofv.get("shader_clock_mhz_under_kernel"):   # the clock THIS box held under the kernel (boxes differ: 1.65-1.88 GHz under pass 2)
+                out["mhz"] = round(roofv["shader_clock_mhz_under_kernel"])
             out.update(extra)
             return out
         legs = {"c2": leg(result["value"], result["ms_per_step"], roof, cpu is not None, recall=result["recall_at_10"])}
