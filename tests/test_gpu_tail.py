@@ -1,7 +1,7 @@
 """GPU (`-m gpu`): the fused tail (lmi_tail.h: selection + exact re-rank + rank merge in one wave per query, LMI_TAIL=1, the default)
 against the five launches it replaces (LMI_TAIL=0) and the all-f32 scan, bit for bit -- every group size (n_buckets 1..4: a query per wave, merged
 in the wave; 5 / 6 / 8 / 10: groups of 1 / 3 / 4 / 2 slots per wave + merge_ranks_kernel), the
-hand-overs (queries with more survivors than the small ring holds -> tail_big_kernel; slots whose candidates overflow or with
+hand-overs (queries with more survivors than the small ring holds -> batches inside the kernel; slots whose candidates overflow or with
 hundreds of survivors -> fallback_kernel, which then merges the query), unvisited and repeated slots, k != 10, the L2 metric."""
 import os
 
