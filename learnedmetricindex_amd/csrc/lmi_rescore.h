@@ -323,9 +323,13 @@ __device__ __forceinline__ void rc_stream_batch(const RescoreParams& P, unsigned
 // The re-rank proper, shared by rescore_kernel and tail_kernel (lmi_tail.h): the wave's survivors krow[0, off[G]) (absolute slab rows, slot after
 // slot) and its query are in LDS; rows streamed, canonical chains, then every slot's rank list.  LCOPY: the lists also go to the
 // wave's LDS copy rl_d / rl_i [G][KPB] (the caller merges them in the wave).  colv / fbv: the slots' columns and fallback flags.
-template <int G, bool SMALL, bool LCOPY>
+// PRE (tail_kernel, round 5): what the rank lists need from global memory was requested by the caller BEFORE the rows were streamed -- the id of
+// survivor `lane` (my_id), and per slot the bucket's first slab row, its row count and the id of its last row (the padding) -- instead of
+// three more dependent round trips at the wave's end (a tail wave is parked on memory two thirds of its life: profiles/r05_tail_ring.txt).
+template <int G, bool SMALL, bool LCOPY, bool PRE = false>
 __device__ __forceinline__ void rescore_core(const RescoreParams& P, const RcWave<G, SMALL>& W, const int (&off)[G + 1], int p0, int lane,
-                                             const int (&colv)[G], const int (&fbv)[G], float* rl_d, unsigned* rl_i) {
+                                             const int (&colv)[G], const int (&fbv)[G], float* rl_d, unsigned* rl_i,
+                                             unsigned my_id = 0u, const unsigned* row_base = nullptr, const int* nbr = nullptr, const unsigned* pad_id = nullptr) {
     unsigned char* mine = W.mine;   // (rows of pitch P.dp: the chain runs over the zero padding too -- +0 * +0 added to the sum changes nothing)
     unsigned* krow = W.krow;
     float* ksc = W.ksc;
@@ -353,7 +357,15 @@ __device__ __forceinline__ void rescore_core(const RescoreParams& P, const RcWav
                 const int p = p0 + sl;
                 const float dv = P.raw ? sc : sim_to_dist(sc, P.qn2, p / P.nb);
                 // (krow holds absolute slab rows; the raw form -- lmi_knn_ip -- returns the row inside its bucket)
-                const unsigned iv = P.raw ? row - (unsigned)P.rb_start[P.bucket_order[p]] * 32u : P.ids_slab[row];
+                unsigned iv;
+                if constexpr (PRE) {
+                    unsigned rbase = row_base[0];
+#pragma unroll
+                    for (int t = 1; t < G; ++t) rbase = sl == t ? row_base[t] : rbase;
+                    iv = P.raw ? row - rbase : my_id;   // (PRE: total <= 64, survivor i sits in lane i)
+                } else {
+                    iv = P.raw ? row - (unsigned)P.rb_start[P.bucket_order[p]] * 32u : P.ids_slab[row];
+                }
                 P.rank_d[(size_t)p * KPB + pos] = dv;
                 P.rank_id[(size_t)p * KPB + pos] = iv;
                 if (LCOPY) { rl_d[sl * KPB + pos] = dv; rl_i[sl * KPB + pos] = iv; }
@@ -366,12 +378,21 @@ __device__ __forceinline__ void rescore_core(const RescoreParams& P, const RcWav
         for (int sl = 0; sl < G; ++sl) {
             const int p = p0 + sl;
             if (colv[sl] < 0 || fbv[sl]) continue;  // written by the selection / recomputed by fallback_kernel
-            const int b = P.bucket_order[p];
-            const int rb0 = P.rb_start[b], n_b = P.nb_rows[b];
+            int n_b;
+            unsigned pad_iv;
+            if constexpr (PRE) {
+                n_b = nbr[sl];
+                pad_iv = pad_id[sl];
+            } else {
+                const int b = P.bucket_order[p];
+                const int rb0 = P.rb_start[b];
+                n_b = P.nb_rows[b];
+                pad_iv = P.raw ? NOROW : P.ids_slab[(size_t)rb0 * 32 + (n_b - 1)];
+            }
             const int nreal = min(min(off[sl + 1] - off[sl], KPB), n_b);
             if (lane >= nreal) {
                 const float dv = P.raw ? -FMAXV : pad_dist(P.qn2);
-                const unsigned iv = P.raw ? NOROW : P.ids_slab[(size_t)rb0 * 32 + (n_b - 1)];
+                const unsigned iv = P.raw ? NOROW : pad_iv;
                 P.rank_d[(size_t)p * KPB + lane] = dv;
                 P.rank_id[(size_t)p * KPB + lane] = iv;
                 if (LCOPY) { rl_d[sl * KPB + lane] = dv; rl_i[sl * KPB + lane] = iv; }

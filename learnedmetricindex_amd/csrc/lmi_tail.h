@@ -106,20 +106,24 @@ __global__ __launch_bounds__(64 * RC_WAVES, 3) void tail_kernel(RescoreParams P,
     const float FMAXV = 3.402823466e+38f;
     constexpr int SPEC = 4;
     constexpr int PER = PF_CAP / 64;
-    // ---- round trip 1: the slots' columns; 2: counts, the first 256 candidates, eps', buckets; 3: the buckets' first rows ----
-    int colv[G], fbv[G], off[G + 1], bkt[G];
-    unsigned cnt[G], row_base[G];
+    // ---- round trip 1: the slots' columns and buckets; 2: counts, the first 256 candidates, eps', the buckets' first rows and sizes; 3 (not waited
+    //      for until the rank lists): the id of each bucket's last row (faiss padding, Q4) ----
+    int colv[G], fbv[G], off[G + 1], bkt[G], nbr[G];
+    unsigned cnt[G], row_base[G], pad_id[G];
     float e2[G];
     float s_spec[G][SPEC];
     unsigned r_spec[G][SPEC];
 #pragma unroll
-    for (int sl = 0; sl < G; ++sl) colv[sl] = P.slot_col[p0 + sl];
+    for (int sl = 0; sl < G; ++sl) { colv[sl] = P.slot_col[p0 + sl]; bkt[sl] = P.bucket_order[p0 + sl]; }
+    W.stage_query(P, q, lane);   // the query's row travels with round trip 1 (it used to be a round trip of its own behind the selection)
 #pragma unroll
     for (int sl = 0; sl < G; ++sl) {
         const size_t c = (size_t)(colv[sl] < 0 ? 0 : colv[sl]);
+        if (colv[sl] < 0) bkt[sl] = 0;   // (a visited slot's bucket id is valid and the bucket has rows: the routing kernels said so)
         cnt[sl] = colv[sl] < 0 ? 0u : P.cand_cnt[c];
         e2[sl] = colv[sl] < 0 ? 0.0f : P.eps2[c];
-        bkt[sl] = colv[sl] < 0 ? 0 : P.bucket_order[p0 + sl];
+        row_base[sl] = colv[sl] < 0 ? 0u : (unsigned)P.rb_start[bkt[sl]] * 32u;
+        nbr[sl] = colv[sl] < 0 ? 0 : P.nb_rows[bkt[sl]];
 #pragma unroll
         for (int i = 0; i < SPEC; ++i) {
             s_spec[sl][i] = colv[sl] < 0 ? 0.0f : P.cand_s[c * PF_CAP + lane + 64 * i];
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(64 * RC_WAVES, 3) void tail_kernel(RescoreParams P,
         }
     }
 #pragma unroll
-    for (int sl = 0; sl < G; ++sl) row_base[sl] = colv[sl] < 0 ? 0u : (unsigned)P.rb_start[bkt[sl]] * 32u;
+    for (int sl = 0; sl < G; ++sl) pad_id[sl] = (colv[sl] < 0 || P.raw || nbr[sl] <= 0) ? NOROW : P.ids_slab[(size_t)row_base[sl] + (unsigned)(nbr[sl] - 1)];
     off[0] = 0;
     int nflag = 0;
 #pragma unroll
@@ -168,11 +172,12 @@ __global__ __launch_bounds__(64 * RC_WAVES, 3) void tail_kernel(RescoreParams P,
     }
     if (lane == 0 && T.merge) T.pending[q] = nflag;
     const int total = off[G];
-    if (total > 0) W.stage_query(P, q, lane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (total <= RC_SMALL_ROWS) {
-        rescore_core<G, true, true>(P, W, off, p0, lane, colv, fbv, rl_d, rl_i);
+        // the survivors' ids: requested now, used behind the chains
+        const unsigned my_id = (lane < total && !P.raw) ? P.ids_slab[W.krow[lane]] : 0u;
+        rescore_core<G, true, true, true>(P, W, off, p0, lane, colv, fbv, rl_d, rl_i, my_id, row_base, nbr, pad_id);
     } else {
         // More survivors than the small ring holds at once (a few per cent of the queries at C2, none at most shapes; round 4 and the
         // first form of this file passed them on to a second launch with a big ring -- 16-35 us per search, most of it the launch's
