@@ -224,6 +224,12 @@ class Workload:
         sync_all()
         eng.timings_reset()
         stamps = []
+        # no garbage collection inside the timed region: a collection that finalises an earlier leg's device tensors ends in hipFree, which
+        # synchronises the device (seen as one 30-ms step in a tenth of the multi-leg runs' hard legs: 6.1 -> 8.7-10.3 ms per step over 10 steps)
+        import gc
+        gc.collect()
+        gc_was = gc.isenabled()
+        gc.disable()
         t0 = time.perf_counter()
         for i in range(steps):
             ticket = pipe.submit(q_hosts[(steps - 1 - i) % nrot])   # ... the last step submits batch 0
@@ -231,6 +237,8 @@ class Workload:
         pipe.drain()
         sync_all()
         elapsed = time.perf_counter() - t0
+        if gc_was:
+            gc.enable()
         if os.environ.get("LMI_BENCH_DEBUG") and rank == 0:
             log(f"[bench:{self.tag}] submit returned at (ms): {[round(v * 1e3, 2) for v in stamps]}; end {elapsed * 1e3:.2f}")
         # device clock stamps (or, at --timing-level 3, hipEvents) on the kernels' own stream around every phase of every step; read
