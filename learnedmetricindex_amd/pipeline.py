@@ -271,10 +271,16 @@ class HostPipeline:
         return s["d_h"].numpy(), s["i_h"].numpy().view(np.uint32)
 
     def bucket_order(self, ticket: int) -> np.ndarray:
-        assert self.want_bo
+        """The batch's bucket order [nq, nb].  `want_bucket_order=True` downloads it with every batch (a kernel behind the search: 18 us of a
+        0.5-ms step at 10M x 45); without it -- the reference's `search` returns no bucket order -- the single-GPU forms keep it in the
+        slot's device buffer and this call fetches it on demand (valid until the slot is reused)."""
+        assert self.t - self.depth <= ticket < self.t, "ticket no longer (or not yet) in the ring"
         s = self.slots[ticket % self.depth]
         s["ev_out"].synchronize()
-        return s["bo_h"].numpy()
+        if self.want_bo:
+            return s["bo_h"].numpy()
+        assert self.search_fn is None and self.sharded is None, "bucket order on demand: single-GPU forms only (pass want_bucket_order=True)"
+        return s["bo_d"].cpu().numpy()
 
     def drain(self) -> None:
         for s in self.slots:

@@ -11,11 +11,14 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("name,depth,mode", [("G3", 2, "nav"), ("G6", 3, "nav"), ("G4", 1, "nav"), ("G3", 2, "plain"), ("G6", 2, "twin"),
-                                             ("G3", 2, "nav+direct"), ("G4", 2, "plain+direct")])
+                                             ("G3", 2, "nav+direct"), ("G4", 2, "plain+direct"), ("G3", 2, "nav+direct+lazybo"), ("G4", 2, "plain+lazybo")])
 def test_pipeline_equals_synchronous_search(oracle, name, depth, mode):
     """mode: "nav" (default) -- the next batch's MLP on a navigation stream beside the current scan; "plain" -- one lmi_search
     per batch; "twin" -- batches alternate between the handle and a clone of it (lmi_clone_view: same index memory);
-    "+direct" -- the search's last kernels store (dists, ids) straight into the pinned host buffers (no download kernel)."""
+    "+direct" -- the search's last kernels store (dists, ids) straight into the pinned host buffers (no download kernel);
+    "+lazybo" -- the bucket order is not downloaded with every batch but fetched from the slot's device buffer on demand."""
+    lazybo = mode.endswith("+lazybo")
+    mode = mode[:-len("+lazybo")] if lazybo else mode
     direct = mode.endswith("+direct")
     mode = mode.split("+")[0]
     from learnedmetricindex_amd import _capi
@@ -31,7 +34,7 @@ def test_pipeline_equals_synchronous_search(oracle, name, depth, mode):
     idx.set_buckets(Xs, g["data_prediction"][:, 0], L)
     nq = 96
     same = Xn.shape[1] == Xs.shape[1] and np.array_equal(Qn, Qs)
-    pipe = HostPipeline(idx, nq, Qn.shape[1], Qs.shape[1], nb, k, depth=depth, same_queries=same, want_bucket_order=True,
+    pipe = HostPipeline(idx, nq, Qn.shape[1], Qs.shape[1], nb, k, depth=depth, same_queries=same, want_bucket_order=not lazybo,
                         overlap_inference=mode == "nav", two_handles=mode == "twin", direct_out=direct)
     assert pipe.direct_out == direct
     assert pipe.calls_per_batch == (2 if mode == "nav" else 1) and len(pipe.handles) == (2 if mode == "twin" else 1)
