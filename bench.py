@@ -2,11 +2,12 @@
 """bench.py -- queries/sec of the LearnedMetricIndex query hot path on MI355X.
 
 A "step" = one LearnedIndex.search of a whole query batch: MLP forward -> top-n_buckets -> routing -> bucket
-scan -> merge.  The timed region is HOST-IN -> HOST-OUT: every step takes its batch from
-pinned host memory and leaves (dists, ids) in pinned host memory; the upload of batch i+1 and the download of
-batch i-1 overlap the search of batch i (learnedmetricindex_amd/pipeline.py).  The index is resident in HBM
-before the timed region (it is built once, like the reference's DataFrames).  The device-resident step
-(inputs/outputs already in HBM) is reported beside it as `resident`.
+scan -> merge.  The index is resident in HBM before the timed region (it is built once, like the reference's DataFrames).
+EXACTLY K steps are timed twice, each between barrier + synchronize: (i) with the query batches already in HBM and the results left
+there -- `value`, `ms_per_step`, `roofline`, `phases_ms` (`value_loop: "resident"`); (ii) HOST-IN -> HOST-OUT, the reference's own
+boundary: every step takes its batch from pinned host memory and leaves (dists, ids) in pinned host memory, the
+upload of batch i+1 and the MLP of batch i+1 overlap the search of batch i (learnedmetricindex_amd/pipeline.py) -- the PCIe-inclusive
+rate, reported beside it as `host_to_host` (`--value-loop host` makes it `value`, as rounds 1-4 did).
 Default workload = BASELINE.json configs[1]: 10M x 768 synthetic unit-norm vectors (LAION-10M shape),
 120 leaves, MLP-4 (768->512->120), top-4 buckets, 10k queries, 1 x MI355X.
 
@@ -168,7 +169,7 @@ class Workload:
 
     # ------------------------------------------------------------------------------------------------
     def run(self, steps, warmup, shard_inference=True, measure_resident=True):
-        """Times `steps` host-in -> host-out searches (pipelined) and, optionally, as many device-resident ones.
+        """Times `steps` host-in -> host-out searches (pipelined) and, optionally (main() picks `value` from these), as many device-resident ones.
         Returns a dict of raw measurements."""
         import torch
         import torch.distributed as dist
